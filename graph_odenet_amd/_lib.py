@@ -1,0 +1,103 @@
+"""ctypes binding of libgraphode.so (the C ABI declared in include/graphode.h).
+
+The library is the product: if it is missing, every op raises.  There is no
+eager/PyTorch fallback behind these calls.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (imported first so that libamdhip64 is torch's copy)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphode.so")
+
+GODE_MAX_TERMS = 8
+
+
+class LinComb(ctypes.Structure):
+    """Mirror of gode_lincomb_t."""
+    _fields_ = [("n", ctypes.c_int32),
+                ("coef", ctypes.c_float * GODE_MAX_TERMS),
+                ("ptr", ctypes.c_void_p * GODE_MAX_TERMS)]
+
+
+c_i64 = ctypes.c_int64
+c_p = ctypes.c_void_p
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+
+# name -> (restype, argtypes); also the list the symbol-export test walks.
+SIGNATURES = {
+    "gode_abi_version": (c_i, []),
+    "gode_error_string": (ctypes.c_char_p, [c_i]),
+    "gode_spmm_csr_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64,
+                                c_i64, c_i64, c_p, c_i, ctypes.POINTER(LinComb), c_p, c_p]),
+    "gode_lincomb_f32": (c_i, [c_p, ctypes.POINTER(LinComb), c_i64, c_p]),
+    "gode_rk_errnorm_scratch_bytes": (c_i64, []),
+    "gode_rk_errnorm_f32": (c_i, [c_p, c_p, c_p, ctypes.POINTER(LinComb), c_f, c_f, c_i64, c_p, c_p]),
+    "gode_rk_scaled_sumsq_f32": (c_i, [c_p, ctypes.POINTER(LinComb), c_p, c_f, c_f, c_i64, c_p, c_p]),
+    "gode_gn_time_gemm_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
+                                    c_p, c_i64, c_i, c_f, c_p, c_p]),
+    "gode_gemm_bwd_parts": (c_i64, [c_i64]),
+    "gode_gn_time_gemm_bwd_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p,
+                                        c_p, c_i64, c_i, c_p, c_f, c_p, c_p, c_p, c_p]),
+    "gode_wgrad_parts": (c_i64, [c_i64]),
+    "gode_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
+                             c_p, c_i64, c_i, c_p, c_p]),
+    "gode_reduce_parts_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
+    "gode_colsum_scratch_bytes": (c_i64, [c_i64, c_i64]),
+    "gode_colsum_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p, c_p]),
+}
+
+_lib = None
+
+
+class GraphodeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgraphode.so or raise; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GraphodeLibraryError(
+            "libgraphode.so not found at %s - build it with `python __graft_entry__.py` "
+            "(or `make -C graph_odenet_amd/csrc`). There is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gode_abi_version() != 1:
+        raise GraphodeLibraryError("libgraphode.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gode_error_string(rc)
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def lincomb(terms):
+    """terms: list of (coef, tensor) -> LinComb struct (keeps no references; caller keeps tensors alive)."""
+    lc = LinComb()
+    terms = [(c, t) for (c, t) in terms if t is not None]
+    if len(terms) > GODE_MAX_TERMS:
+        raise ValueError("too many lincomb terms")
+    lc.n = len(terms)
+    for j, (c, t) in enumerate(terms):
+        lc.coef[j] = float(c)
+        lc.ptr[j] = t.data_ptr()
+    return lc
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None

@@ -1,0 +1,81 @@
+// common.h — shared device helpers for libgraphode (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/graphode.h"
+
+#define GODE_WAVE 64
+
+// Device-side copy of gode_lincomb_t (passed by value as a kernel argument).
+struct LinComb {
+    int n;
+    float coef[GODE_MAX_TERMS];
+    const float* ptr[GODE_MAX_TERMS];
+};
+
+static inline LinComb make_lincomb(const gode_lincomb_t* h) {
+    LinComb lc;
+    lc.n = 0;
+    for (int j = 0; j < GODE_MAX_TERMS; ++j) { lc.coef[j] = 0.f; lc.ptr[j] = nullptr; }
+    if (h) {
+        lc.n = h->n;
+        for (int j = 0; j < h->n && j < GODE_MAX_TERMS; ++j) { lc.coef[j] = h->coef[j]; lc.ptr[j] = h->ptr[j]; }
+    }
+    return lc;
+}
+
+static inline int check_lincomb(const gode_lincomb_t* h, bool required) {
+    if (!h) return required ? GODE_E_NULLPTR : 0;
+    if (h->n < 0 || h->n > GODE_MAX_TERMS) return GODE_E_RANGE;
+    if (required && h->n == 0) return GODE_E_RANGE;
+    for (int j = 0; j < h->n; ++j) if (!h->ptr[j]) return GODE_E_NULLPTR;
+    return 0;
+}
+
+static inline bool lincomb_aligned16(const gode_lincomb_t* h) {
+    if (!h) return true;
+    for (int j = 0; j < h->n; ++j) if (((uintptr_t)h->ptr[j]) & 15) return false;
+    return true;
+}
+
+__device__ __forceinline__ float4 lc_load4(const LinComb& lc, int64_t idx) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < GODE_MAX_TERMS; ++j) {
+        if (j < lc.n) {
+            const float4 v = *reinterpret_cast<const float4*>(lc.ptr[j] + idx);
+            const float c = lc.coef[j];
+            r.x = fmaf(c, v.x, r.x); r.y = fmaf(c, v.y, r.y);
+            r.z = fmaf(c, v.z, r.z); r.w = fmaf(c, v.w, r.w);
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ float lc_load1(const LinComb& lc, int64_t idx) {
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < GODE_MAX_TERMS; ++j)
+        if (j < lc.n) r = fmaf(lc.coef[j], lc.ptr[j][idx], r);
+    return r;
+}
+
+// When the first coefficient is exactly 1 the first term is taken as-is so that
+// a one-term {1.0, y} combination reproduces y bit for bit.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+#define GODE_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

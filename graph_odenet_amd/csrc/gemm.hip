@@ -1,0 +1,704 @@
+// gemm.hip — dense part of the ODE function: S = [t | GroupNorm(x)] * W, its VJP and
+// the weight gradient, on fp32-input MFMA (v_mfma_f32_16x16x4_f32, exact fp32) — gfx950.
+//
+// Replaces GCN/models.py:175-177 (GroupNorm, time column, concat) + GCN/layers.py:70
+// (torch.mm) of the reference, and their autograd.
+//
+// Layout of the fast path (d_in = d_out = d in {16,32,64,128}, GroupNorm(min(32,d), d)):
+//   * W (without its time row) lives in LDS for the whole launch, row stride d+4 floats
+//     so that the two k-rows a 32-lane group reads fall on disjoint banks;
+//   * the x operand never goes through LDS: lane (r = lane&15, g = lane>>4) loads
+//     float4 x[row0+r][16j+4g .. +3]; these are exactly the B-operand values of the
+//     MFMA whose k-slot g carries k = 16j+4g+c, so the stage combination
+//     (y + h*sum a_j k_j), GroupNorm (a group of 4 channels = one float4) and the MFMA
+//     feed all happen in registers;
+//   * the product is formed transposed, D[n][row], so each lane ends with 4 consecutive
+//     output columns of one row -> one 16-byte store, and (in the VJP) one GroupNorm
+//     group per accumulator register quad.
+// Bounds: fwd/bwd-data read + write one N x d operand each (HBM) against
+// 2*N*d*d flop on the fp32 MFMA pipe (157 TFLOP/s peak) - near the ridge at d=128.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxBlocks = 512;   // 2 blocks per CU
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// GroupNorm statistics of the 4 values a lane holds.  CG = channels per group.
+// CG = 1,2,4: the group is inside the float4.  CG = 8,16: spread over lane groups
+// g (xor 16 / xor 32).  mean/rstd are returned per component.
+template <int CG>
+__device__ __forceinline__ void gn_stats(const float4 x, float eps, float4& mean, float4& rstd) {
+    if (CG == 1) {
+        mean = x;
+        const float r = 1.0f / sqrtf(eps);
+        rstd = make_float4(r, r, r, r);
+    } else if (CG == 2) {
+        const float m0 = (x.x + x.y) * 0.5f, m1 = (x.z + x.w) * 0.5f;
+        const float v0 = ((x.x - m0) * (x.x - m0) + (x.y - m0) * (x.y - m0)) * 0.5f;
+        const float v1 = ((x.z - m1) * (x.z - m1) + (x.w - m1) * (x.w - m1)) * 0.5f;
+        const float r0 = 1.0f / sqrtf(v0 + eps), r1 = 1.0f / sqrtf(v1 + eps);
+        mean = make_float4(m0, m0, m1, m1);
+        rstd = make_float4(r0, r0, r1, r1);
+    } else {
+        float s = (x.x + x.y) + (x.z + x.w);
+        if (CG >= 8) s += __shfl_xor(s, 16, 64);
+        if (CG >= 16) s += __shfl_xor(s, 32, 64);
+        const float m = s * (1.0f / CG);
+        const float dx = x.x - m, dy = x.y - m, dz = x.z - m, dw = x.w - m;
+        float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        if (CG >= 8) q += __shfl_xor(q, 16, 64);
+        if (CG >= 16) q += __shfl_xor(q, 32, 64);
+        const float r = 1.0f / sqrtf(q * (1.0f / CG) + eps);
+        mean = make_float4(m, m, m, m);
+        rstd = make_float4(r, r, r, r);
+    }
+}
+
+// y = x*scale + shift with scale = rstd*gamma, shift = beta - mean*scale (ATen's CPU form,
+// aten/src/ATen/native/cpu/group_norm_kernel.cpp), rounded step by step (no contraction).
+__device__ __forceinline__ float gn_apply1(float x, float mean, float rstd, float gam, float bet) {
+    const float scale = __fmul_rn(rstd, gam);
+    const float shift = __fsub_rn(bet, __fmul_rn(mean, scale));
+    return __fadd_rn(__fmul_rn(x, scale), shift);
+}
+
+template <int CG>
+__device__ __forceinline__ float4 gn_forward(const float4 x, float eps, const float* gamma, const float* beta, int c0) {
+    if (CG == 0) return x;
+    float4 mean, rstd;
+    gn_stats<CG>(x, eps, mean, rstd);
+    float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gamma) gm = ld4(gamma + c0);
+    if (beta) bt = ld4(beta + c0);
+    return make_float4(gn_apply1(x.x, mean.x, rstd.x, gm.x, bt.x), gn_apply1(x.y, mean.y, rstd.y, gm.y, bt.y),
+                       gn_apply1(x.z, mean.z, rstd.z, gm.z, bt.z), gn_apply1(x.w, mean.w, rstd.w, gm.w, bt.w));
+}
+
+template <int CG>
+__device__ __forceinline__ float group_mean4(float4 v) {   // mean over the lane's group (CG >= 4)
+    float s = (v.x + v.y) + (v.z + v.w);
+    if (CG >= 8) s += __shfl_xor(s, 16, 64);
+    if (CG >= 16) s += __shfl_xor(s, 32, 64);
+    return s * (1.0f / CG);
+}
+
+
+// One 16-row panel: acc[tt] += sum_k Wlds[k][16tt + r] * xb[k]   (k-slot g of step (j,c) carries k = 16j+4g+c).
+// The A operands of step s+1 are read from LDS before the MFMAs of step s are issued, and a
+// scheduling barrier per step keeps hipcc from hoisting all 4*NJ*NJ LDS reads to the top (spills).
+template <int NJ>
+__device__ __forceinline__ void mfma_panel(const float* wl /* Wlds + 4g*LDW + r */, const float4 (&xv)[NJ], f32x4 (&acc)[NJ]) {
+    constexpr int LDW = 16 * NJ + 4;
+    float a_cur[NJ], a_nxt[NJ];
+#pragma unroll
+    for (int tt = 0; tt < NJ; ++tt) a_cur[tt] = wl[16 * tt];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float xb[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int s = 4 * j + c;
+            if (s + 1 < 4 * NJ) {
+                const int jn = (s + 1) / 4, cn = (s + 1) % 4;
+#pragma unroll
+                for (int tt = 0; tt < NJ; ++tt) a_nxt[tt] = wl[(16 * jn + cn) * LDW + 16 * tt];
+            }
+#pragma unroll
+            for (int tt = 0; tt < NJ; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[tt], xb[c], acc[tt], 0, 0, 0);
+#pragma unroll
+            for (int tt = 0; tt < NJ; ++tt) a_cur[tt] = a_nxt[tt];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// forward:  S[row, :] = t*W[0,:] + GN(x[row,:]) * W[1:, :]
+// ---------------------------------------------------------------------------------
+template <int NJ, int CG>   // d = 16*NJ
+__global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_rows, float eps,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ W, int has_time, float t,
+                                                             float* __restrict__ S)
+{
+    constexpr int D = 16 * NJ;
+    constexpr int LDW = D + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;
+    for (int idx = threadIdx.x; idx < D * D; idx += 256) {
+        const int k = idx / D, n = idx % D;
+        Ws[k * LDW + n] = W[(int64_t)(k + has_time) * D + n];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const int n_tiles = (n_rows + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 16 + r;
+        const bool valid = row < n_rows;
+        float4 xv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) xv[j] = lc_load4(xin, (int64_t)row * D + 16 * j + 4 * g);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xv[j] = gn_forward<CG>(xv[j], eps, gamma, beta, 16 * j + 4 * g);
+
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            if (has_time) {
+                const float4 w0 = ld4(W + 16 * tt + 4 * g);
+                acc[tt] = (f32x4){t * w0.x, t * w0.y, t * w0.z, t * w0.w};
+            } else {
+                acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        mfma_panel<NJ>(Ws + 4 * g * LDW + r, xv, acc);
+        if (valid) {
+#pragma unroll
+            for (int tt = 0; tt < NJ; ++tt)
+                *reinterpret_cast<float4*>(S + (int64_t)row * D + 16 * tt + 4 * g) =
+                    make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// VJP w.r.t. x:  dxn = dS * W1^T ; dx = GN'(x)^T dxn ; out = out_scale*dx
+// per-wave partial sums of dgamma / dbeta.
+// ---------------------------------------------------------------------------------
+template <int NJ, int CG>
+__global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_rows, float eps,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ W, int has_time,
+                                                             const float* __restrict__ dS, float out_scale,
+                                                             float* __restrict__ dx,
+                                                             float* __restrict__ dgamma_part,
+                                                             float* __restrict__ dbeta_part)
+{
+    constexpr int D = 16 * NJ;
+    constexpr int LDW = D + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wt = smem;   // Wt[n][i] = W1[i][n]
+    for (int idx = threadIdx.x; idx < D * D; idx += 256) {
+        const int i = idx / D, n = idx % D;
+        Wt[n * LDW + i] = W[(int64_t)(i + has_time) * D + n];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const int n_tiles = (n_rows + 15) / 16;
+    float4 dgs[NJ], dbs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { dgs[j] = make_float4(0.f, 0.f, 0.f, 0.f); dbs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 16 + r;
+        const bool valid = row < n_rows;
+        float4 gv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) gv[j] = ld4(dS + (int64_t)row * D + 16 * j + 4 * g);
+        }
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_panel<NJ>(Wt + 4 * g * LDW + r, gv, acc);
+        // acc[tt] = dxn[row][16tt+4g .. +3]
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            const int c0 = 16 * tt + 4 * g;
+            float4 dy = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+            float4 out = dy;
+            if (CG != 0) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) x = lc_load4(xin, (int64_t)row * D + c0);
+                float4 mean, rstd;
+                gn_stats<CG>(x, eps, mean, rstd);
+                const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y,
+                                              (x.z - mean.z) * rstd.z, (x.w - mean.w) * rstd.w);
+                float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (gamma) gm = ld4(gamma + c0);
+                const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+                if (valid) {
+                    dgs[tt].x += dy.x * xh.x; dgs[tt].y += dy.y * xh.y; dgs[tt].z += dy.z * xh.z; dgs[tt].w += dy.w * xh.w;
+                    dbs[tt].x += dy.x; dbs[tt].y += dy.y; dbs[tt].z += dy.z; dbs[tt].w += dy.w;
+                }
+                if (CG == 1) {
+                    out = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (CG == 2) {
+                    const float a0 = (dh.x + dh.y) * 0.5f, a1 = (dh.z + dh.w) * 0.5f;
+                    const float b0 = (dh.x * xh.x + dh.y * xh.y) * 0.5f, b1 = (dh.z * xh.z + dh.w * xh.w) * 0.5f;
+                    out = make_float4(rstd.x * (dh.x - a0 - xh.x * b0), rstd.y * (dh.y - a0 - xh.y * b0),
+                                      rstd.z * (dh.z - a1 - xh.z * b1), rstd.w * (dh.w - a1 - xh.w * b1));
+                } else {
+                    const float a = group_mean4<(CG < 4 ? 4 : CG)>(dh);
+                    const float b = group_mean4<(CG < 4 ? 4 : CG)>(make_float4(dh.x * xh.x, dh.y * xh.y, dh.z * xh.z, dh.w * xh.w));
+                    out = make_float4(rstd.x * (dh.x - a - xh.x * b), rstd.y * (dh.y - a - xh.y * b),
+                                      rstd.z * (dh.z - a - xh.z * b), rstd.w * (dh.w - a - xh.w * b));
+                }
+            }
+            if (valid)
+                *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) =
+                    make_float4(out_scale * out.x, out_scale * out.y, out_scale * out.z, out_scale * out.w);
+        }
+    }
+    if (CG != 0 && dgamma_part) {
+        const int part = blockIdx.x * 4 + wave;
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            float4 a = dgs[tt], b = dbs[tt];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+                b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+            }
+            if (r == 0) {
+                *reinterpret_cast<float4*>(dgamma_part + (int64_t)part * D + 16 * tt + 4 * g) = a;
+                *reinterpret_cast<float4*>(dbeta_part + (int64_t)part * D + 16 * tt + 4 * g) = b;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// weight gradient: dW[has_time + i][n] = sum_rows xn[row][i] * dS[row][n]; row 0 (has_time) = sum_rows dS[row][n]
+// (the gradient w.r.t. a unit time column: the caller scales it by t and uses it for dL/dt)
+// one block partial per block.
+// ---------------------------------------------------------------------------------
+template <int NJ, int CG>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(LinComb xin, int n_rows, float eps,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ dS, int has_time,
+                                                       float* __restrict__ dW_part)
+{
+    constexpr int D = 16 * NJ;
+    constexpr int LD = D + 16;
+    constexpr int R = 32;                       // rows per staged tile
+    constexpr int TPR = D / 4;                  // threads per row (float4 each)
+    constexpr int RPP = 256 / TPR;              // rows per pass
+    constexpr int ITW = (NJ >= 4) ? NJ / 4 : 1; // i-tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;            // [R][LD]
+    float* Gs = smem + R * LD;   // [R][LD]
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const int trow = threadIdx.x / TPR, tcol = (threadIdx.x % TPR) * 4;
+    const bool wave_active = wave * ITW < NJ;
+
+    f32x4 acc[ITW][NJ];
+#pragma unroll
+    for (int a = 0; a < ITW; ++a)
+#pragma unroll
+        for (int b = 0; b < NJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int n_tiles = (n_rows + R - 1) / R;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        for (int rr = trow; rr < R; rr += RPP) {
+            const int row = tile * R + rr;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), gg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < n_rows) {
+                x = lc_load4(xin, (int64_t)row * D + tcol);
+                gg = ld4(dS + (int64_t)row * D + tcol);
+            }
+            // CG in {0,1,2,4}: group inside the float4
+            x = gn_forward<CG>(x, eps, gamma, beta, tcol);
+            if (row >= n_rows) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Xs + rr * LD + tcol) = x;
+            *reinterpret_cast<float4*>(Gs + rr * LD + tcol) = gg;
+            csum.x += gg.x; csum.y += gg.y; csum.z += gg.z; csum.w += gg.w;
+        }
+        __syncthreads();
+        if (wave_active) {
+#pragma unroll
+            for (int kb = 0; kb < R; kb += 4) {
+                float av[ITW], bv[NJ];
+#pragma unroll
+                for (int a = 0; a < ITW; ++a) av[a] = Xs[(kb + g) * LD + 16 * (wave * ITW + a) + r];
+#pragma unroll
+                for (int b = 0; b < NJ; ++b) bv[b] = Gs[(kb + g) * LD + 16 * b + r];
+#pragma unroll
+                for (int a = 0; a < ITW; ++a)
+#pragma unroll
+                    for (int b = 0; b < NJ; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    float* out = dW_part + (int64_t)blockIdx.x * (D + has_time) * D;
+    if (wave_active) {
+#pragma unroll
+        for (int a = 0; a < ITW; ++a)
+#pragma unroll
+            for (int b = 0; b < NJ; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * (wave * ITW + a) + 4 * g + q;
+                    out[(int64_t)(i + has_time) * D + 16 * b + r] = acc[a][b][q];
+                }
+    }
+    if (has_time) {
+        __syncthreads();
+        float* red = smem;   // [RPP][D]
+        *reinterpret_cast<float4*>(red + trow * D + tcol) = csum;
+        __syncthreads();
+        if (threadIdx.x < D) {
+            float s = 0.f;
+            for (int p = 0; p < RPP; ++p) s += red[p * D + threadIdx.x];
+            out[threadIdx.x] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// generic fallbacks (any d_in, d_out, groups): correct, not tuned.
+// block = 256 threads, RB rows per block pass, rows staged (normalised) in LDS.
+// ---------------------------------------------------------------------------------
+constexpr int RB = 8;
+
+__device__ __forceinline__ void stage_rows_gn(float* xs, float* stat, const LinComb& xin, int row0, int n_rows,
+                                              int d_in, int groups, float eps, const float* gamma,
+                                              const float* beta, bool apply)
+{
+    // xs[RB][d_in] raw x; stat[RB][groups][2] = mean, rstd
+    for (int idx = threadIdx.x; idx < RB * d_in; idx += 256) {
+        const int rr = idx / d_in, c = idx % d_in;
+        const int row = row0 + rr;
+        xs[idx] = row < n_rows ? lc_load1(xin, (int64_t)row * d_in + c) : 0.f;
+    }
+    __syncthreads();
+    if (groups > 0) {
+        const int cg = d_in / groups;
+        for (int idx = threadIdx.x; idx < RB * groups; idx += 256) {
+            const int rr = idx / groups, gi = idx % groups;
+            const float* p = xs + rr * d_in + gi * cg;
+            float m = 0.f;
+            for (int c = 0; c < cg; ++c) m += p[c];
+            m /= cg;
+            float v = 0.f;
+            for (int c = 0; c < cg; ++c) v += (p[c] - m) * (p[c] - m);
+            v /= cg;
+            stat[idx * 2] = m;
+            stat[idx * 2 + 1] = 1.0f / sqrtf(v + eps);
+        }
+        __syncthreads();
+        if (apply) {
+            for (int idx = threadIdx.x; idx < RB * d_in; idx += 256) {
+                const int rr = idx / d_in, c = idx % d_in;
+                const int gi = c / cg;
+                const float m = stat[(rr * groups + gi) * 2], rs = stat[(rr * groups + gi) * 2 + 1];
+                xs[idx] = gn_apply1(xs[idx], m, rs, gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_gemm_fwd_generic(LinComb xin, int n_rows, int d_in, int groups, float eps,
+                                                           const float* gamma, const float* beta, const float* W,
+                                                           int d_out, int has_time, float t, float* S)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* stat = smem + RB * d_in;
+    const int n_blk = (n_rows + RB - 1) / RB;
+    for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+        __syncthreads();
+        stage_rows_gn(xs, stat, xin, blk * RB, n_rows, d_in, groups, eps, gamma, beta, true);
+        for (int idx = threadIdx.x; idx < RB * d_out; idx += 256) {
+            const int rr = idx / d_out, n = idx % d_out;
+            const int row = blk * RB + rr;
+            if (row >= n_rows) continue;
+            float acc = has_time ? t * W[n] : 0.f;
+            for (int k = 0; k < d_in; ++k) acc = fmaf(xs[rr * d_in + k], W[(int64_t)(k + has_time) * d_out + n], acc);
+            S[(int64_t)row * d_out + n] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_rows, int d_in, int groups, float eps,
+                                                           const float* gamma, const float* W, int d_out,
+                                                           int has_time, const float* dS, float out_scale, float* dx,
+                                                           float* dgamma_part, float* dbeta_part)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                       // raw x  [RB][d_in]
+    float* stat = xs + RB * d_in;           // [RB][groups][2]
+    float* dy = stat + RB * (groups > 0 ? groups : 1) * 2;   // dxn [RB][d_in]
+    float* red = dy + RB * d_in;            // [RB][groups][2] group means of dh, dh*xh
+    const int n_blk = (n_rows + RB - 1) / RB;
+    for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+        __syncthreads();
+        stage_rows_gn(xs, stat, xin, blk * RB, n_rows, d_in, groups, eps, nullptr, nullptr, false);
+        for (int idx = threadIdx.x; idx < RB * d_in; idx += 256) {
+            const int rr = idx / d_in, i = idx % d_in;
+            const int row = blk * RB + rr;
+            float acc = 0.f;
+            if (row < n_rows)
+                for (int n = 0; n < d_out; ++n)
+                    acc = fmaf(dS[(int64_t)row * d_out + n], W[(int64_t)(i + has_time) * d_out + n], acc);
+            dy[idx] = acc;
+        }
+        __syncthreads();
+        if (groups > 0) {
+            const int cg = d_in / groups;
+            for (int idx = threadIdx.x; idx < RB * groups; idx += 256) {
+                const int rr = idx / groups, gi = idx % groups;
+                const float m = stat[idx * 2], rs = stat[idx * 2 + 1];
+                float a = 0.f, b = 0.f;
+                for (int c = 0; c < cg; ++c) {
+                    const int cc = gi * cg + c;
+                    const float dh = dy[rr * d_in + cc] * (gamma ? gamma[cc] : 1.f);
+                    a += dh; b += dh * (xs[rr * d_in + cc] - m) * rs;
+                }
+                red[idx * 2] = a / cg; red[idx * 2 + 1] = b / cg;
+            }
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < RB * d_in; idx += 256) {
+                const int rr = idx / d_in, c = idx % d_in;
+                const int row = blk * RB + rr;
+                if (row >= n_rows) continue;
+                const int gi = c / cg;
+                const float m = stat[(rr * groups + gi) * 2], rs = stat[(rr * groups + gi) * 2 + 1];
+                const float xh = (xs[idx] - m) * rs;
+                const float dh = dy[idx] * (gamma ? gamma[c] : 1.f);
+                dx[(int64_t)row * d_in + c] = out_scale * rs * (dh - red[(rr * groups + gi) * 2] - xh * red[(rr * groups + gi) * 2 + 1]);
+            }
+            if (dgamma_part) {
+                // per-block partial over the block's rows (accumulated across the grid-stride loop)
+                for (int c = threadIdx.x; c < d_in; c += 256) {
+                    const int gi = c / cg;
+                    float sg = 0.f, sb = 0.f;
+                    for (int rr = 0; rr < RB; ++rr) {
+                        if (blk * RB + rr >= n_rows) break;
+                        const float m = stat[(rr * groups + gi) * 2], rs = stat[(rr * groups + gi) * 2 + 1];
+                        sg += dy[rr * d_in + c] * (xs[rr * d_in + c] - m) * rs;
+                        sb += dy[rr * d_in + c];
+                    }
+                    dgamma_part[(int64_t)blockIdx.x * d_in + c] += sg;
+                    dbeta_part[(int64_t)blockIdx.x * d_in + c] += sb;
+                }
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < RB * d_in; idx += 256) {
+                const int rr = idx / d_in, c = idx % d_in;
+                const int row = blk * RB + rr;
+                if (row < n_rows) dx[(int64_t)row * d_in + c] = out_scale * dy[idx];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_generic(LinComb xin, int n_rows, int d_in, int groups, float eps,
+                                                     const float* gamma, const float* beta, const float* dS,
+                                                     int d_out, int has_time, float* dW_part)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;
+    float* stat = smem + RB * d_in;
+    const int n_blk = (n_rows + RB - 1) / RB;
+    const int K = d_in + has_time;
+    float* out = dW_part + (int64_t)blockIdx.x * K * d_out;
+    for (int idx = threadIdx.x; idx < K * d_out; idx += 256) out[idx] = 0.f;
+    for (int blk = blockIdx.x; blk < n_blk; blk += gridDim.x) {
+        __syncthreads();
+        stage_rows_gn(xs, stat, xin, blk * RB, n_rows, d_in, groups, eps, gamma, beta, true);
+        const int nr = (n_rows - blk * RB) < RB ? (n_rows - blk * RB) : RB;
+        for (int idx = threadIdx.x; idx < K * d_out; idx += 256) {
+            const int i = idx / d_out, n = idx % d_out;
+            float acc = 0.f;
+            for (int rr = 0; rr < nr; ++rr) {
+                const float a = (has_time && i == 0) ? 1.0f : xs[rr * d_in + (i - has_time)];
+                acc = fmaf(a, dS[(int64_t)(blk * RB + rr) * d_out + n], acc);
+            }
+            out[idx] += acc;
+        }
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+int fast_cg(int64_t d_in, int64_t d_out, int32_t groups) {
+    // returns CG (0,1,2,4) when the MFMA fast path applies, else -1
+    if (d_in != d_out) return -1;
+    if (d_in != 16 && d_in != 32 && d_in != 64 && d_in != 128) return -1;
+    if (groups == 0) return 0;
+    if (d_in % groups) return -1;
+    const int64_t cg = d_in / groups;
+    if (cg == 1 || cg == 2 || cg == 4) return (int)cg;
+    return -1;
+}
+
+int64_t fwd_blocks(int64_t n_rows) {
+    int64_t b = ((n_rows + 15) / 16 + 3) / 4;
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return b;
+}
+int64_t wgrad_blocks(int64_t n_rows) {
+    int64_t b = (n_rows + 31) / 32;
+    if (b < 1) b = 1;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    return b;
+}
+
+}  // namespace
+
+#define GODE_DISPATCH_NJ_CG(NJV, CGV, MACRO)                                        \
+    if (nj == NJV && cg == CGV) { MACRO(NJV, CGV) }
+
+#define GODE_DISPATCH_ALL(MACRO)                                                    \
+    GODE_DISPATCH_NJ_CG(1, 0, MACRO) GODE_DISPATCH_NJ_CG(1, 1, MACRO)               \
+    GODE_DISPATCH_NJ_CG(2, 0, MACRO) GODE_DISPATCH_NJ_CG(2, 1, MACRO)               \
+    GODE_DISPATCH_NJ_CG(4, 0, MACRO) GODE_DISPATCH_NJ_CG(4, 2, MACRO)               \
+    GODE_DISPATCH_NJ_CG(8, 0, MACRO) GODE_DISPATCH_NJ_CG(8, 4, MACRO)               \
+    GODE_DISPATCH_NJ_CG(1, 2, MACRO) GODE_DISPATCH_NJ_CG(1, 4, MACRO)               \
+    GODE_DISPATCH_NJ_CG(2, 2, MACRO) GODE_DISPATCH_NJ_CG(2, 4, MACRO)               \
+    GODE_DISPATCH_NJ_CG(4, 1, MACRO) GODE_DISPATCH_NJ_CG(4, 4, MACRO)               \
+    GODE_DISPATCH_NJ_CG(8, 1, MACRO) GODE_DISPATCH_NJ_CG(8, 2, MACRO)
+
+static int check_common(const gode_lincomb_t* xin, int64_t n_rows, int64_t d_in, int32_t groups, int64_t d_out) {
+    if (n_rows < 0 || d_in <= 0 || d_out <= 0 || groups < 0) return GODE_E_SHAPE;
+    if (groups > 0 && d_in % groups) return GODE_E_SHAPE;
+    if (n_rows > INT32_MAX || d_in > 2048 || d_out > 65536) return GODE_E_RANGE;
+    return check_lincomb(xin, true);
+}
+
+extern "C" int gode_gn_time_gemm_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d_in, int32_t groups,
+                                     float eps, const float* gamma, const float* beta, const float* W,
+                                     int64_t d_out, int has_time, float t, float* S, void* stream)
+{
+    int rc = check_common(xin, n_rows, d_in, groups, d_out); if (rc) return rc;
+    if (n_rows == 0) return 0;
+    if (!W || !S) return GODE_E_NULLPTR;
+    has_time = has_time ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    LinComb lc = make_lincomb(xin);
+    const int cg = fast_cg(d_in, d_out, groups);
+    const bool al = lincomb_aligned16(xin) && !(((uintptr_t)S) & 15) && !(((uintptr_t)W) & 15) &&
+                    (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15));
+    if (cg >= 0 && al) {
+        const int nj = (int)(d_in / 16);
+        const size_t lds = (size_t)d_in * (d_in + 4) * sizeof(float);
+        const int64_t blocks = fwd_blocks(n_rows);
+#define GODE_FWD(NJV, CGV)                                                                          \
+        { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
+          hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
+                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S);                 \
+          GODE_LAUNCH_CHECK(); return 0; }
+        GODE_DISPATCH_ALL(GODE_FWD)
+#undef GODE_FWD
+    }
+    const size_t lds = ((size_t)RB * d_in + (size_t)RB * (groups > 0 ? groups : 1) * 2) * sizeof(float);
+    rc = set_lds(gn_gemm_fwd_generic, lds); if (rc) return rc;
+    int64_t blocks = (n_rows + RB - 1) / RB; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gn_gemm_fwd_generic, dim3((unsigned)blocks), dim3(256), lds, s, lc, (int)n_rows, (int)d_in,
+                       (int)groups, eps, gamma, beta, W, (int)d_out, has_time, t, S);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gode_gemm_bwd_parts(int64_t n_rows) {
+    // upper bound valid for both the MFMA path (blocks*4 wave partials) and the generic path
+    int64_t a = fwd_blocks(n_rows) * 4;
+    int64_t b = (n_rows + RB - 1) / RB; if (b > 2048) b = 2048; if (b < 1) b = 1;
+    return a > b ? a : b;
+}
+
+extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d_in, int32_t groups,
+                                         float eps, const float* gamma, const float* W, int64_t d_out,
+                                         int has_time, const float* dS, float out_scale, float* dx,
+                                         float* dgamma_part, float* dbeta_part, void* stream)
+{
+    int rc = check_common(xin, n_rows, d_in, groups, d_out); if (rc) return rc;
+    if (n_rows == 0) return 0;
+    if (!W || !dS || !dx) return GODE_E_NULLPTR;
+    if ((dgamma_part == nullptr) != (dbeta_part == nullptr)) return GODE_E_NULLPTR;
+    has_time = has_time ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    LinComb lc = make_lincomb(xin);
+    const int64_t n_part = gode_gemm_bwd_parts(n_rows);
+    if (dgamma_part && groups > 0) {
+        hipError_t e = hipMemsetAsync(dgamma_part, 0, (size_t)n_part * d_in * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(dbeta_part, 0, (size_t)n_part * d_in * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int cg = fast_cg(d_in, d_out, groups);
+    const bool al = lincomb_aligned16(xin) && !(((uintptr_t)dS) & 15) && !(((uintptr_t)dx) & 15) &&
+                    (!gamma || !(((uintptr_t)gamma) & 15)) &&
+                    (!dgamma_part || (!(((uintptr_t)dgamma_part) & 15) && !(((uintptr_t)dbeta_part) & 15)));
+    if (cg >= 0 && al) {
+        const int nj = (int)(d_in / 16);
+        const size_t lds = (size_t)d_in * (d_in + 4) * sizeof(float);
+        const int64_t blocks = fwd_blocks(n_rows);
+#define GODE_BWD(NJV, CGV)                                                                          \
+        { rc = set_lds(gn_gemm_bwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
+          hipLaunchKernelGGL((gn_gemm_bwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
+                             lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, dx, dgamma_part, dbeta_part); \
+          GODE_LAUNCH_CHECK(); return 0; }
+        GODE_DISPATCH_ALL(GODE_BWD)
+#undef GODE_BWD
+    }
+    const size_t g2 = (size_t)RB * (groups > 0 ? groups : 1) * 2;
+    const size_t lds = ((size_t)RB * d_in * 2 + g2 * 2) * sizeof(float);
+    rc = set_lds(gn_gemm_bwd_generic, lds); if (rc) return rc;
+    int64_t blocks = (n_rows + RB - 1) / RB; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gn_gemm_bwd_generic, dim3((unsigned)blocks), dim3(256), lds, s, lc, (int)n_rows, (int)d_in,
+                       (int)groups, eps, gamma, W, (int)d_out, has_time, dS, out_scale, dx, dgamma_part, dbeta_part);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gode_wgrad_parts(int64_t n_rows) {
+    return wgrad_blocks(n_rows);
+}
+
+extern "C" int gode_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d_in, int32_t groups, float eps,
+                              const float* gamma, const float* beta, const float* dS, int64_t d_out, int has_time,
+                              float* dW_part, void* stream)
+{
+    int rc = check_common(xin, n_rows, d_in, groups, d_out); if (rc) return rc;
+    if (!dW_part || (n_rows > 0 && !dS)) return GODE_E_NULLPTR;
+    has_time = has_time ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    LinComb lc = make_lincomb(xin);
+    const int64_t blocks = wgrad_blocks(n_rows);
+    const int cg = fast_cg(d_in, d_out, groups);
+    const bool al = lincomb_aligned16(xin) && !(((uintptr_t)dS) & 15) &&
+                    (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15));
+    if (cg >= 0 && al) {
+        const int nj = (int)(d_in / 16);
+        const size_t lds = (size_t)2 * 32 * (d_in + 16) * sizeof(float);
+#define GODE_WG(NJV, CGV)                                                                           \
+        { rc = set_lds(wgrad_kernel<NJV, CGV>, lds); if (rc) return rc;                             \
+          hipLaunchKernelGGL((wgrad_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s,   \
+                             lc, (int)n_rows, eps, gamma, beta, dS, has_time, dW_part);             \
+          GODE_LAUNCH_CHECK(); return 0; }
+        GODE_DISPATCH_ALL(GODE_WG)
+#undef GODE_WG
+    }
+    const size_t lds = ((size_t)RB * d_in + (size_t)RB * (groups > 0 ? groups : 1) * 2) * sizeof(float);
+    rc = set_lds(wgrad_generic, lds); if (rc) return rc;
+    hipLaunchKernelGGL(wgrad_generic, dim3((unsigned)blocks), dim3(256), lds, s, lc, (int)n_rows, (int)d_in,
+                       (int)groups, eps, gamma, beta, dS, (int)d_out, has_time, dW_part);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,203 @@
+// rk.hip — Runge-Kutta elementwise steps and reductions (gfx950).
+//
+// These replace the tensor arithmetic torchdiffeq performs between two calls of
+// the ODE function (call site GCN/models.py:192 of the reference): stage input
+// y + h*sum(a_ij k_j), solution combine y + h*sum(b_i k_i), the dopri5 error
+// ratio and the initial-step norms.  One pass over each operand, 16 B per lane.
+// Bound: HBM.  Algorithmic bytes: (n_terms + 1) * n * 4 for gode_lincomb_f32.
+#include "common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void lincomb4_kernel(float* out, LinComb lc, int64_t n4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const float4 r = lc_load4(lc, i * 4);
+        *reinterpret_cast<float4*>(out + i * 4) = r;
+    }
+}
+__global__ __launch_bounds__(256) void lincomb1_kernel(float* out, LinComb lc, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = lc_load1(lc, i);
+}
+
+__device__ __forceinline__ void block_reduce_store(double v, double* part) {
+    __shared__ double sm[4];
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// MODE 0: dopri5 error ratio, tol = atol + rtol*max(|y0|,|y1|)
+// MODE 1: scaled norm, tol = atol + rtol*|y0|
+template <int MODE>
+__global__ __launch_bounds__(256) void ratio_sumsq_kernel(double* part, LinComb lc, const float* y0,
+                                                          const float* y1, float rtol, float atol, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double s = 0.0;
+    for (; i < n; i += stride) {
+        const float e = lc_load1(lc, i);
+        float m = fabsf(y0[i]);
+        if (MODE == 0) m = fmaxf(m, fabsf(y1[i]));
+        const float r = e / (atol + rtol * m);
+        s += (double)r * (double)r;
+    }
+    block_reduce_store(s, part);
+}
+
+__global__ __launch_bounds__(256) void final_sum_kernel(double* out, const double* part, int nparts) {
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+__global__ __launch_bounds__(256) void reduce_parts_kernel(float* out, const float* part, int64_t n_part,
+                                                           int64_t len, float scale, int accumulate) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= len) return;
+    float s = 0.f;
+    for (int64_t p = 0; p < n_part; ++p) s += part[p * len + j];
+    s *= scale;
+    out[j] = accumulate ? out[j] + s : s;
+}
+
+// column sums, stage 1: block b sums rows [b*rpb, (b+1)*rpb) -> part[b][d]
+__global__ __launch_bounds__(256) void colsum_kernel(float* part, const float* X, int64_t n_rows, int d, int64_t rpb) {
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = r0 + rpb < n_rows ? r0 + rpb : n_rows;
+    // thread t owns column c = t % dpad, row phase t / dpad
+    for (int c = threadIdx.x; c < d; c += 256) part[(int64_t)blockIdx.x * d + c] = 0.f;
+    __syncthreads();
+    if (d <= 256) {
+        const int lanes_per_row = d;              // threads covering one row
+        const int rows_par = 256 / lanes_per_row; // rows processed concurrently
+        const int c = threadIdx.x % lanes_per_row;
+        const int ph = threadIdx.x / lanes_per_row;
+        float s = 0.f;
+        if (ph < rows_par)
+            for (int64_t r = r0 + ph; r < r1; r += rows_par) s += X[r * d + c];
+        __shared__ float sm[256];
+        sm[threadIdx.x] = (ph < rows_par) ? s : 0.f;
+        __syncthreads();
+        if (ph == 0) {
+            float t = 0.f;
+            for (int p = 0; p < rows_par; ++p) t += sm[p * lanes_per_row + c];
+            part[(int64_t)blockIdx.x * d + c] = t;
+        }
+    } else {
+        for (int c = threadIdx.x; c < d; c += 256) {
+            float s = 0.f;
+            for (int64_t r = r0; r < r1; ++r) s += X[r * d + c];
+            part[(int64_t)blockIdx.x * d + c] = s;
+        }
+    }
+}
+
+int red_blocks(int64_t n) {
+    int64_t b = (n + 1023) / 1024;
+    if (b < 1) b = 1;
+    if (b > RED_BLOCKS) b = RED_BLOCKS;
+    return (int)b;
+}
+
+int64_t colsum_blocks(int64_t n_rows) {
+    int64_t b = (n_rows + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return b;
+}
+
+}  // namespace
+
+extern "C" int gode_lincomb_f32(float* out, const gode_lincomb_t* lc, int64_t n, void* stream) {
+    if (n < 0) return GODE_E_SHAPE;
+    if (n == 0) return 0;
+    if (!out) return GODE_E_NULLPTR;
+    int rc = check_lincomb(lc, true); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    LinComb d = make_lincomb(lc);
+    if (n % 4 == 0 && !(((uintptr_t)out) & 15) && lincomb_aligned16(lc)) {
+        const int64_t n4 = n / 4;
+        int64_t blocks = (n4 + 255) / 256; if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(lincomb4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, d, n4);
+    } else {
+        int64_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(lincomb1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, d, n);
+    }
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gode_rk_errnorm_scratch_bytes(void) { return (int64_t)RED_BLOCKS * sizeof(double); }
+
+extern "C" int gode_rk_errnorm_f32(double* out, const float* y0, const float* y1, const gode_lincomb_t* elc,
+                                   float rtol, float atol, int64_t n, void* scratch, void* stream) {
+    if (n <= 0) return GODE_E_SHAPE;
+    if (!out || !y0 || !y1 || !scratch) return GODE_E_NULLPTR;
+    int rc = check_lincomb(elc, true); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(ratio_sumsq_kernel<0>, dim3(nb), dim3(256), 0, s, (double*)scratch, make_lincomb(elc),
+                       y0, y1, rtol, atol, n);
+    GODE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, out, (const double*)scratch, nb);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_rk_scaled_sumsq_f32(double* out, const gode_lincomb_t* lc, const float* y, float rtol,
+                                        float atol, int64_t n, void* scratch, void* stream) {
+    if (n <= 0) return GODE_E_SHAPE;
+    if (!out || !y || !scratch) return GODE_E_NULLPTR;
+    int rc = check_lincomb(lc, true); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(ratio_sumsq_kernel<1>, dim3(nb), dim3(256), 0, s, (double*)scratch, make_lincomb(lc),
+                       y, y, rtol, atol, n);
+    GODE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, out, (const double*)scratch, nb);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_reduce_parts_f32(float* out, const float* part, int64_t n_part, int64_t len, float scale,
+                                     int accumulate, void* stream) {
+    if (n_part < 0 || len < 0) return GODE_E_SHAPE;
+    if (len == 0) return 0;
+    if (!out || (n_part > 0 && !part)) return GODE_E_NULLPTR;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       out, part, n_part, len, scale, accumulate);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gode_colsum_scratch_bytes(int64_t n_rows, int64_t d) {
+    return colsum_blocks(n_rows) * d * (int64_t)sizeof(float);
+}
+
+extern "C" int gode_colsum_f32(float* out, const float* X, int64_t n_rows, int64_t d, float scale,
+                               int accumulate, float* scratch, void* stream) {
+    if (n_rows < 0 || d <= 0) return GODE_E_SHAPE;
+    if (!out || !scratch || (n_rows > 0 && !X)) return GODE_E_NULLPTR;
+    if (d > INT32_MAX) return GODE_E_RANGE;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nb = colsum_blocks(n_rows);
+    const int64_t rpb = (n_rows + nb - 1) / nb;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nb), dim3(256), 0, s, scratch, X, n_rows, (int)d, rpb > 0 ? rpb : 1);
+    GODE_LAUNCH_CHECK();
+    return gode_reduce_parts_f32(out, scratch, nb, d, scale, accumulate, stream);
+}

@@ -1,0 +1,239 @@
+// spmm.hip — CSR sparse aggregation  Z = A*X (+bias) with fused epilogue (gfx950).
+//
+// Replaces torch.spmm at GCN/layers.py:33,71 (+bias :35,73, relu GCN/models.py:178),
+// GAT/layers.py:53,55 and QC/mpnn.py:29 / QC/layers.py:145 of the reference.
+//
+// Work decomposition: the host builds an nnz-balanced record list once per graph
+// (graph_odenet_amd/graph.py): {row, begin, end, slot}.  A group of LPR lanes owns one
+// record; each lane keeps VEC=4 consecutive feature columns, so a group reads one
+// X row as LPR*16 contiguous bytes (d=128: 32 lanes x 16 B = 512 B per gathered row,
+// two records per wave64).  Column indices / values of a record are loaded
+// cooperatively (coalesced) and broadcast inside the group with ds_bpermute.
+// Rows longer than the split length are cut into several records that write raw
+// partial sums; spmm_finish adds them in record order (deterministic, no atomics).
+//
+// Bound: HBM.  Algorithmic bytes per launch: nnz*(4+4+4d) + (N+1)*4 + N*d*4.
+#include "common.h"
+
+namespace {
+
+struct Epilogue {
+    const float* bias;
+    int relu;
+    LinComb cot;
+    float* Y2;
+};
+
+template <int LPR>
+__device__ __forceinline__ void epilogue_store4(const Epilogue& ep, float4 z, int row, int lane,
+                                                int64_t d, float* Y, int64_t ldy) {
+    if (ep.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(ep.bias + lane * 4);
+        z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;
+    }
+    float4 y = z;
+    if (ep.relu) { y.x = fmaxf(z.x, 0.f); y.y = fmaxf(z.y, 0.f); y.z = fmaxf(z.z, 0.f); y.w = fmaxf(z.w, 0.f); }
+    *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + lane * 4) = y;
+    if (ep.Y2) {
+        const int64_t o = (int64_t)row * d + lane * 4;
+        float4 g = lc_load4(ep.cot, o);
+        g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f;
+        g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+        *reinterpret_cast<float4*>(ep.Y2 + o) = g;
+    }
+}
+
+// d == 4*LPR, X/Y rows 16-byte aligned.
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_vec4_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const int4* __restrict__ items, int n_items, float* __restrict__ partial,
+    const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, Epilogue ep)
+{
+    constexpr int U = 4;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (int)(tid / LPR);
+    const int lane = threadIdx.x & (LPR - 1);
+    const bool active = gid < n_items;
+    int row = 0, b = 0, e = 0, slot = -1;
+    if (active) {
+        if (items) { const int4 it = items[gid]; row = it.x; b = it.y; e = it.z; slot = it.w; }
+        else { row = gid; b = rowptr[gid]; e = rowptr[gid + 1]; }
+    }
+    const int len = e - b;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* Xl = X + lane * 4;
+
+    for (int base = 0; __any(base < len); base += LPR) {
+        int c = 0; float v = 0.f;
+        if (base + lane < len) {
+            c = col[b + base + lane];
+            v = val ? val[b + base + lane] : 1.f;
+        }
+        const int cnt = len - base;   // may be <= 0 or > LPR
+        for (int k = 0; k < LPR; k += U) {
+            if (!__any(k < cnt)) break;
+            int cc[U]; float vv[U]; float4 xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                cc[u] = __shfl(c, k + u, LPR);
+                vv[u] = __shfl(v, k + u, LPR);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k + u < cnt && k + u < LPR)
+                    xv[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)cc[u] * ldx);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc.x = fmaf(vv[u], xv[u].x, acc.x); acc.y = fmaf(vv[u], xv[u].y, acc.y);
+                acc.z = fmaf(vv[u], xv[u].z, acc.z); acc.w = fmaf(vv[u], xv[u].w, acc.w);
+            }
+        }
+    }
+    if (!active) return;
+    if (slot < 0) epilogue_store4<LPR>(ep, acc, row, lane, (int64_t)LPR * 4, Y, ldy);
+    else *reinterpret_cast<float4*>(partial + (int64_t)slot * (LPR * 4) + lane * 4) = acc;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_finish_vec4_kernel(
+    const int4* __restrict__ long_rows, int n_long, const float* __restrict__ partial,
+    float* __restrict__ Y, int64_t ldy, Epilogue ep)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (int)(tid / LPR);
+    const int lane = threadIdx.x & (LPR - 1);
+    if (gid >= n_long) return;
+    const int4 lr = long_rows[gid];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = lr.y; s < lr.z; ++s) {
+        const float4 p = *reinterpret_cast<const float4*>(partial + (int64_t)s * (LPR * 4) + lane * 4);
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    epilogue_store4<LPR>(ep, acc, lr.x, lane, (int64_t)LPR * 4, Y, ldy);
+}
+
+// Generic path: any d, any alignment.  A group of G lanes (power of two <= 64) owns a record.
+__device__ __forceinline__ void epilogue_store1(const Epilogue& ep, float z, int row, int c, int64_t d,
+                                                float* Y, int64_t ldy) {
+    if (ep.bias) z += ep.bias[c];
+    Y[(int64_t)row * ldy + c] = ep.relu ? fmaxf(z, 0.f) : z;
+    if (ep.Y2) {
+        const int64_t o = (int64_t)row * d + c;
+        const float g = lc_load1(ep.cot, o);
+        ep.Y2[o] = z > 0.f ? g : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void spmm_generic_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const int4* __restrict__ items, int n_items, float* __restrict__ partial,
+    const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int d, int G, Epilogue ep)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (int)(tid / G);
+    const int lane = threadIdx.x & (G - 1);
+    if (gid >= n_items) return;
+    int row, b, e, slot = -1;
+    if (items) { const int4 it = items[gid]; row = it.x; b = it.y; e = it.z; slot = it.w; }
+    else { row = gid; b = rowptr[gid]; e = rowptr[gid + 1]; }
+    for (int c = lane; c < d; c += G) {
+        float acc = 0.f;
+        for (int j = b; j < e; ++j) {
+            const float v = val ? val[j] : 1.f;
+            acc = fmaf(v, X[(int64_t)col[j] * ldx + c], acc);
+        }
+        if (slot < 0) epilogue_store1(ep, acc, row, c, d, Y, ldy);
+        else partial[(int64_t)slot * d + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void spmm_finish_generic_kernel(
+    const int4* __restrict__ long_rows, int n_long, const float* __restrict__ partial,
+    float* __restrict__ Y, int64_t ldy, int d, int G, Epilogue ep)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (int)(tid / G);
+    const int lane = threadIdx.x & (G - 1);
+    if (gid >= n_long) return;
+    const int4 lr = long_rows[gid];
+    for (int c = lane; c < d; c += G) {
+        float acc = 0.f;
+        for (int s = lr.y; s < lr.z; ++s) acc += partial[(int64_t)s * d + c];
+        epilogue_store1(ep, acc, lr.x, c, d, Y, ldy);
+    }
+}
+
+template <int LPR>
+int launch_vec4(const int* rowptr, const int* col, const float* val, const int4* items, int n_items,
+                const int4* long_rows, int n_long, float* partial, const float* X, int64_t ldx,
+                float* Y, int64_t ldy, const Epilogue& ep, hipStream_t s) {
+    const int64_t threads = (int64_t)n_items * LPR;
+    const int64_t blocks = (threads + 255) / 256;
+    if (blocks > 0) {
+        hipLaunchKernelGGL(spmm_vec4_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           rowptr, col, val, items, n_items, partial, X, ldx, Y, ldy, ep);
+        GODE_LAUNCH_CHECK();
+    }
+    if (n_long > 0) {
+        const int64_t b2 = ((int64_t)n_long * LPR + 255) / 256;
+        hipLaunchKernelGGL(spmm_finish_vec4_kernel<LPR>, dim3((unsigned)b2), dim3(256), 0, s,
+                           long_rows, n_long, partial, Y, ldy, ep);
+        GODE_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                 const int32_t* items, int64_t n_items,
+                                 const int32_t* long_rows, int64_t n_long, float* partial,
+                                 const float* X, int64_t ldx, float* Y, int64_t ldy,
+                                 int64_t n_rows, int64_t d,
+                                 const float* bias, int relu,
+                                 const gode_lincomb_t* cot, float* Y2, void* stream)
+{
+    if (n_rows < 0 || d <= 0 || ldx < d || ldy < d) return GODE_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!rowptr || !col || !X || !Y) return GODE_E_NULLPTR;
+    if (n_rows > INT32_MAX || d > (1 << 20)) return GODE_E_RANGE;
+    if (!items) { n_items = n_rows; n_long = 0; }
+    if (n_items < 0 || n_items > INT32_MAX || n_long < 0 || n_long > INT32_MAX) return GODE_E_RANGE;
+    if (n_long > 0 && (!long_rows || !partial)) return GODE_E_NULLPTR;
+    if (Y2) { int rc = check_lincomb(cot, true); if (rc) return rc; }
+    hipStream_t s = (hipStream_t)stream;
+
+    Epilogue ep;
+    ep.bias = bias; ep.relu = relu; ep.cot = make_lincomb(Y2 ? cot : nullptr); ep.Y2 = Y2;
+
+    const bool al = !(((uintptr_t)X) & 15) && !(((uintptr_t)Y) & 15) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+                    (!bias || !(((uintptr_t)bias) & 15)) && (!partial || !(((uintptr_t)partial) & 15)) &&
+                    (!Y2 || (!(((uintptr_t)Y2) & 15) && lincomb_aligned16(cot)));
+    const int4* it4 = reinterpret_cast<const int4*>(items);
+    const int4* lr4 = reinterpret_cast<const int4*>(long_rows);
+    if (al && d % 4 == 0) {
+        switch (d / 4) {
+#define GODE_CASE(L) case L: return launch_vec4<L>(rowptr, col, val, it4, (int)n_items, lr4, (int)n_long, partial, X, ldx, Y, ldy, ep, s);
+            GODE_CASE(1) GODE_CASE(2) GODE_CASE(4) GODE_CASE(8) GODE_CASE(16) GODE_CASE(32) GODE_CASE(64)
+#undef GODE_CASE
+            default: break;
+        }
+    }
+    int G = 1; while (G < d && G < 64) G <<= 1;
+    {
+        const int64_t blocks = ((int64_t)n_items * G + 255) / 256;
+        hipLaunchKernelGGL(spmm_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           rowptr, col, val, it4, (int)n_items, partial, X, ldx, Y, ldy, (int)d, G, ep);
+        GODE_LAUNCH_CHECK();
+    }
+    if (n_long > 0) {
+        const int64_t b2 = ((int64_t)n_long * G + 255) / 256;
+        hipLaunchKernelGGL(spmm_finish_generic_kernel, dim3((unsigned)b2), dim3(256), 0, s,
+                           lr4, (int)n_long, partial, Y, ldy, (int)d, G, ep);
+        GODE_LAUNCH_CHECK();
+    }
+    return 0;
+}

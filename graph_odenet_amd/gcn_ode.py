@@ -1,0 +1,145 @@
+"""Fused GCN ODE function: f(t, x) = relu( A @ ([t | GroupNorm(x)] @ W) + b )
+(reference: ODEfunc.forward, GCN/models.py:172-179 -> FixedGraphConvolution.forward,
+GCN/layers.py:69-75) and its vector-Jacobian products, as two / five HIP kernel launches:
+
+  forward   : gode_gn_time_gemm_f32 (stage combine + GroupNorm + time column + MFMA GEMM)
+              gode_spmm_csr_f32     (gather-aggregate + bias + relu)
+  adjoint   : + relu-masked cotangent in the SpMM epilogue, gode_spmm_csr_f32 on A^T,
+              gode_gn_time_gemm_bwd_f32 (dS W^T + GroupNorm backward), gode_wgrad_f32,
+              gode_colsum_f32 (bias), gode_reduce_parts_f32 (block partials).
+
+Stage inputs arrive as (coef, tensor) term lists and are combined inside the kernels.
+"""
+import torch
+
+from . import ops
+from .graph import as_graph
+from .solver import Field
+
+
+class _Shared:
+    """Per-(graph, d) workspaces shared by the forward and adjoint fields."""
+
+    def __init__(self, graph, d, device):
+        n = graph.n_rows
+        self.S = torch.empty(n, d, dtype=torch.float32, device=device)
+        self.dZ = None
+        self.dS = None
+        self.n = n
+        self.d = d
+
+    def bwd(self):
+        if self.dZ is None:
+            self.dZ = torch.empty_like(self.S)
+            self.dS = torch.empty_like(self.S)
+        return self.dZ, self.dS
+
+
+class GcnOdeSpec:
+    """Plain description of one ODEfunc instance (tensors are the live parameters)."""
+
+    def __init__(self, graph, W, b, gamma, beta, groups, eps):
+        self.graph, self.W, self.b, self.gamma, self.beta = graph, W, b, gamma, beta
+        self.groups, self.eps = int(groups), float(eps)
+        self.d = W.shape[1]
+        if W.shape[0] != self.d + 1:
+            raise ValueError("GcnOdeSpec: weight must be (d+1) x d, got %s" % (tuple(W.shape),))
+        if graph.n_rows != graph.n_cols:
+            raise ValueError("GcnOdeSpec: adjacency must be square")
+
+
+class GcnOdeField(Field):
+    n_components = 1
+    fused = True
+
+    def __init__(self, spec, shared):
+        self.s, self.w = spec, shared
+
+    def eval(self, t, terms, out):
+        s, w = self.s, self.w
+        ops.gn_time_gemm(terms[0], w.n, s.d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
+        ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0])
+
+
+class GcnOdeAdjointField(Field):
+    """Components: [y, a, a_t, W, b, gamma, beta] (b may be absent -> never, FixedGC always has bias here)."""
+    fused = True
+
+    def __init__(self, spec, shared, params_order):
+        self.s, self.w = spec, shared
+        self.params_order = params_order      # list of 'gamma','beta','W','b' in func.parameters() order
+        self.n_components = 7
+        self.ratio_groups = [[0], [1], [2], [3, 4, 5, 6]]
+
+    def new_state(self, y_end):
+        s = self.s
+        z = lambda p: torch.zeros_like(p)   # noqa: E731
+        return [y_end.clone(), torch.zeros_like(y_end), torch.zeros(1, dtype=torch.float32, device=y_end.device),
+                z(s.W), z(s.b), z(s.gamma), z(s.beta)]
+
+    def param_grads(self, comps):
+        m = {"W": comps[3], "b": comps[4], "gamma": comps[5], "beta": comps[6]}
+        return [m[k] for k in self.params_order]
+
+    def eval(self, t, terms, out):
+        s, w = self.s, self.w
+        dZ, dS = w.bwd()
+        n, d = w.n, s.d
+        y_terms = terms[0]
+        ops.gn_time_gemm(y_terms, n, d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
+        # k_y = relu(A S + b);  dZ = (-a) * mask
+        ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0],
+                 cot_terms=[(-c, x) for (c, x) in terms[1]], out2=dZ)
+        ops.spmm(s.graph.transpose(), dZ, out=dS)                       # dS = A^T dZ
+        _, dgp, dbp = ops.gn_time_gemm_bwd(y_terms, n, d, s.groups, s.eps, s.gamma, s.W, True, dS,
+                                           out_scale=1.0, out=out[1])   # k_a = -a^T df/dy
+        part = ops.wgrad(y_terms, n, d, s.groups, s.eps, s.gamma, s.beta, dS, True)
+        ops.reduce_parts_(out[3].view(-1), part)                        # row 0 = colsum(dS)
+        out[2].copy_((out[3][0] * s.W[0]).sum().reshape(1))             # a_t' = -a^T df/dt
+        out[3][0].mul_(t)                                               # dW[0,:] = t * colsum(dS)
+        ops.colsum_(out[4], dZ)
+        if dgp is not None:
+            ops.reduce_parts_(out[5], dgp)
+            ops.reduce_parts_(out[6], dbp)
+        else:
+            out[5].zero_(); out[6].zero_()
+
+
+class _OdeFuncFn(torch.autograd.Function):
+    """Stand-alone differentiable f(t, x) (used when ODEfunc is called outside our solver)."""
+
+    @staticmethod
+    def forward(ctx, spec, t, x, W, b, gamma, beta):
+        x = x.contiguous()
+        n, d = x.shape
+        S = ops.gn_time_gemm([(1.0, x)], n, d, spec.groups, spec.eps, gamma, beta, W, True, t)
+        out = ops.spmm(spec.graph, S, bias=b, relu=True)
+        ctx.spec, ctx.t = spec, t
+        ctx.save_for_backward(x, W, b, gamma, beta, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, b, gamma, beta, out = ctx.saved_tensors
+        spec, t = ctx.spec, ctx.t
+        n, d = x.shape
+        dZ = g.contiguous() * (out > 0).to(g.dtype)
+        dS = ops.spmm(spec.graph.transpose(), dZ)
+        dx, dgp, dbp = ops.gn_time_gemm_bwd([(1.0, x)], n, d, spec.groups, spec.eps, gamma, W, True, dS)
+        part = ops.wgrad([(1.0, x)], n, d, spec.groups, spec.eps, gamma, beta, dS, True)
+        gW = torch.empty_like(W)
+        ops.reduce_parts_(gW.view(-1), part)
+        gW[0].mul_(t)
+        gb = torch.empty_like(b)
+        ops.colsum_(gb, dZ)
+        gg = torch.zeros_like(gamma)
+        gbe = torch.zeros_like(beta)
+        if dgp is not None:
+            ops.reduce_parts_(gg, dgp)
+            ops.reduce_parts_(gbe, dbp)
+        return None, None, dx, gW, gb, gg, gbe
+
+
+def odefunc_apply(adj, t, x, W, b, gamma, beta, groups, eps):
+    spec = GcnOdeSpec(as_graph(adj), W, b, gamma, beta, groups, eps)
+    return _OdeFuncFn.apply(spec, float(t), x, W, b, gamma, beta)

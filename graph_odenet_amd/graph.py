@@ -1,0 +1,172 @@
+"""Graph-format normaliser: every adjacency format the reference passes to its layers
+is converted ONCE per distinct tensor object into device-resident int32 CSR plus the
+nnz-balanced record list the SpMM kernel walks.
+
+Accepted:
+  * uncoalesced torch sparse COO  N x N   (GCN/utils.py:222-229)
+  * dense N x N                           (GCN-dense-paper/utils.py:87)
+  * sparse COO incidence  N x E  (Mtgt)   (GAT/utils.py:194-209)
+  * dense incidence       N x 2M (Etgt)   (QC/datasets/utils.py:213-214)
+
+Duplicate COO entries are summed (torch.spmm semantics on uncoalesced input).
+The conversion is index bookkeeping with torch ops on whatever device the tensor lives
+on; the arithmetic of the hot path is in csrc/.
+"""
+import weakref
+
+import torch
+
+DEFAULT_SPLIT = 128   # records longer than this are split (see csrc/spmm.hip)
+
+
+class CSRGraph:
+    """CSR of an (n_rows x n_cols) sparse matrix + balanced record list."""
+
+    def __init__(self, rowptr, col, val, n_rows, n_cols, split=DEFAULT_SPLIT):
+        self.rowptr = rowptr.to(torch.int32).contiguous()
+        self.col = col.to(torch.int32).contiguous()
+        self.val = None if val is None else val.to(torch.float32).contiguous()
+        self.n_rows = int(n_rows)
+        self.n_cols = int(n_cols)
+        self.nnz = int(self.col.numel())
+        self.device = self.col.device
+        self.split = int(split)
+        self._build_items()
+        self._partial = {}
+        self._T = None
+
+    # -- balanced record list -------------------------------------------------
+    def _build_items(self):
+        dev = self.device
+        n = self.n_rows
+        rp = self.rowptr.to(torch.int64)
+        deg = rp[1:] - rp[:-1]
+        L = self.split
+        nseg = torch.clamp((deg + L - 1) // L, min=1)
+        total = int(nseg.sum().item()) if n > 0 else 0
+        rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), nseg)
+        first = torch.cumsum(nseg, 0) - nseg
+        k = torch.arange(total, device=dev, dtype=torch.int64) - first[rows]
+        begin = rp[rows] + k * L
+        end = torch.minimum(begin + L, rp[rows + 1])
+        is_long = nseg[rows] > 1
+        slot = torch.where(is_long, torch.cumsum(is_long.to(torch.int64), 0) - 1,
+                           torch.full_like(rows, -1))
+        self.n_slots = int(is_long.sum().item()) if total > 0 else 0
+        items = torch.stack([rows, begin, end, slot], 1)
+        # longest first: better tail behaviour and less divergence inside a wave
+        order = torch.argsort(end - begin, descending=True, stable=True)
+        self.items = items[order].to(torch.int32).contiguous()
+        self.n_items = total
+        long_rows = torch.nonzero(nseg > 1).flatten()
+        self.n_long = int(long_rows.numel())
+        if self.n_long:
+            # slots of one row are consecutive in row order
+            long_first = torch.cumsum(nseg[long_rows], 0) - nseg[long_rows]
+            lr = torch.stack([long_rows, long_first, long_first + nseg[long_rows],
+                              torch.zeros_like(long_rows)], 1)
+            self.long_rows = lr.to(torch.int32).contiguous()
+        else:
+            self.long_rows = None
+
+    def partial(self, d):
+        """Scratch for split rows at feature width d (owned here, reused across calls)."""
+        if self.n_slots == 0:
+            return None
+        buf = self._partial.get(d)
+        if buf is None:
+            buf = torch.empty(self.n_slots * d, dtype=torch.float32, device=self.device)
+            self._partial[d] = buf
+        return buf
+
+    # -- transpose (CSR by source) for the backward pass -----------------------
+    def transpose(self):
+        if self._T is None:
+            rp = self.rowptr.to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), rp[1:] - rp[:-1])
+            self._T = from_coo(self.col.to(torch.int64), rows, self.val, self.n_cols, self.n_rows,
+                               split=self.split, coalesce=False)
+            self._T._T = self
+        return self._T
+
+    def to_dense(self):
+        rp = self.rowptr.to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), rp[1:] - rp[:-1])
+        out = torch.zeros(self.n_rows, self.n_cols, dtype=torch.float32, device=self.device)
+        v = self.val if self.val is not None else torch.ones(self.nnz, device=self.device)
+        out.index_put_((rows, self.col.to(torch.int64)), v, accumulate=True)
+        return out
+
+    def algorithmic_bytes(self, d):
+        """nnz*(4+4+4d) + (N+1)*4 + N*d*4 (value term dropped when pattern-only)."""
+        per = 4 + (4 if self.val is not None else 0) + 4 * d
+        return self.nnz * per + (self.n_rows + 1) * 4 + self.n_rows * d * 4
+
+
+def from_coo(rows, cols, vals, n_rows, n_cols, split=DEFAULT_SPLIT, coalesce=True):
+    rows = rows.to(torch.int64)
+    cols = cols.to(torch.int64)
+    key = rows * n_cols + cols
+    if coalesce:
+        ukey, inv = torch.unique(key, sorted=True, return_inverse=True)
+        if ukey.numel() != key.numel():
+            if vals is None:
+                vals = torch.ones(key.numel(), dtype=torch.float32, device=key.device)
+            vals = torch.zeros(ukey.numel(), dtype=torch.float32, device=key.device).index_add_(0, inv, vals.float())
+        elif vals is not None:
+            vals = torch.empty_like(vals, dtype=torch.float32).index_copy_(0, inv, vals.float())
+        key = ukey
+    else:
+        order = torch.argsort(key, stable=True)
+        key = key[order]
+        if vals is not None:
+            vals = vals[order]
+    r = key // n_cols
+    c = key % n_cols
+    counts = torch.bincount(r, minlength=n_rows)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=key.device)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return CSRGraph(rowptr, c, vals, n_rows, n_cols, split=split)
+
+
+_cache = {}
+
+
+def _evict(key):
+    _cache.pop(key, None)
+
+
+def as_graph(adj, split=DEFAULT_SPLIT):
+    """Normalise `adj` (sparse COO / dense / CSRGraph); cached per tensor object."""
+    if isinstance(adj, CSRGraph):
+        return adj
+    if not torch.is_tensor(adj):
+        raise TypeError("adjacency must be a torch tensor (sparse COO or dense) or CSRGraph")
+    key = id(adj)
+    hit = _cache.get(key)
+    if hit is not None and hit[0]() is adj and hit[2] == adj._version:
+        return hit[1]
+    if adj.dim() != 2:
+        raise ValueError("adjacency must be 2-D, got shape %s" % (tuple(adj.shape),))
+    if adj.is_sparse:
+        idx = adj._indices()
+        vals = adj._values()
+        g = from_coo(idx[0], idx[1], vals, adj.shape[0], adj.shape[1], split=split)
+    elif adj.layout == torch.sparse_csr:
+        g = CSRGraph(adj.crow_indices(), adj.col_indices(), adj.values(), adj.shape[0], adj.shape[1], split=split)
+    else:
+        nz = torch.nonzero(adj)
+        g = from_coo(nz[:, 0], nz[:, 1], adj[nz[:, 0], nz[:, 1]], adj.shape[0], adj.shape[1], split=split)
+    try:
+        ref = weakref.ref(adj, lambda _r, k=key: _evict(k))
+        _cache[key] = (ref, g, adj._version)
+    except TypeError:
+        pass
+    return g
+
+
+def incidence_from_index(index, n_rows, split=DEFAULT_SPLIT):
+    """N x E incidence with a single 1.0 per column at row index[e] (Mtgt of GAT/utils.py:194-197),
+    built directly from the index vector."""
+    e = index.numel()
+    return from_coo(index.to(torch.int64), torch.arange(e, device=index.device), None, n_rows, e, split=split)

@@ -1,0 +1,107 @@
+"""GCN-family graph layers with the reference's names, constructor signatures, parameter
+names, initialisation and forward API (GCN/layers.py:9-83 == GCN-sum/layers.py; the
+dense-adjacency variant of GCN-dense-paper/layers.py differs only in init), computing on
+the HIP kernels of libgraphode.so.
+
+    GraphConvolution(in_features, out_features, bias=True).forward(input, adj)
+    FixedGraphConvolution(in_features, out_features, bias=True).set_adj(adj); .forward(input)
+
+`adj` may be an (uncoalesced) sparse COO tensor, a dense N x N tensor or a CSRGraph; it is
+normalised once per tensor object (graph.as_graph).
+"""
+import math
+
+import torch
+from torch.nn.modules.module import Module
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .graph import as_graph
+
+
+class _GraphConvFn(torch.autograd.Function):
+    """output = A @ (input @ W) + bias   (GCN/layers.py:31-37)."""
+
+    @staticmethod
+    def forward(ctx, graph, x, weight, bias):
+        support = torch.mm(x, weight)            # plain dense GEMM (rocBLAS); see DESIGN.md
+        out = ops.spmm(graph, support.contiguous(), bias=bias, relu=False)
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        g = grad_out.contiguous()
+        d_support = ops.spmm(ctx.graph.transpose(), g)       # A^T dY
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gx = torch.mm(d_support, weight.t())
+        if ctx.needs_input_grad[2]:
+            gw = torch.mm(x.t(), d_support)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = torch.empty_like(weight[0])
+            ops.colsum_(gb, g)
+        return None, gx, gw, gb
+
+
+class GraphConvolution(Module):
+    """Simple GCN layer (reference: GCN/layers.py:9-42)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super(GraphConvolution, self).__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = Parameter(torch.empty(in_features, out_features))
+        if bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # GCN/layers.py:25-29: U(-1/sqrt(out), 1/sqrt(out)) for weight and bias
+        stdv = 1. / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, input, adj):
+        return _GraphConvFn.apply(as_graph(adj), input.contiguous(), self.weight, self.bias)
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
+
+
+class FixedGraphConvolution(Module):
+    """GCN layer with the adjacency held as an attribute so an ODE solver can call f(t, x)
+    (reference: GCN/layers.py:46-83; `adj` is a plain attribute there too, Q3)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super(FixedGraphConvolution, self).__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = Parameter(torch.empty(in_features, out_features))
+        if bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+        self.adj = torch.Tensor([[1]])
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, input):
+        return _GraphConvFn.apply(as_graph(self.adj), input.contiguous(), self.weight, self.bias)
+
+    def set_adj(self, adj):
+        self.adj = adj
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

@@ -1,0 +1,240 @@
+"""Model classes of the reference's GCN family with the same names, constructor kwargs
+(nfeat=, nhid=, nclass=, dropout=[, nlayers=]), sub-module / state_dict key names and
+forward(x, adj) API (GCN/models.py), built on graph_odenet_amd.layers and our solver.
+
+Extensions (default to the reference's behaviour): ODEBlock(odefunc, tol=1e-5, method=None,
+step_size=None) - method=None is adaptive dopri5 with rtol=atol=tol exactly as
+GCN/models.py:192 calls torchdiffeq; method='rk4' + step_size=1/16 is the fixed 64-eval
+integration the benchmark metric is quoted on.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .gcn_ode import GcnOdeAdjointField, GcnOdeField, GcnOdeSpec, _Shared, odefunc_apply
+from .graph import as_graph
+from .layers import FixedGraphConvolution, GraphConvolution
+from .odeint import odeint_adjoint as odeint
+
+
+class GCN(nn.Module):
+    """GCN/models.py:8-20."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(GCN, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc2 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gc1(x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        x = self.gc2(x, adj)
+        return F.log_softmax(x, dim=1)
+
+
+class GCN3(nn.Module):
+    """GCN/models.py:66-81."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(GCN3, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc2 = GraphConvolution(nhid, nhid)
+        self.gc3 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gc1(x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        x = F.relu(self.gc2(x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        x = self.gc3(x, adj)
+        return F.log_softmax(x, dim=1)
+
+
+class RGCN3(nn.Module):
+    """GCN/models.py:101-118."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(RGCN3, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc2 = GraphConvolution(nhid, nhid)
+        self.gc3 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gc1(x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        r = x
+        x = F.relu(self.gc2(x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        x = x + r
+        x = self.gc3(x, adj)
+        return F.log_softmax(x, dim=1)
+
+
+class RGCN3norm(nn.Module):
+    """GCN/models.py:120-138."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(RGCN3norm, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc2 = GraphConvolution(nhid, nhid)
+        self.norm2 = nn.GroupNorm(min(32, nhid), nhid)
+        self.gc3 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gc1(x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        r = x
+        x = F.relu(self.gc2(x, adj))
+        x = self.norm2(x)
+        x = x + r
+        x = self.gc3(x, adj)
+        return F.log_softmax(x, dim=1)
+
+
+class RGCN3fullnorm(nn.Module):
+    """GCN/models.py:140-159."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(RGCN3fullnorm, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.norm1 = nn.GroupNorm(min(32, nhid), nhid)
+        self.gc2 = GraphConvolution(nhid, nhid)
+        self.norm2 = nn.GroupNorm(min(32, nhid), nhid)
+        self.gc3 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gc1(x, adj))
+        x = self.norm1(x)
+        r = x
+        x = F.relu(self.gc2(x, adj))
+        x = self.norm2(x)
+        x = x + r
+        x = self.gc3(x, adj)
+        return F.log_softmax(x, dim=1)
+
+
+class ODEfunc(nn.Module):
+    """GCN/models.py:161-179: relu(gc1([t | norm1(x)])), counting calls in `nfe`."""
+
+    _gode_counts_nfe = True
+
+    def __init__(self, dim):
+        super(ODEfunc, self).__init__()
+        self.norm1 = nn.GroupNorm(min(32, dim), dim)
+        self.gc1 = FixedGraphConvolution(dim + 1, dim)
+        self.nfe = 0
+        self._shared = None
+
+    def set_adj(self, adj):
+        self.gc1.set_adj(adj)
+
+    def _spec(self):
+        return GcnOdeSpec(as_graph(self.gc1.adj), self.gc1.weight, self.gc1.bias, self.norm1.weight,
+                          self.norm1.bias, self.norm1.num_groups, self.norm1.eps)
+
+    def forward(self, t, x):
+        self.nfe += 1
+        return odefunc_apply(self.gc1.adj, float(t), x, self.gc1.weight, self.gc1.bias, self.norm1.weight,
+                             self.norm1.bias, self.norm1.num_groups, self.norm1.eps)
+
+    # hook used by graph_odenet_amd.odeint: fused forward / adjoint fields
+    def gode_fields(self, y0):
+        if self.gc1.bias is None or y0.dim() != 2:
+            return None
+        spec = self._spec()
+        sh = self._shared
+        if sh is None or sh.n != y0.shape[0] or sh.d != y0.shape[1] or sh.S.device != y0.device:
+            sh = self._shared = _Shared(spec.graph, spec.d, y0.device)
+        names = {id(self.norm1.weight): "gamma", id(self.norm1.bias): "beta",
+                 id(self.gc1.weight): "W", id(self.gc1.bias): "b"}
+        plist = [p for p in self.parameters() if p.requires_grad]
+        if len(plist) != 4:
+            return None           # frozen parameters: take the generic autograd path
+        order = [names[id(p)] for p in plist]
+        return GcnOdeField(spec, sh), (lambda: GcnOdeAdjointField(spec, sh, order)), tuple(plist)
+
+
+class ODEBlock(nn.Module):
+    """GCN/models.py:181-201."""
+
+    def __init__(self, odefunc, tol=1e-5, method=None, step_size=None):
+        super(ODEBlock, self).__init__()
+        self.odefunc = odefunc
+        self.integration_time = torch.tensor([0, 1]).float()
+        self.tol = tol
+        self.method = method
+        self.step_size = step_size
+
+    def forward(self, x, adj):
+        self.integration_time = self.integration_time.type_as(x)
+        self.odefunc.set_adj(adj)
+        options = {"step_size": self.step_size} if self.step_size is not None else None
+        out = odeint(self.odefunc, x, self.integration_time, rtol=self.tol, atol=self.tol,
+                     method=self.method, options=options)
+        return out[1]
+
+    @property
+    def nfe(self):
+        return self.odefunc.nfe
+
+    @nfe.setter
+    def nfe(self, value):
+        self.odefunc.nfe = value
+
+
+class ODEGCN3(nn.Module):
+    """GCN/models.py:204-226 (the north-star model: gc1 -> ODEBlock -> gc3)."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout, method=None, step_size=None, tol=1e-5):
+        super(ODEGCN3, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc2 = ODEBlock(ODEfunc(nhid), tol=tol, method=method, step_size=step_size)
+        self.gc3 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gc1(x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        x = self.gc2(x, adj)
+        x = self.gc3(x, adj)
+        return F.log_softmax(x, dim=1)
+
+    @property
+    def nfe(self):
+        return self.gc2.nfe
+
+    @nfe.setter
+    def nfe(self, value):
+        self.gc2.nfe = value
+
+
+class ODEGCN3fullnorm(nn.Module):
+    """GCN/models.py:229-253."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout, method=None, step_size=None, tol=1e-5):
+        super(ODEGCN3fullnorm, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.norm1 = nn.GroupNorm(min(32, nhid), nhid)
+        self.gc2 = ODEBlock(ODEfunc(nhid), tol=tol, method=method, step_size=step_size)
+        self.gc3 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gc1(x, adj))
+        x = self.norm1(x)
+        x = self.gc2(x, adj)
+        x = self.gc3(x, adj)
+        return F.log_softmax(x, dim=1)
+
+    @property
+    def nfe(self):
+        return self.gc2.nfe
+
+    @nfe.setter
+    def nfe(self, value):
+        self.gc2.nfe = value

@@ -1,0 +1,179 @@
+"""`odeint` / `odeint_adjoint` with the public torchdiffeq signature (the solver seam of
+GCN/models.py:5,192, GAT/models.py:5,192 in the reference):
+
+    odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None)
+        -> Tensor[len(t), *y0.shape]
+
+`func` is an nn.Module called as func(t: 0-dim tensor, y).  When it offers
+`gode_fields(y0)` (our ODEfunc does) the whole f-eval and its VJP run as fused HIP kernels
+and stage inputs are never materialised; any other module runs through autograd with the
+RK arithmetic still in the HIP kernels.
+"""
+import torch
+
+from . import ops
+from .solver import (Dopri5Stats, Field, integrate_dopri5_inplace, integrate_rk4, uniform_grid)
+
+
+def _materialise(terms):
+    if len(terms) == 1 and terms[0][0] == 1.0:
+        return terms[0][1]
+    out = torch.empty_like(terms[0][1])
+    return ops.lincomb_(out, terms)
+
+
+class AutogradField(Field):
+    """Forward field of an arbitrary module: one component."""
+    n_components = 1
+
+    def __init__(self, func, like):
+        self.func = func
+        self.like = like
+
+    def eval(self, t, terms, out):
+        y = _materialise(terms[0])
+        tt = torch.tensor(t, dtype=self.like.dtype, device=self.like.device)
+        with torch.no_grad():
+            out[0].copy_(self.func(tt, y))
+
+
+class AutogradAdjointField(Field):
+    """Augmented field (y, a, a_t, theta...) of an arbitrary module via torch.autograd."""
+
+    def __init__(self, func, params, like):
+        self.func = func
+        self.params = tuple(params)
+        self.like = like
+        self.n_components = 3 + len(self.params)
+        self.ratio_groups = [[0], [1], [2]] + ([list(range(3, 3 + len(self.params)))] if self.params else [])
+
+    def eval(self, t, terms, out):
+        y = _materialise(terms[0])
+        a = _materialise(terms[1])
+        with torch.enable_grad():
+            tt = torch.tensor(t, dtype=self.like.dtype, device=self.like.device, requires_grad=True)
+            y_ = y.detach().requires_grad_(True)
+            fe = self.func(tt, y_)
+            vj = torch.autograd.grad(fe, (tt, y_) + self.params, -a, allow_unused=True)
+        out[0].copy_(fe.detach())
+        out[1].copy_(vj[1]) if vj[1] is not None else out[1].zero_()
+        out[2].copy_(vj[0].reshape(out[2].shape)) if vj[0] is not None else out[2].zero_()
+        for i, _p in enumerate(self.params):
+            g = vj[2 + i]
+            out[3 + i].copy_(g) if g is not None else out[3 + i].zero_()
+
+
+def _check_state(y0):
+    if not torch.is_tensor(y0):
+        raise TypeError("graph_odenet_amd.odeint: y0 must be a tensor (tuple states are not part of the hot path)")
+    if not y0.is_cuda:
+        raise RuntimeError("graph_odenet_amd.odeint: y0 must live on the GPU (got %s); there is no CPU path" % y0.device)
+    if y0.dtype != torch.float32:
+        raise TypeError("graph_odenet_amd.odeint: y0 must be float32")
+
+
+def _times(t):
+    tl = [float(v) for v in (t.tolist() if torch.is_tensor(t) else t)]
+    if len(tl) < 2:
+        raise ValueError("odeint: t must hold at least two time points")
+    return tl
+
+
+def _method(method):
+    m = "dopri5" if method is None else method
+    if m not in ("dopri5", "rk4"):
+        raise ValueError("odeint: unsupported method %r (supported: dopri5, rk4)" % (method,))
+    return m
+
+
+def _integrate(field, comps, t0, t1, rtol, atol, method, options, stats):
+    if method == "rk4":
+        n = uniform_grid(t0, t1, (options or {}).get("step_size"))
+        stats.nfe += integrate_rk4(field, comps, t0, t1, n)
+    else:
+        integrate_dopri5_inplace(field, comps, t0, t1, rtol, atol, stats)
+
+
+def _fields(func, y0):
+    mk = getattr(func, "gode_fields", None)
+    if mk is not None:
+        pair = mk(y0)
+        if pair is not None:
+            return pair
+    params = tuple(p for p in func.parameters() if p.requires_grad) if isinstance(func, torch.nn.Module) else ()
+    return AutogradField(func, y0), (lambda: AutogradAdjointField(func, params, y0)), params
+
+
+def _bump_nfe(func, n):
+    # fused fields do not call func.forward; keep the reference's counter (GCN/models.py:173) alive
+    if getattr(func, "_gode_counts_nfe", False):
+        func.nfe += n
+
+
+def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
+    """Forward solve without gradient support through the solver (use odeint_adjoint to train)."""
+    _check_state(y0)
+    tl = _times(t)
+    method = _method(method)
+    fwd, _, _ = _fields(func, y0)
+    stats = Dopri5Stats()
+    y = y0.detach().contiguous().clone()
+    outs = [y.clone()]
+    with torch.no_grad():
+        for i in range(1, len(tl)):
+            _integrate(fwd, [y], tl[i - 1], tl[i], rtol, atol, method, options, stats)
+            outs.append(y.clone())
+    _bump_nfe(func, stats.nfe if getattr(fwd, "fused", False) else 0)
+    return torch.stack(outs)
+
+
+class _OdeintAdjoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, func, tl, rtol, atol, method, options, y0, *params):
+        fwd, mk_adj, plist = _fields(func, y0)
+        stats = Dopri5Stats()
+        y = y0.detach().contiguous().clone()
+        outs = [y.clone()]
+        for i in range(1, len(tl)):
+            _integrate(fwd, [y], tl[i - 1], tl[i], rtol, atol, method, options, stats)
+            outs.append(y.clone())
+        _bump_nfe(func, stats.nfe if getattr(fwd, "fused", False) else 0)
+        ans = torch.stack(outs)
+        ctx.func, ctx.tl, ctx.rtol, ctx.atol, ctx.method, ctx.options = func, tl, rtol, atol, method, options
+        ctx.mk_adj = mk_adj
+        ctx.n_params = len(params)
+        ctx.save_for_backward(ans)
+        return ans
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (ans,) = ctx.saved_tensors
+        func, tl = ctx.func, ctx.tl
+        adj = ctx.mk_adj()
+        grad_out = grad_out.contiguous()
+        stats = Dopri5Stats()
+        with torch.no_grad():
+            comps = adj.new_state(ans[-1]) if hasattr(adj, "new_state") else None
+            if comps is None:
+                comps = [ans[-1].clone(), torch.zeros_like(ans[-1]),
+                         torch.zeros(1, dtype=ans.dtype, device=ans.device)]
+                comps += [torch.zeros_like(p) for p in adj.params]
+            comps[1].copy_(grad_out[-1])
+            for i in range(len(tl) - 1, 0, -1):
+                comps[0].copy_(ans[i])
+                _integrate(adj, comps, tl[i], tl[i - 1], ctx.rtol, ctx.atol, ctx.method, ctx.options, stats)
+                if i - 1 > 0 or True:
+                    comps[1].add_(grad_out[i - 1])
+        _bump_nfe(func, stats.nfe if getattr(adj, "fused", False) else 0)
+        pg = adj.param_grads(comps) if hasattr(adj, "param_grads") else comps[3:]
+        return (None, None, None, None, None, None, comps[1], *pg)
+
+
+def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):
+    _check_state(y0)
+    tl = _times(t)
+    method = _method(method)
+    if not isinstance(func, torch.nn.Module):
+        raise ValueError("odeint_adjoint: func must be an nn.Module")
+    params = tuple(p for p in func.parameters() if p.requires_grad)
+    return _OdeintAdjoint.apply(func, tl, float(rtol), float(atol), method, options, y0, *params)

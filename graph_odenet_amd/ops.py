@@ -1,0 +1,207 @@
+"""Thin, validating Python wrappers over the C ABI (include/graphode.h).
+
+Every function here launches HIP kernels on torch's current stream and returns
+immediately.  Inputs must be CUDA fp32 contiguous tensors: there is deliberately no CPU
+or eager fallback (a missing library or a CPU tensor raises).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, lincomb, ptr, stream_ptr
+
+
+def _need(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError("graph_odenet_amd: %s must live on the GPU (got %s); there is no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("graph_odenet_amd: %s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("graph_odenet_amd: %s must be contiguous" % name)
+
+
+def _need_terms(terms, name):
+    n = None
+    for c, t in terms:
+        _need(t, name)
+        if n is None:
+            n = t.numel()
+        elif t.numel() != n:
+            raise ValueError("graph_odenet_amd: %s terms differ in size" % name)
+    return n
+
+
+def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None):
+    """Y = relu?(A @ X + bias); optionally out2 = (sum cot_terms) * (A@X+bias > 0)."""
+    lib = _lib.load()
+    _need(X, "X")
+    _need(bias, "bias")
+    if X.dim() != 2 or X.shape[0] != graph.n_cols:
+        raise ValueError("spmm: X has shape %s, graph is %d x %d" % (tuple(X.shape), graph.n_rows, graph.n_cols))
+    d = X.shape[1]
+    if bias is not None and bias.numel() != d:
+        raise ValueError("spmm: bias has %d elements, expected %d" % (bias.numel(), d))
+    if out is None:
+        out = torch.empty(graph.n_rows, d, dtype=torch.float32, device=X.device)
+    else:
+        _need(out, "out")
+        if tuple(out.shape) != (graph.n_rows, d):
+            raise ValueError("spmm: out has wrong shape")
+    lc = None
+    if cot_terms is not None:
+        if _need_terms(cot_terms, "cot") != graph.n_rows * d:
+            raise ValueError("spmm: cotangent terms have wrong size")
+        lc = lincomb(cot_terms)
+        if out2 is None:
+            out2 = torch.empty(graph.n_rows, d, dtype=torch.float32, device=X.device)
+        _need(out2, "out2")
+    partial = graph.partial(d)
+    rc = lib.gode_spmm_csr_f32(ptr(graph.rowptr), ptr(graph.col), ptr(graph.val),
+                               ptr(graph.items), graph.n_items,
+                               ptr(graph.long_rows), graph.n_long, ptr(partial),
+                               ptr(X), d, ptr(out), d, graph.n_rows, d,
+                               ptr(bias), 1 if relu else 0,
+                               ctypes.byref(lc) if lc is not None else None, ptr(out2) if lc is not None else None,
+                               stream_ptr())
+    check(rc, "gode_spmm_csr_f32")
+    return (out, out2) if cot_terms is not None else out
+
+
+def lincomb_(out, terms):
+    """out = sum_j coef_j * tensor_j (in place on `out`)."""
+    lib = _lib.load()
+    _need(out, "out")
+    if _need_terms(terms, "lincomb") != out.numel():
+        raise ValueError("lincomb: size mismatch")
+    lc = lincomb(terms)
+    check(lib.gode_lincomb_f32(ptr(out), ctypes.byref(lc), out.numel(), stream_ptr()), "gode_lincomb_f32")
+    return out
+
+
+_red_scratch = {}
+
+
+def _scratch(device, nbytes):
+    buf = _red_scratch.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        _red_scratch[device] = buf
+    return buf
+
+
+def rk_error_sumsq(y0, y1, err_terms, rtol, atol, out=None):
+    """sum_i (err_i / (atol + rtol*max(|y0_i|,|y1_i|)))^2 as a 1-element fp64 device tensor."""
+    lib = _lib.load()
+    _need(y0, "y0"); _need(y1, "y1")
+    n = y0.numel()
+    if _need_terms(err_terms, "err") != n or y1.numel() != n:
+        raise ValueError("rk_error_sumsq: size mismatch")
+    if out is None:
+        out = torch.empty(1, dtype=torch.float64, device=y0.device)
+    sc = _scratch(y0.device, lib.gode_rk_errnorm_scratch_bytes())
+    lc = lincomb(err_terms)
+    check(lib.gode_rk_errnorm_f32(ptr(out), ptr(y0), ptr(y1), ctypes.byref(lc), float(rtol), float(atol), n,
+                                  ptr(sc), stream_ptr()), "gode_rk_errnorm_f32")
+    return out
+
+
+def rk_scaled_sumsq(terms, y, rtol, atol, out=None):
+    """sum_i ((sum terms)_i / (atol + rtol*|y_i|))^2 as a 1-element fp64 device tensor."""
+    lib = _lib.load()
+    _need(y, "y")
+    n = y.numel()
+    if _need_terms(terms, "terms") != n:
+        raise ValueError("rk_scaled_sumsq: size mismatch")
+    if out is None:
+        out = torch.empty(1, dtype=torch.float64, device=y.device)
+    sc = _scratch(y.device, lib.gode_rk_errnorm_scratch_bytes())
+    lc = lincomb(terms)
+    check(lib.gode_rk_scaled_sumsq_f32(ptr(out), ctypes.byref(lc), ptr(y), float(rtol), float(atol), n,
+                                       ptr(sc), stream_ptr()), "gode_rk_scaled_sumsq_f32")
+    return out
+
+
+def gn_time_gemm(x_terms, n_rows, d_in, groups, eps, gamma, beta, W, has_time, t, out=None):
+    """S = [t | GroupNorm(sum x_terms)] @ W   (W is (d_in+has_time) x d_out)."""
+    lib = _lib.load()
+    _need(W, "W"); _need(gamma, "gamma"); _need(beta, "beta")
+    if _need_terms(x_terms, "x") != n_rows * d_in:
+        raise ValueError("gn_time_gemm: x terms have wrong size")
+    if W.dim() != 2 or W.shape[0] != d_in + (1 if has_time else 0):
+        raise ValueError("gn_time_gemm: W has shape %s" % (tuple(W.shape),))
+    d_out = W.shape[1]
+    if out is None:
+        out = torch.empty(n_rows, d_out, dtype=torch.float32, device=W.device)
+    _need(out, "out")
+    lc = lincomb(x_terms)
+    check(lib.gode_gn_time_gemm_f32(ctypes.byref(lc), n_rows, d_in, groups, float(eps), ptr(gamma), ptr(beta),
+                                    ptr(W), d_out, 1 if has_time else 0, float(t), ptr(out), stream_ptr()),
+          "gode_gn_time_gemm_f32")
+    return out
+
+
+def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS, out_scale=1.0, out=None,
+                     want_affine_grads=True):
+    """Returns (dx, dgamma_part, dbeta_part); parts are [n_part, d_in] block partials (or None)."""
+    lib = _lib.load()
+    _need(W, "W"); _need(gamma, "gamma"); _need(dS, "dS")
+    if _need_terms(x_terms, "x") != n_rows * d_in:
+        raise ValueError("gn_time_gemm_bwd: x terms have wrong size")
+    d_out = W.shape[1]
+    if out is None:
+        out = torch.empty(n_rows, d_in, dtype=torch.float32, device=W.device)
+    _need(out, "out")
+    dg = db = None
+    if want_affine_grads and groups > 0:
+        n_part = lib.gode_gemm_bwd_parts(n_rows)
+        dg = torch.empty(n_part, d_in, dtype=torch.float32, device=W.device)
+        db = torch.empty(n_part, d_in, dtype=torch.float32, device=W.device)
+    lc = lincomb(x_terms)
+    check(lib.gode_gn_time_gemm_bwd_f32(ctypes.byref(lc), n_rows, d_in, groups, float(eps), ptr(gamma), ptr(W),
+                                        d_out, 1 if has_time else 0, ptr(dS), float(out_scale), ptr(out),
+                                        ptr(dg), ptr(db), stream_ptr()), "gode_gn_time_gemm_bwd_f32")
+    return out, dg, db
+
+
+def wgrad(x_terms, n_rows, d_in, groups, eps, gamma, beta, dS, has_time):
+    """Block partials [n_part, (d_in+has_time)*d_out] of dW = [1 | GN(x)]^T dS (row 0 = colsum(dS))."""
+    lib = _lib.load()
+    _need(dS, "dS"); _need(gamma, "gamma"); _need(beta, "beta")
+    if _need_terms(x_terms, "x") != n_rows * d_in:
+        raise ValueError("wgrad: x terms have wrong size")
+    d_out = dS.shape[1]
+    n_part = lib.gode_wgrad_parts(n_rows)
+    K = d_in + (1 if has_time else 0)
+    part = torch.empty(n_part, K * d_out, dtype=torch.float32, device=dS.device)
+    lc = lincomb(x_terms)
+    check(lib.gode_wgrad_f32(ctypes.byref(lc), n_rows, d_in, groups, float(eps), ptr(gamma), ptr(beta), ptr(dS),
+                             d_out, 1 if has_time else 0, ptr(part), stream_ptr()), "gode_wgrad_f32")
+    return part
+
+
+def reduce_parts_(out, part, scale=1.0, accumulate=False):
+    """out (+)= scale * part.sum(0)   with `part` of shape [n_part, out.numel()]."""
+    lib = _lib.load()
+    _need(out, "out"); _need(part, "part")
+    n_part = part.shape[0]
+    if part.numel() != n_part * out.numel():
+        raise ValueError("reduce_parts: size mismatch")
+    check(lib.gode_reduce_parts_f32(ptr(out), ptr(part), n_part, out.numel(), float(scale), 1 if accumulate else 0,
+                                    stream_ptr()), "gode_reduce_parts_f32")
+    return out
+
+
+def colsum_(out, X, scale=1.0, accumulate=False):
+    """out (+)= scale * X.sum(0)."""
+    lib = _lib.load()
+    _need(out, "out"); _need(X, "X")
+    n, d = X.shape
+    if out.numel() != d:
+        raise ValueError("colsum: size mismatch")
+    sc = _scratch(X.device, lib.gode_colsum_scratch_bytes(n, d))
+    check(lib.gode_colsum_f32(ptr(out), ptr(X), n, d, float(scale), 1 if accumulate else 0, ptr(sc), stream_ptr()),
+          "gode_colsum_f32")
+    return out

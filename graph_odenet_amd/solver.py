@@ -1,0 +1,224 @@
+"""Own ODE solver behind the torchdiffeq seam of the reference (GCN/models.py:5,192).
+
+torchdiffeq is an un-vendored third-party dependency of the reference; this
+module re-creates the two methods the hot path needs from the published algorithms
+(see oracle/solver_ref.py for the restatement and its sources):
+
+  * fixed-grid `rk4`  : 3/8-rule steps on a uniform grid (options['step_size']);
+  * adaptive `dopri5` : Dormand-Prince 5(4), FSAL, RMS mixed-tolerance error ratio per
+                        state tensor, safety 0.9 / ifactor 10 / dfactor 0.2, 4th-order
+                        interpolation to the end time (the reference's default: no
+                        `method=` is passed, rtol = atol = 1e-5);
+  * `odeint_adjoint`  : O(1)-memory adjoint; the augmented state (y, a, [a_t], a_theta) is
+                        integrated backwards with the same method.
+
+All state arithmetic (stage inputs, solution combine, error ratio, interpolation) runs in
+the HIP kernels of csrc/rk.hip through `ops`; the vector field is a "field" object that
+consumes stage inputs as (coef, tensor) term lists so that a fused field (gcn_ode.py) never
+materialises them.  Step acceptance is host logic (one device->host sync per adaptive step).
+"""
+import math
+
+import torch
+
+from . import ops
+
+# 3/8-rule (Kutta 1901): c = [0, 1/3, 2/3, 1]
+RK38_C = [0.0, 1.0 / 3.0, 2.0 / 3.0, 1.0]
+RK38_A = [[], [1.0 / 3.0], [-1.0 / 3.0, 1.0], [1.0, -1.0, 1.0]]
+RK38_B = [1.0 / 8.0, 3.0 / 8.0, 3.0 / 8.0, 1.0 / 8.0]
+
+DP_C = [0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+DP_A = [
+    [],
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+DP_B = [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0]
+DP_E = [
+    35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+    -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1.0 / 60.0,
+]
+DP_MID = [
+    6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+    187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2,
+]
+
+
+class Field:
+    """A vector field over a list of state components.
+
+    eval(t, terms, out): terms[c] is the (coef, tensor) list whose sum is the stage value of
+    component c; out[c] receives d(component c)/dt.  t is a python float.
+    """
+    n_components = 1
+
+    def eval(self, t, terms, out):   # pragma: no cover - interface
+        raise NotImplementedError
+
+
+def _stage_terms(y, ks, coefs, h):
+    """terms of  y + h * sum_j coefs[j] * ks[j]  per component (zero coefficients dropped)."""
+    nc = len(y)
+    out = []
+    for c in range(nc):
+        tl = [(1.0, y[c])]
+        for j, a in enumerate(coefs):
+            if a != 0.0:
+                tl.append((h * a, ks[j][c]))
+        out.append(tl)
+    return out
+
+
+def _alloc_like(y, n):
+    return [[torch.empty_like(c) for c in y] for _ in range(n)]
+
+
+def uniform_grid(t0, t1, step_size):
+    """Number of equal steps covering [t0, t1] with |h| <= step_size (last step not shortened:
+    the grid is re-spaced uniformly, which coincides with torchdiffeq's grid whenever
+    (t1-t0)/step_size is an integer, e.g. 1/16 on [0,1])."""
+    if step_size is None:
+        return 1
+    n = int(math.ceil(abs(t1 - t0) / step_size - 1e-9))
+    return max(n, 1)
+
+
+def integrate_rk4(field, y, t0, t1, n_steps, work=None):
+    """In-place 3/8-rule integration of the component list y from t0 to t1. Returns nfe."""
+    ks = work if work is not None else _alloc_like(y, 4)
+    h = (t1 - t0) / n_steps
+    nfe = 0
+    for i in range(n_steps):
+        t = t0 + i * h
+        for s in range(4):
+            field.eval(t + RK38_C[s] * h, _stage_terms(y, ks, RK38_A[s], h), ks[s])
+            nfe += 1
+        for c in range(len(y)):
+            ops.lincomb_(y[c], [(1.0, y[c])] + [(h * RK38_B[s], ks[s][c]) for s in range(4)])
+    return nfe
+
+
+class Dopri5Stats:
+    def __init__(self):
+        self.accepted = 0
+        self.rejected = 0
+        self.nfe = 0
+
+
+def _rms_scaled(terms_per_comp, y, rtol, atol):
+    """sqrt( sum_c sum_i (v_ci / (atol + rtol*|y_ci|))^2 / sum_c numel_c )  -> python float (syncs)."""
+    outs = [ops.rk_scaled_sumsq(terms_per_comp[c], y[c], rtol, atol) for c in range(len(y))]
+    tot = torch.cat(outs).sum().item()
+    n = sum(c.numel() for c in y)
+    return math.sqrt(tot / n)
+
+
+def _initial_step(field, t0, y, f0, rtol, atol, sgn, scratch_y, scratch_f, stats):
+    nc = len(y)
+    d0 = _rms_scaled([[(1.0, y[c])] for c in range(nc)], y, rtol, atol)
+    d1 = _rms_scaled([[(1.0, f0[c])] for c in range(nc)], y, rtol, atol)
+    if d0 < 1e-5 or d1 < 1e-5:
+        h0 = 1e-6
+    else:
+        h0 = 0.01 * d0 / d1
+    field.eval(t0 + sgn * h0, [[(1.0, y[c]), (sgn * h0, f0[c])] for c in range(nc)], scratch_f)
+    stats.nfe += 1
+    d2 = _rms_scaled([[(1.0, scratch_f[c]), (-1.0, f0[c])] for c in range(nc)], y, rtol, atol) / h0
+    if d1 <= 1e-15 and d2 <= 1e-15:
+        h1 = max(1e-6, h0 * 1e-3)
+    else:
+        h1 = (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+    return min(100 * h0, h1)
+
+
+def _optimal_step(last, ratio, safety=0.9, ifactor=10.0, dfactor=0.2, order=5):
+    if ratio == 0:
+        return last * ifactor
+    if ratio < 1:
+        dfactor = 1.0
+    er = math.sqrt(ratio)
+    factor = max(1.0 / ifactor, min(er ** (1.0 / order) / safety, 1.0 / dfactor))
+    return last / factor
+
+
+def integrate_dopri5(field, y, t0, t1, rtol, atol, stats=None, max_steps=100000):
+    """In-place adaptive integration of the component list y from t0 to t1 (either direction)."""
+    stats = stats if stats is not None else Dopri5Stats()
+    nc = len(y)
+    sgn = 1.0 if t1 >= t0 else -1.0
+    span = abs(t1 - t0)
+    ks = _alloc_like(y, 7)
+    y1 = [torch.empty_like(c) for c in y]
+    tmp = [torch.empty_like(c) for c in y]
+    field.eval(t0, [[(1.0, y[c])] for c in range(nc)], ks[0])
+    stats.nfe += 1
+    dt = _initial_step(field, t0, y, ks[0], rtol, atol, sgn, tmp, y1, stats)
+    tau = 0.0                      # elapsed |t - t0|
+    fsal = 0                       # index of the buffer that currently holds f(t, y)
+    last = None
+    steps = 0
+    while tau < span:
+        steps += 1
+        if steps > max_steps:
+            raise RuntimeError("dopri5: max_num_steps exceeded")
+        h = sgn * dt
+        # stage buffers: slot 0 is whichever buffer holds the FSAL value
+        order = [fsal] + [i for i in range(7) if i != fsal]
+        kk = [ks[i] for i in order]
+        t = t0 + sgn * tau
+        for s in range(1, 7):
+            field.eval(t + DP_C[s] * h, _stage_terms(y, kk, DP_A[s], h), kk[s])
+            stats.nfe += 1
+        for c in range(nc):
+            ops.lincomb_(y1[c], [(1.0, y[c])] + [(h * DP_B[s], kk[s][c]) for s in range(7) if DP_B[s] != 0.0])
+        sums = [ops.rk_error_sumsq(y[c], y1[c], [(h * DP_E[s], kk[s][c]) for s in range(7) if DP_E[s] != 0.0],
+                                   rtol, atol) for c in range(nc)]
+        sums = torch.cat(sums).tolist()          # the one device->host sync of this step
+        groups = getattr(field, "ratio_groups", None) or [[c] for c in range(nc)]
+        ratios = [sum(sums[c] for c in grp) / sum(y[c].numel() for c in grp) for grp in groups]
+        ratio = max(ratios)
+        if all(r <= 1.0 for r in ratios):
+            stats.accepted += 1
+            if tau + dt >= span:
+                # interpolate back to the end time with the 4th-order fit through (y0, y_mid, y1, f0, f1)
+                x = (span - tau) / dt
+                if x >= 1.0:
+                    for c in range(nc):
+                        y[c].copy_(y1[c])
+                else:
+                    x2, x3, x4 = x * x, x * x * x, x * x * x * x
+                    wm = 16 * x4 - 32 * x3 + 16 * x2
+                    cy0 = -8 * x4 + 18 * x3 - 11 * x2 + 1 + wm
+                    cy1 = -8 * x4 + 14 * x3 - 5 * x2
+                    cf0 = -2 * x4 + 5 * x3 - 4 * x2 + x
+                    cf1 = 2 * x4 - 3 * x3 + x2
+                    kc = [wm * m for m in DP_MID]
+                    kc[0] += cf0
+                    kc[6] += cf1
+                    for c in range(nc):
+                        ops.lincomb_(y[c], [(cy0, y[c]), (cy1, y1[c])] +
+                                     [(h * kc[s], kk[s][c]) for s in range(7) if kc[s] != 0.0])
+                tau = span
+                break
+            y, y1 = y1, y
+            last = y1
+            tau += dt
+            fsal = order[6]
+        else:
+            stats.rejected += 1
+        dt = _optimal_step(dt, ratio)
+    return y, stats
+
+
+def integrate_dopri5_inplace(field, y, t0, t1, rtol, atol, stats=None):
+    """Wrapper keeping the caller's tensors as the result holders."""
+    res, stats = integrate_dopri5(field, list(y), t0, t1, rtol, atol, stats)
+    for dst, src in zip(y, res):
+        if dst.data_ptr() != src.data_ptr():
+            dst.copy_(src)
+    return stats

@@ -1,0 +1,146 @@
+/*
+ * graphode.h — C ABI of libgraphode.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary of the graph-odenet hot path: the ATen call
+ * sites the reference reaches from its layers are replaced by
+ * the entry points below.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - all matrices are row-major fp32, indices are int32;
+ *   - the caller owns every buffer (scratch included); nothing here allocates,
+ *     frees or synchronises; all launches are asynchronous on `stream`
+ *     (a hipStream_t passed as void*);
+ *   - return value: 0 = success, >0 = hipError_t of a failed launch,
+ *     <0 = argument-validation code (GODE_E_*); no C++ exception crosses.
+ *
+ * Reference call sites replaced (paths relative to the reference checkout):
+ *   gode_spmm_csr_f32            GCN/layers.py:33,71   torch.spmm(adj, support) (+bias :35,73; relu GCN/models.py:178)
+ *                                GAT/layers.py:53,55   torch.spmm(Mtgt, .)      QC/mpnn.py:29, QC/layers.py:145
+ *   gode_gn_time_gemm_f32        GCN/models.py:175-177 GroupNorm, [t|x] concat; GCN/layers.py:70 torch.mm
+ *   gode_gn_time_gemm_bwd_f32    autograd of the three sites above
+ *   gode_wgrad_f32               autograd of GCN/layers.py:70 w.r.t. weight
+ *   gode_lincomb_f32             torchdiffeq RK stage input / solution combine (call site GCN/models.py:192)
+ *   gode_rk_errnorm_f32          torchdiffeq dopri5 mixed-tolerance error ratio (same call site)
+ *   gode_edge_softmax_*          GAT/layers.py:40-55 (and :104-120)
+ *   gode_edge_matvec_*           QC/mpnn.py:27-29, QC/layers.py:143-145
+ */
+#ifndef GRAPHODE_H
+#define GRAPHODE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GODE_ABI_VERSION 1
+
+#define GODE_E_NULLPTR  (-1)
+#define GODE_E_SHAPE    (-2)
+#define GODE_E_ALIGN    (-3)
+#define GODE_E_RANGE    (-4)
+#define GODE_E_UNSUPPORTED (-5)
+
+#define GODE_MAX_TERMS 8
+
+/* value(i) = sum_j coef[j] * ptr[j][i]; every ptr[j] is a contiguous array of
+ * the same length.  Used for RK stage inputs y + h*sum(a_ij k_j), the RK
+ * solution combine and the cotangent fed to a VJP. */
+typedef struct gode_lincomb {
+    int32_t      n;                      /* 0..GODE_MAX_TERMS */
+    float        coef[GODE_MAX_TERMS];
+    const float* ptr[GODE_MAX_TERMS];
+} gode_lincomb_t;
+
+int         gode_abi_version(void);
+const char* gode_error_string(int code);   /* host string, static storage */
+
+/* ---- sparse aggregation -------------------------------------------------
+ * Z = A * X (+ bias);  Y = relu ? max(Z,0) : Z
+ * optional second output  Y2 = (sum_j cot.coef[j]*cot.ptr[j]) * (Z > 0)
+ * (the relu-masked cotangent the adjoint pass needs; cot rows have ld = d).
+ *
+ * A is CSR (rowptr[n_rows+1], col[nnz], val[nnz] or NULL = all ones).
+ * `items` (nullable) is the nnz-balanced work list built once per graph by
+ * the host: n_items records of 4 int32 {row, begin, end, slot}; a row whose
+ * record has slot < 0 is complete in one record and is written with the
+ * epilogue; rows split over several records (slot >= 0) write raw partial sums
+ * to partial[slot*d .. ] and are finished by the `long_rows` list: n_long
+ * records of 4 int32 {row, first_slot, last_slot_exclusive, 0}.
+ * With items == NULL every row is one record (n_items ignored).
+ */
+int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                      const int32_t* items, int64_t n_items,
+                      const int32_t* long_rows, int64_t n_long, float* partial,
+                      const float* X, int64_t ldx, float* Y, int64_t ldy,
+                      int64_t n_rows, int64_t d,
+                      const float* bias, int relu,
+                      const gode_lincomb_t* cot /* host, nullable */, float* Y2,
+                      void* stream);
+
+/* ---- Runge-Kutta elementwise steps -------------------------------------- */
+/* out[i] = sum_j lc.coef[j]*lc.ptr[j][i],  i < n.  out may alias any ptr[j]. */
+int gode_lincomb_f32(float* out, const gode_lincomb_t* lc /* host */, int64_t n, void* stream);
+
+/* dopri5 acceptance test (torchdiffeq _compute_error_ratio):
+ *   err = sum_j elc.coef[j]*elc.ptr[j][i];  tol = atol + rtol*max(|y0[i]|,|y1[i]|)
+ *   out[0] = sum_i (err/tol)^2   (fp64, deterministic two-stage reduction)
+ * scratch: >= gode_rk_errnorm_scratch_bytes() bytes. */
+int64_t gode_rk_errnorm_scratch_bytes(void);
+int gode_rk_errnorm_f32(double* out, const float* y0, const float* y1,
+                        const gode_lincomb_t* elc /* host */, float rtol, float atol,
+                        int64_t n, void* scratch, void* stream);
+
+/* sum of squares of sum_j lc.coef[j]*lc.ptr[j][i] / (atol + rtol*|y[i]|) (initial-step heuristic), fp64 */
+int gode_rk_scaled_sumsq_f32(double* out, const gode_lincomb_t* lc /* host */, const float* y,
+                             float rtol, float atol, int64_t n, void* scratch, void* stream);
+
+/* ---- ODEfunc dense part: S = [t | GroupNorm(x)] * W ---------------------
+ * x(i,:) = sum_j xin.coef[j]*xin.ptr[j][i,:]   (stage input formed on the fly)
+ * xn = GroupNorm(groups, eps)(x) * gamma + beta   (per row; gamma/beta NULL = identity affine;
+ *                                                  groups == 0 = no normalisation)
+ * S  = t * W[0,:] + xn * W[1:,:]     W is (d_in+1) x d_out row-major  (has_time = 1)
+ * S  =              xn * W          W is  d_in    x d_out             (has_time = 0)
+ */
+int gode_gn_time_gemm_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d_in,
+                          int32_t groups, float eps, const float* gamma, const float* beta,
+                          const float* W, int64_t d_out, int has_time, float t,
+                          float* S, void* stream);
+
+/* VJP of the above w.r.t. x:  dxn = dS * W[has_time:,:]^T ; dx = GroupNorm'(x)^T dxn
+ * out[i,:] = out_scale * dx[i,:]   (out_scale = 1 for a plain VJP).
+ * Also accumulates (when non-NULL) the per-row reductions needed for the
+ * parameter gradients into fp32 buffers of block partials:
+ *   dgamma_part/dbeta_part : [n_part][d_in]   (n_part = gode_gemm_bwd_parts(n_rows))
+ */
+int64_t gode_gemm_bwd_parts(int64_t n_rows);
+int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d_in,
+                              int32_t groups, float eps, const float* gamma,
+                              const float* W, int64_t d_out, int has_time,
+                              const float* dS, float out_scale, float* dx,
+                              float* dgamma_part, float* dbeta_part, void* stream);
+
+/* dW = [1 | xn]^T * dS  ((d_in+has_time) x d_out) as n_part block partials
+ * dW_part[n_part][(d_in+has_time)*d_out]; the caller sums over parts
+ * (gode_reduce_parts_f32).  With has_time, row 0 holds the plain column sums of dS
+ * (the gradient w.r.t. a unit time column): dW[0,:] = t * row0 and dL/dt = row0 . W[0,:]. */
+int64_t gode_wgrad_parts(int64_t n_rows);
+int gode_wgrad_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d_in,
+                   int32_t groups, float eps, const float* gamma, const float* beta,
+                   const float* dS, int64_t d_out, int has_time,
+                   float* dW_part, void* stream);
+
+/* out[j] (+)= scale * sum_p part[p*len + j]   (accumulate != 0 adds to out) */
+int gode_reduce_parts_f32(float* out, const float* part, int64_t n_part, int64_t len,
+                          float scale, int accumulate, void* stream);
+
+/* column sums: out[c] (+)= scale * sum_i X[i,c]  (bias gradient) */
+int gode_colsum_f32(float* out, const float* X, int64_t n_rows, int64_t d, float scale,
+                    int accumulate, float* scratch /* >= gode_colsum_scratch_bytes */, void* stream);
+int64_t gode_colsum_scratch_bytes(int64_t n_rows, int64_t d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHODE_H */

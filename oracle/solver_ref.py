@@ -1,0 +1,267 @@
+"""ORACLE (test infrastructure, NOT product code) — PARITY UNPINNED at this boundary.
+
+CPU restatement of the ODE solver the reference calls at GCN/models.py:192
+(`odeint_adjoint(self.odefunc, x, self.integration_time, rtol=self.tol, atol=self.tol)`).
+The solver is the third-party package torchdiffeq: un-vendored, un-pinned (no requirements
+file; code era 2019 => torchdiffeq 0.0.1), absent from /root/reference and from this image.
+The reference holds no test or golden vector at this boundary, so this restatement is
+pinned only by (a) analytic solutions, (b) scipy.integrate.solve_ivp(RK45) at the same
+tolerances and (c) the published Dormand-Prince / 3/8-rule tableaux — see
+tests/test_solver_oracle.py.  "parity unpinned".
+
+Published algorithm restated here (Chen et al., "Neural Ordinary Differential Equations",
+NeurIPS 2018, Appendix B/C; Dormand & Prince 1980; Shampine 1986 for the mid-point
+interpolant; torchdiffeq 0.0.1's documented controller: safety 0.9, ifactor 10, dfactor 0.2,
+RMS mixed-tolerance norm per state tensor, initial step by Hairer-Norsett-Wanner II.4):
+
+  * fixed-grid `rk4` = the 3/8 rule (k2 at t+h/3, k3 at t+2h/3), grid = `t` itself unless
+    options['step_size'] is given;
+  * adaptive `dopri5` (default when method is None): FSAL, error ratio
+    mean((err / (atol + rtol*max(|y0|,|y1|)))^2) <= 1 for EVERY state tensor, step factor
+    from the largest ratio, 4th-order interpolation to the requested output times;
+  * adjoint backward: augmented state (y, a, a_t, a_theta) integrated from t[i] to t[i-1]
+    with the same method/tolerances; one extra func eval per output time for dL/dt.
+
+Plain torch CPU ops only; `func(t, y)` is any callable (nn.Module for the adjoint).
+"""
+import torch
+
+# ---- Dormand-Prince 5(4), Shampine's dense-output mid-point weights -----------------
+DP_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+DP_BETA = [
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+DP_C_SOL = [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0]
+DP_C_ERR = [
+    35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+    -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1.0 / 60.0,
+]
+DP_C_MID = [
+    6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+    187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2,
+]
+
+
+def _as_tuple(y):
+    return ((y,), True) if torch.is_tensor(y) else (tuple(y), False)
+
+
+def _rms(x):
+    return x.norm() / (x.numel() ** 0.5)
+
+
+def _rms_tuple(xs):
+    return torch.sqrt(sum(x.norm() ** 2 for x in xs) / sum(x.numel() for x in xs))
+
+
+def rk4_38_step(func, t, dt, y):
+    """3/8-rule step on a tuple state; returns the increment."""
+    k1 = func(t, y)
+    k2 = func(t + dt / 3, tuple(y_ + dt * k1_ / 3 for y_, k1_ in zip(y, k1)))
+    k3 = func(t + dt * 2 / 3, tuple(y_ + dt * (k2_ - k1_ / 3) for y_, k1_, k2_ in zip(y, k1, k2)))
+    k4 = func(t + dt, tuple(y_ + dt * (k1_ - k2_ + k3_) for y_, k1_, k2_, k3_ in zip(y, k1, k2, k3)))
+    return tuple((k1_ + 3 * (k2_ + k3_) + k4_) * (dt / 8) for k1_, k2_, k3_, k4_ in zip(k1, k2, k3, k4))
+
+
+def _grid(t, step_size):
+    if step_size is None:
+        return t
+    t0, t1 = float(t[0]), float(t[-1])
+    n = int(torch.ceil(torch.tensor(abs(t1 - t0) / step_size + 1)).item())
+    sign = 1.0 if t1 >= t0 else -1.0
+    grid = t0 + sign * step_size * torch.arange(n, dtype=t.dtype)
+    if (sign > 0 and grid[-1] > t1) or (sign < 0 and grid[-1] < t1) or grid[-1] != t1:
+        grid[-1] = t1
+    return grid
+
+
+def _odeint_fixed_rk4(func, y0, t, step_size):
+    grid = _grid(t, step_size)
+    sol = [y0]
+    j = 1
+    y = y0
+    for t0, t1 in zip(grid[:-1], grid[1:]):
+        dy = rk4_38_step(func, t0, t1 - t0, y)
+        y1 = tuple(a + b for a, b in zip(y, dy))
+        while j < len(t) and ((t1 >= t[j]) if t[-1] >= t[0] else (t1 <= t[j])):
+            # linear interpolation between grid points (identity when t[j] is a grid point)
+            if t1 == t[j]:
+                sol.append(y1)
+            else:
+                w = (t[j] - t0) / (t1 - t0)
+                sol.append(tuple(a + w * (b - a) for a, b in zip(y, y1)))
+            j += 1
+        y = y1
+    return sol
+
+
+def _select_initial_step(func, t0, y0, order, rtol, atol, f0):
+    scale = tuple(atol + y.abs() * rtol for y in y0)
+    d0 = _rms_tuple(tuple(y / s for y, s in zip(y0, scale)))
+    d1 = _rms_tuple(tuple(f / s for f, s in zip(f0, scale)))
+    if d0 < 1e-5 or d1 < 1e-5:
+        h0 = torch.tensor(1e-6, dtype=t0.dtype)
+    else:
+        h0 = 0.01 * d0 / d1
+    y1 = tuple(y + h0 * f for y, f in zip(y0, f0))
+    f1 = func(t0 + h0, y1)
+    d2 = _rms_tuple(tuple((a - b) / s for a, b, s in zip(f1, f0, scale))) / h0
+    if d1 <= 1e-15 and d2 <= 1e-15:
+        h1 = torch.max(torch.tensor(1e-6, dtype=t0.dtype), h0 * 1e-3)
+    else:
+        h1 = (0.01 / max(float(d1), float(d2))) ** (1.0 / float(order + 1))
+    return min(float(100 * h0), float(h1))
+
+
+def _dopri5_step(func, y0, f0, t0, dt):
+    k = [f0]
+    for alpha_i, beta_i in zip(DP_ALPHA, DP_BETA):
+        ti = t0 + alpha_i * dt
+        yi = tuple(y + sum(b * kk[c] for b, kk in zip(beta_i, k) if b != 0) * dt for c, y in enumerate(y0))
+        k.append(func(ti, yi))
+    y1 = tuple(y + dt * sum(c * kk[i] for c, kk in zip(DP_C_SOL, k) if c != 0) for i, y in enumerate(y0))
+    f1 = k[-1]
+    err = tuple(dt * sum(c * kk[i] for c, kk in zip(DP_C_ERR, k) if c != 0) for i in range(len(y0)))
+    return y1, f1, err, k
+
+
+def _error_ratio(err, rtol, atol, y0, y1):
+    out = []
+    for e, a, b in zip(err, y0, y1):
+        tol = atol + rtol * torch.max(a.abs(), b.abs())
+        r = e / tol
+        out.append(float((r * r).mean()))
+    return out
+
+
+def _optimal_step(last_step, ratios, safety=0.9, ifactor=10.0, dfactor=0.2, order=5):
+    m = max(ratios)
+    if m == 0:
+        return last_step * ifactor
+    if m < 1:
+        dfactor = 1.0
+    err_ratio = m ** 0.5
+    factor = max(1.0 / ifactor, min(err_ratio ** (1.0 / order) / safety, 1.0 / dfactor))
+    return last_step / factor
+
+
+def _interp_fit(y0, y1, k, dt):
+    out = []
+    for i in range(len(y0)):
+        y_mid = y0[i] + dt * sum(c * kk[i] for c, kk in zip(DP_C_MID, k) if c != 0)
+        f0, f1 = k[0][i], k[-1][i]
+        a = 2 * dt * (f1 - f0) - 8 * (y1[i] + y0[i]) + 16 * y_mid
+        b = dt * (5 * f0 - 3 * f1) + 18 * y0[i] + 14 * y1[i] - 32 * y_mid
+        c = dt * (f1 - 4 * f0) - 11 * y0[i] - 5 * y1[i] + 16 * y_mid
+        d = dt * f0
+        e = y0[i]
+        out.append((a, b, c, d, e))
+    return out
+
+
+def _interp_eval(coeffs, t0, t1, t):
+    x = float((t - t0) / (t1 - t0))
+    out = []
+    for (a, b, c, d, e) in coeffs:
+        out.append((((a * x + b) * x + c) * x + d) * x + e)
+    return tuple(out)
+
+
+def _odeint_dopri5(func, y0, t, rtol, atol, stats=None):
+    sign = 1.0 if t[-1] >= t[0] else -1.0
+    if sign < 0:   # integrate in reversed time (torchdiffeq flips t and negates func)
+        f_user = func
+        func = lambda tt, yy: tuple(-v for v in f_user(-tt, yy))   # noqa: E731
+        t = -t
+    tcur = t[0]
+    f0 = func(tcur, y0)
+    dt = _select_initial_step(func, tcur, y0, 4, rtol, atol, f0)
+    y = y0
+    sol = [y0]
+    t_prev, interp = tcur, None
+    n_acc = n_rej = 0
+    for j in range(1, len(t)):
+        while t[j] > tcur:
+            y1, f1, err, k = _dopri5_step(func, y, f0, tcur, dt)
+            ratios = _error_ratio(err, rtol, atol, y, y1)
+            accept = all(r <= 1 for r in ratios)
+            if accept:
+                interp = _interp_fit(y, y1, k, dt)
+                t_prev, tcur = tcur, tcur + dt
+                y, f0 = y1, f1
+                n_acc += 1
+            else:
+                n_rej += 1
+            dt = _optimal_step(dt, ratios)
+        sol.append(_interp_eval(interp, t_prev, tcur, t[j]))
+    if stats is not None:
+        stats["accepted"] = n_acc
+        stats["rejected"] = n_rej
+    return sol
+
+
+def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, stats=None):
+    """Returns a tensor [len(t), *y0.shape] (or a tuple of such for a tuple state)."""
+    y0t, is_tensor = _as_tuple(y0)
+    f = (lambda tt, yy: (func(tt, yy[0]),)) if is_tensor else func
+    options = options or {}
+    if method in (None, "dopri5"):
+        sol = _odeint_dopri5(f, y0t, t, rtol, atol, stats)
+    elif method == "rk4":
+        sol = _odeint_fixed_rk4(f, y0t, t, options.get("step_size"))
+    else:
+        raise ValueError("oracle solver: unknown method %r" % (method,))
+    out = tuple(torch.stack([s[i] for s in sol]) for i in range(len(y0t)))
+    return out[0] if is_tensor else out
+
+
+class _Adjoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, func, t, rtol, atol, method, options, y0, *params):
+        with torch.no_grad():
+            ans = odeint(func, y0, t, rtol, atol, method, options)
+        ctx.func, ctx.rtol, ctx.atol, ctx.method, ctx.options = func, rtol, atol, method, options
+        ctx.save_for_backward(t, ans, *params)
+        return ans
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        t, ans, *params = ctx.saved_tensors
+        func = ctx.func
+        params = tuple(params)
+
+        def aug(tt, state):
+            y, a = state[0], state[1]
+            with torch.enable_grad():
+                tt_ = tt.detach().requires_grad_(True)
+                y_ = y.detach().requires_grad_(True)
+                fe = func(tt_, y_)
+                vj = torch.autograd.grad(fe, (tt_, y_) + params, -a, allow_unused=True)
+            vt = vj[0] if vj[0] is not None else torch.zeros_like(tt)
+            vy = vj[1] if vj[1] is not None else torch.zeros_like(y)
+            vp = [v if v is not None else torch.zeros_like(p) for v, p in zip(vj[2:], params)]
+            return (fe.detach(), vy, vt.reshape(()), *vp)
+
+        with torch.no_grad():
+            adj_y = grad_out[-1].clone()
+            adj_t = torch.zeros((), dtype=t.dtype)
+            adj_p = [torch.zeros_like(p) for p in params]
+            for i in range(len(t) - 1, 0, -1):
+                f_i = func(t[i], ans[i])
+                adj_t = adj_t - (f_i * grad_out[i]).sum()
+                state = (ans[i], adj_y, adj_t, *adj_p)
+                sol = odeint(aug, state, torch.stack([t[i], t[i - 1]]), ctx.rtol, ctx.atol, ctx.method, ctx.options)
+                adj_y = sol[1][1] + grad_out[i - 1]
+                adj_t = sol[2][1]
+                adj_p = [s[1] for s in sol[3:]]
+        return (None, None, None, None, None, None, adj_y, *adj_p)
+
+
+def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):
+    params = tuple(p for p in func.parameters() if p.requires_grad)
+    return _Adjoint.apply(func, t, rtol, atol, method, options, y0, *params)

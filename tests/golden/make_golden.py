@@ -1,0 +1,237 @@
+"""Generates tests/golden/*.npz by importing the REFERENCE's own classes from
+/root/reference (build container only; the reference never travels to the GPU box).
+
+Run:  python tests/golden/make_golden.py
+What is captured (inputs AND expected outputs, fp32):
+  gcn_layer.npz      GraphConvolution / FixedGraphConvolution fwd + grads   (GCN/layers.py)
+  gcn_odefunc_*.npz  ODEfunc fwd + VJP at d in {16, 64, 128}                (GCN/models.py:161-179)
+  gcn_odefunc2.npz   ODEfunc2 fwd + VJP                                     (GCN/models.py:551-575)
+  gcn3_cora.npz      GCN3 / RGCN3 eval logits on real Cora with fixed weights (GCN/models.py, GCN/utils.py)
+  cora_graph.npz / citeseer_graph.npz   loader outputs (GCN/utils.py:134-229, GAT/utils.py:187-209)
+  gat_layer.npz      GAT GraphConvolution fwd + grads                        (GAT/layers.py)
+  gat_odefunc.npz    GAT ODEfunc fwd + VJP                                   (GAT/models.py:161-179)
+  qc_layers.npz      MPNN_enn_edge (T=1,3) and EdgeGraphConvolution fwd + grads (QC/mpnn.py, QC/layers.py)
+  scatter_kat.npz    the scatter_add docstring known-answer vector           (QC/torch_scatter.py:207-218)
+
+`torchdiffeq` is absent from the image; an EMPTY stand-in module object is registered so
+that `models.py` imports.  No solver is ever called through it (parity at the solver
+boundary stays unpinned, see oracle/solver_ref.py).
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def ref_import(subdir, *names):
+    """Import reference modules by bare name from REF/subdir (as its scripts do)."""
+    for n in ("layers", "models", "utils", "mpnn"):
+        sys.modules.pop(n, None)
+    sys.path.insert(0, os.path.join(REF, subdir))
+    try:
+        return [importlib.import_module(n) for n in names]
+    finally:
+        sys.path.pop(0)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+def rand_graph(n, nnz, seed, normalize=True, dup=True):
+    g = torch.Generator().manual_seed(seed)
+    r = torch.randint(0, n, (nnz,), generator=g)
+    c = torch.randint(0, n, (nnz,), generator=g)
+    if dup:   # uncoalesced: repeat some entries (torch.spmm sums duplicates)
+        r = torch.cat([r, r[:nnz // 10]])
+        c = torch.cat([c, c[:nnz // 10]])
+    v = torch.rand(r.numel(), generator=g) + 0.1
+    if normalize:
+        deg = torch.zeros(n).index_add_(0, r, v)
+        v = v / deg[r]
+    return r, c, v
+
+
+def main():
+    sys.dont_write_bytecode = True
+    stub = types.ModuleType("torchdiffeq")
+    stub.odeint_adjoint = None
+    stub.odeint = None
+    sys.modules["torchdiffeq"] = stub
+    # scipy >= 1.8 moved this private module; GCN/utils.py:8 imports an unused symbol from it
+    import scipy.sparse.linalg as spla
+    alias = types.ModuleType("scipy.sparse.linalg.eigen.arpack")
+    alias.eigsh = spla.eigsh
+    sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
+    sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
+
+    torch.manual_seed(0)
+
+    # ---------------- GCN layer --------------------------------------------------
+    layers, models = ref_import("GCN", "layers", "models")
+    n, fi, fo = 300, 40, 16
+    r, c, v = rand_graph(n, 1500, 1)
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n))
+    x = torch.randn(n, fi, requires_grad=True)
+    gc = layers.GraphConvolution(fi, fo)
+    out = gc(x, adj)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    save("gcn_layer.npz", rows=r, cols=c, vals=v, n=n, x=x, weight=gc.weight, bias=gc.bias, out=out, gout=gout,
+         gx=x.grad, gw=gc.weight.grad, gb=gc.bias.grad)
+
+    # ---------------- ODEfunc fwd + VJP ------------------------------------------
+    for d in (16, 64, 128):
+        torch.manual_seed(10 + d)
+        n = 257
+        r, c, v = rand_graph(n, 1800, 2 + d)
+        adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n))
+        f = models.ODEfunc(d)
+        with torch.no_grad():   # non-trivial affine so that gamma/beta paths are exercised
+            f.norm1.weight.uniform_(0.5, 1.5)
+            f.norm1.bias.uniform_(-0.5, 0.5)
+        f.set_adj(adj)
+        x = torch.randn(n, d, requires_grad=True)
+        t = torch.tensor(0.37)
+        out = f(t, x)
+        gout = torch.randn_like(out)
+        out.backward(gout)
+        save("gcn_odefunc_%d.npz" % d, rows=r, cols=c, vals=v, n=n, t=t, x=x, gn_w=f.norm1.weight, gn_b=f.norm1.bias,
+             W=f.gc1.weight, b=f.gc1.bias, out=out, gout=gout, gx=x.grad, g_gn_w=f.norm1.weight.grad,
+             g_gn_b=f.norm1.bias.grad, gW=f.gc1.weight.grad, gb=f.gc1.bias.grad)
+
+    # ---------------- ODEfunc2 ----------------------------------------------------
+    torch.manual_seed(5)
+    d, n = 64, 200
+    r, c, v = rand_graph(n, 1200, 7)
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n))
+    f2 = models.ODEfunc2(d, 0.5)
+    f2.set_adj(adj)
+    x = torch.randn(n, d, requires_grad=True)
+    t = torch.tensor(0.61)
+    out = f2(t, x)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    sd = {k.replace(".", "__"): p for k, p in f2.state_dict().items()}
+    gd = {"g__" + k.replace(".", "__"): p.grad for k, p in f2.named_parameters()}
+    save("gcn_odefunc2.npz", rows=r, cols=c, vals=v, n=n, t=t, x=x, out=out, gout=gout, gx=x.grad, **sd, **gd)
+
+    # ---------------- real Cora / Citeseer through the reference loader -----------
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        (gutils,) = ref_import("GCN", "utils")
+        for ds in ("cora", "citeseer"):
+            adj, feats, labels, itr, iva, ite = gutils.load_data_new(ds)
+            idx = adj._indices()
+            fnz = feats.nonzero()
+            save("%s_graph.npz" % ds, rows=idx[0].to(torch.int32), cols=idx[1].to(torch.int32),
+                 vals=adj._values(), n=adj.shape[0], feat_rows=fnz[:, 0].to(torch.int32),
+                 feat_cols=fnz[:, 1].to(torch.int32), feat_vals=feats[fnz[:, 0], fnz[:, 1]],
+                 n_feat=feats.shape[1], labels=labels.to(torch.int16), idx_train=itr.to(torch.int32),
+                 idx_val=iva.to(torch.int32), idx_test=ite.to(torch.int32))
+            if ds == "cora":
+                torch.manual_seed(42)
+                res = {}
+                for name in ("GCN3", "RGCN3"):
+                    m = getattr(models, name)(nfeat=feats.shape[1], nhid=16, nclass=int(labels.max()) + 1, dropout=0.5)
+                    m.eval()
+                    with torch.no_grad():
+                        res[name + "__out"] = m(feats, adj)
+                    for k, p in m.state_dict().items():
+                        res[name + "__" + k.replace(".", "__")] = p
+                save("gcn3_cora.npz", **res)
+        # GAT edge list of citeseer (GAT/utils.py:187-209)
+        (gatutils,) = ref_import("GAT", "utils")
+        src, tgt, Mtgt, feats, labels, itr, iva, ite = gatutils.load_data_new("citeseer")
+        mi = Mtgt._indices()
+        save("citeseer_gat_edges.npz", src=src.to(torch.int32), tgt=tgt.to(torch.int32),
+             m_rows=mi[0].to(torch.int32), m_cols=mi[1].to(torch.int32), m_vals=Mtgt._values(), n=Mtgt.shape[0])
+    finally:
+        os.chdir(cwd)
+
+    # ---------------- GAT layer + ODEfunc ------------------------------------------
+    glayers, gmodels = ref_import("GAT", "layers", "models")
+    torch.manual_seed(3)
+    n, e, fi, fo = 120, 700, 24, 16
+    g = torch.Generator().manual_seed(11)
+    src = torch.randint(0, n, (e,), generator=g)
+    tgt = torch.randint(0, n - 10, (e,), generator=g)     # last 10 nodes never a target -> 0/eps rows
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(e)]), torch.ones(e), (n, e))
+    layer = glayers.GraphConvolution(fi, fo)
+    x = torch.randn(n, fi, requires_grad=True)
+    out = layer(x, src, tgt, Mtgt)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    save("gat_layer.npz", src=src, tgt=tgt, n=n, x=x, f_w=layer.f.weight, f_b=layer.f.bias, w_w=layer.w.weight,
+         w_b=layer.w.bias, out=out, gout=gout, gx=x.grad, g_f_w=layer.f.weight.grad, g_f_b=layer.f.bias.grad,
+         g_w_w=layer.w.weight.grad, g_w_b=layer.w.bias.grad)
+    d = 64
+    f = gmodels.ODEfunc(d)
+    f.set_adj(src, tgt, Mtgt)
+    x = torch.randn(n, d, requires_grad=True)
+    t = torch.tensor(0.25)
+    out = f(t, x)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    save("gat_odefunc.npz", src=src, tgt=tgt, n=n, t=t, x=x, gn_w=f.norm1.weight, gn_b=f.norm1.bias,
+         f_w=f.gc1.f.weight, f_b=f.gc1.f.bias, w_w=f.gc1.w.weight, w_b=f.gc1.w.bias, out=out, gout=gout, gx=x.grad,
+         g_f_w=f.gc1.f.weight.grad, g_f_b=f.gc1.f.bias.grad, g_w_w=f.gc1.w.weight.grad, g_w_b=f.gc1.w.bias.grad,
+         g_gn_w=f.norm1.weight.grad, g_gn_b=f.norm1.bias.grad)
+
+    # ---------------- QC layers ------------------------------------------------------
+    qlayers, qmpnn = ref_import("QC", "layers", "mpnn")
+    torch.manual_seed(4)
+    n, e, h = 14, 24, 73
+    g = torch.Generator().manual_seed(13)
+    Esrc = torch.randint(0, n, (e,), generator=g)
+    etgt = torch.randint(0, n, (e,), generator=g)
+    Etgt = torch.zeros(n, e)
+    Etgt[etgt, torch.arange(e)] = 1.0
+    edge_data = (torch.randn(e, h, h, generator=g) * 0.1).requires_grad_(True)
+    x = torch.randn(n, h, generator=g).requires_grad_(True)
+    res = dict(Esrc=Esrc, etgt=etgt, n=n, x=x, edge_data=edge_data)
+    for T in (1, 3):
+        m = qmpnn.MPNN_enn_edge(5, h)
+        m.set_T(T)
+        x.grad = None
+        edge_data.grad = None
+        out = m(x, Esrc, Etgt, edge_data)
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout)
+        res.update({"T%d__out" % T: out, "T%d__gout" % T: gout, "T%d__gx" % T: x.grad.clone(),
+                    "T%d__gedge" % T: edge_data.grad.clone()})
+        for k, p in m.update_net.state_dict().items():
+            res["T%d__gru__%s" % (T, k)] = p
+        for k, p in m.update_net.named_parameters():
+            res["T%d__ggru__%s" % (T, k)] = p.grad
+    egc = qlayers.EdgeGraphConvolution(h, h)
+    x.grad = None
+    edge_data.grad = None
+    out = egc(x, Esrc, Etgt, edge_data)
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+    res.update(egc__weight=egc.weight, egc__bias=egc.bias, egc__out=out, egc__gout=gout, egc__gx=x.grad,
+               egc__gedge=edge_data.grad, egc__gw=egc.weight.grad, egc__gb=egc.bias.grad)
+    save("qc_layers.npz", **res)
+
+    # ---------------- scatter_add docstring KAT (QC/torch_scatter.py:207-218) ---------
+    save("scatter_kat.npz", src=np.array([[2, 0, 1, 4, 3], [0, 2, 1, 3, 4]], dtype=np.float32),
+         index=np.array([[4, 5, 4, 2, 3], [0, 0, 2, 2, 1]], dtype=np.int64),
+         out=np.array([[0, 0, 4, 3, 3, 0], [2, 4, 4, 0, 0, 0]], dtype=np.float32))
+
+
+if __name__ == "__main__":
+    main()
