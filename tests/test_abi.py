@@ -1,0 +1,43 @@
+"""The C-ABI library loads and exports every symbol include/graphode.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+from graph_odenet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "graphode.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gode_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(lib, s), "missing export: " + s
+
+
+def test_python_binding_covers_header():
+    assert set(declared_symbols()) == set(_lib.SIGNATURES.keys())
+
+
+def test_load_and_version():
+    lib = _lib.load()
+    assert lib.gode_abi_version() == 1
+    assert b"NULL" in lib.gode_error_string(-1)
+
+
+def test_argument_validation_without_gpu():
+    """Validation codes come back before any HIP call, so they can be checked on CPU."""
+    lib = _lib.load()
+    assert lib.gode_lincomb_f32(None, None, -1, None) == -2        # GODE_E_SHAPE
+    assert lib.gode_lincomb_f32(None, None, 4, None) == -1         # GODE_E_NULLPTR
+    assert lib.gode_spmm_csr_f32(None, None, None, None, 0, None, 0, None, None, 4, None, 4, 3, 8,
+                                 None, 0, None, None, None) == -2  # ldx < d
+    assert lib.gode_spmm_csr_f32(None, None, None, None, 0, None, 0, None, None, 8, None, 8, 3, 8,
+                                 None, 0, None, None, None) == -1  # null pointers

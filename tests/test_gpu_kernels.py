@@ -1,0 +1,172 @@
+"""GPU parity of the C-ABI kernels against the oracle / plain torch CPU ops on the same seeded
+inputs.  Tolerance: 1e-5 (fp32, relative to the largest reference magnitude), as BASELINE.json
+states.  All calls go through libgraphode.so (graph_odenet_amd.ops)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def close(a, b, tol=TOL, what=""):
+    a = a.detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, "%s: max err %.3e (scale %.3e)" % (what, err, scale)
+
+
+def powerlaw_graph(n, m, avg, seed, long_row=None, empty=0, vals=True):
+    rs = np.random.RandomState(seed)
+    deg = rs.zipf(1.8, n).clip(1, max(4, 20 * avg))
+    deg[:empty] = 0
+    if long_row:
+        deg[empty] = long_row
+    rows = np.repeat(np.arange(n), deg)
+    cols = rs.randint(0, m, rows.size)
+    v = (rs.rand(rows.size).astype(np.float32) + 0.1) if vals else None
+    return torch.from_numpy(rows), torch.from_numpy(cols), (torch.from_numpy(v) if vals else None)
+
+
+@pytest.mark.parametrize("d", [4, 7, 16, 32, 64, 73, 128, 256])
+@pytest.mark.parametrize("pattern_only", [False, True])
+def test_spmm_matches_cpu(d, pattern_only):
+    from graph_odenet_amd import graph as G, ops
+    n, m = 1500, 1300
+    r, c, v = powerlaw_graph(n, m, 8, d, long_row=1000, empty=7, vals=not pattern_only)
+    vv = v if v is not None else torch.ones(r.numel())
+    A = torch.sparse_coo_tensor(torch.stack([r, c]), vv, (n, m))
+    g = G.from_coo(r.to(dev()), c.to(dev()), None if v is None else v.to(dev()), n, m, split=64)
+    assert g.n_long >= 1
+    X = torch.randn(m, d)
+    bias = torch.randn(d)
+    ref = torch.sparse.mm(A, X) + bias
+    out = ops.spmm(g, X.to(dev()), bias=bias.to(dev()), relu=False)
+    close(out, ref, what="spmm")
+    out = ops.spmm(g, X.to(dev()), bias=bias.to(dev()), relu=True)
+    close(out, ref.clamp_min(0), what="spmm+relu")
+    # transposed graph (backward direction)
+    Y = torch.randn(n, d)
+    close(ops.spmm(g.transpose(), Y.to(dev())), torch.sparse.mm(A.t(), Y), what="spmm^T")
+
+
+def test_spmm_masked_cotangent_epilogue():
+    from graph_odenet_amd import graph as G, ops
+    n, d = 900, 128
+    r, c, v = powerlaw_graph(n, n, 6, 3, long_row=700)
+    A = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n))
+    g = G.from_coo(r.to(dev()), c.to(dev()), v.to(dev()), n, n, split=128)
+    X, b = torch.randn(n, d), torch.randn(d)
+    a0, a1 = torch.randn(n, d), torch.randn(n, d)
+    Z = torch.sparse.mm(A, X) + b
+    out, out2 = ops.spmm(g, X.to(dev()), bias=b.to(dev()), relu=True,
+                         cot_terms=[(-1.0, a0.to(dev())), (0.25, a1.to(dev()))])
+    close(out, Z.clamp_min(0))
+    ref2 = (-a0 + 0.25 * a1) * (Z > 0)
+    # a handful of entries sit within rounding of the relu kink; compare where |Z| is clear of it
+    safe = Z.abs() > 1e-4
+    close(out2.cpu() * safe, ref2 * safe, what="masked cotangent")
+
+
+def test_spmm_row_sum_property_full_size():
+    """Size-independent property at BASELINE's full size (2^20 nodes, ~10M edges, d=128):
+    a row-normalised A_hat maps the all-ones matrix to all-ones, and SpMM is linear."""
+    from graph_odenet_amd import graph as G, ops
+    from graph_odenet_amd.synth import rmat_graph
+    g = rmat_graph(20, 10_000_000, seed=0, device=dev())
+    n, d = g.n_rows, 128
+    ones = torch.ones(n, d, device=dev())
+    out = ops.spmm(g, ones)
+    assert (out - 1).abs().max().item() < 1e-5
+    x1 = torch.randn(n, d, device=dev())
+    x2 = torch.randn(n, d, device=dev())
+    lhs = ops.spmm(g, 2.0 * x1 - 0.5 * x2)
+    rhs = 2.0 * ops.spmm(g, x1) - 0.5 * ops.spmm(g, x2)
+    assert (lhs - rhs).abs().max().item() < 1e-4
+    # <A x, y> == <x, A^T y>
+    y = torch.randn(n, d, device=dev())
+    a = (ops.spmm(g, x1).double() * y.double()).sum()
+    b = (x1.double() * ops.spmm(g.transpose(), y).double()).sum()
+    assert abs(a.item() - b.item()) <= 1e-6 * max(1.0, abs(a.item()))
+
+
+def test_lincomb_and_error_norms():
+    from graph_odenet_amd import ops
+    torch.manual_seed(0)
+    for n in (5, 1024, 100003):
+        xs = [torch.randn(n) for _ in range(6)]
+        cs = [1.0, 0.5, -0.25, 3.0, 1e-3, -2.0]
+        ref = sum(c * x for c, x in zip(cs, xs))
+        gx = [x.to(dev()) for x in xs]
+        out = torch.empty(n, device=dev())
+        ops.lincomb_(out, list(zip(cs, gx)))
+        close(out, ref, what="lincomb")
+        # in place
+        ops.lincomb_(gx[0], list(zip(cs, gx)))
+        close(gx[0], ref, what="lincomb in place")
+        y0, y1 = torch.randn(n), torch.randn(n)
+        err = 1e-4 * xs[1] - 2e-4 * xs[2]
+        ref_s = ((err / (1e-5 + 1e-5 * torch.max(y0.abs(), y1.abs()))).double() ** 2).sum()
+        got = ops.rk_error_sumsq(y0.to(dev()), y1.to(dev()), [(1e-4, gx[1]), (-2e-4, gx[2])], 1e-5, 1e-5)
+        assert abs(got.item() - ref_s.item()) <= 1e-4 * ref_s.item()
+        ref_n = ((xs[3] / (1e-5 + 1e-5 * y0.abs())).double() ** 2).sum()
+        got = ops.rk_scaled_sumsq([(1.0, gx[3])], y0.to(dev()), 1e-5, 1e-5)
+        assert abs(got.item() - ref_n.item()) <= 1e-4 * ref_n.item()
+
+
+def test_colsum_and_reduce_parts():
+    from graph_odenet_amd import ops
+    torch.manual_seed(1)
+    for n, d in ((1, 16), (300, 7), (5000, 128), (70000, 73)):
+        X = torch.randn(n, d)
+        out = torch.zeros(d, device=dev())
+        ops.colsum_(out, X.to(dev()), scale=-0.5)
+        close(out, -0.5 * X.double().sum(0).float(), tol=1e-5 * max(1, n ** 0.5), what="colsum")
+    P = torch.randn(37, 1000)
+    out = torch.ones(1000, device=dev())
+    ops.reduce_parts_(out, P.to(dev()), scale=2.0, accumulate=True)
+    close(out, 1 + 2 * P.sum(0), tol=1e-5 * 6)
+
+
+@pytest.mark.parametrize("d,groups", [(16, 16), (32, 32), (64, 32), (128, 32), (128, 0), (24, 24), (96, 32), (40, 8)])
+@pytest.mark.parametrize("n", [1, 257, 4100])
+def test_gn_time_gemm_fwd_bwd_wgrad(d, groups, n):
+    """GroupNorm + time column + GEMM against plain torch CPU ops (GCN/models.py:175-177 + layers.py:70)."""
+    from graph_odenet_amd import ops
+    import torch.nn.functional as F
+    torch.manual_seed(d * 7 + n)
+    y, k1 = torch.randn(n, d), torch.randn(n, d)
+    h = 0.3
+    x = (y + h * k1).requires_grad_(True)
+    gam = (torch.rand(d) + 0.5).requires_grad_(True)
+    bet = (torch.rand(d) - 0.5).requires_grad_(True)
+    W = (torch.randn(d + 1, d) / d ** 0.5).requires_grad_(True)
+    t = 0.37
+    xn = F.group_norm(x, groups, gam, bet, 1e-5) if groups else x
+    S = torch.cat([torch.full((n, 1), t), xn], 1) @ W
+    dS = torch.randn(n, d)
+    S.backward(dS)
+    D = dev()
+    terms = [(1.0, y.to(D)), (h, k1.to(D))]
+    g_, b_ = (gam.detach().to(D), bet.detach().to(D)) if groups else (None, None)
+    got = ops.gn_time_gemm(terms, n, d, groups, 1e-5, g_, b_, W.detach().to(D), True, t)
+    # at one channel per group the normalised value is rounding noise amplified by 1/sqrt(eps)=316
+    tol = TOL if (groups == 0 or d // max(groups, 1) > 1) else 2e-4
+    close(got, S, tol=tol, what="gn_time_gemm")
+    dx, dgp, dbp = ops.gn_time_gemm_bwd(terms, n, d, groups, 1e-5, g_, W.detach().to(D), True, dS.to(D))
+    close(dx, x.grad, tol=max(tol, 2e-5), what="dx")
+    if groups:
+        close(dgp.sum(0), gam.grad, tol=5e-5 * max(1, n ** 0.5) if tol > TOL else 2e-5 * max(1, n ** 0.5), what="dgamma")
+        close(dbp.sum(0), bet.grad, tol=2e-5 * max(1, n ** 0.5), what="dbeta")
+    part = ops.wgrad(terms, n, d, groups, 1e-5, g_, b_, dS.to(D), True)
+    gW = part.sum(0).view(d + 1, d)
+    close(gW[1:], W.grad[1:], tol=max(tol, 2e-5) * max(1, n ** 0.5), what="dW")
+    close(gW[0] * t, W.grad[0], tol=2e-5 * max(1, n ** 0.5), what="dW time row")

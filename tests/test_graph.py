@@ -1,0 +1,69 @@
+"""Host logic of the graph normaliser (CPU tensors)."""
+import numpy as np
+import torch
+
+from graph_odenet_amd import graph as G
+
+
+def rand_coo(n, m, nnz, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randint(0, n, (nnz,), generator=g), torch.randint(0, m, (nnz,), generator=g),
+            torch.rand(nnz, generator=g))
+
+
+def test_coo_duplicates_are_summed_and_dense_matches():
+    r, c, v = rand_coo(50, 40, 600, 0)
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (50, 40))
+    g = G.as_graph(adj)
+    assert torch.allclose(g.to_dense(), adj.to_dense(), atol=1e-6)
+    assert g.nnz == int((adj.to_dense() != 0).sum())
+    assert G.as_graph(adj) is g            # cached per tensor object
+    gd = G.as_graph(adj.to_dense())
+    assert torch.allclose(gd.to_dense(), adj.to_dense(), atol=1e-6)
+
+
+def test_items_partition_every_nonzero_once():
+    # power-law-ish degrees with some empty rows and rows far longer than the split length
+    n = 400
+    deg = np.r_[np.zeros(20, int), np.random.RandomState(0).zipf(1.5, n - 20).clip(1, 3000)]
+    rows = torch.from_numpy(np.repeat(np.arange(n), deg))
+    cols = torch.from_numpy(np.random.RandomState(1).randint(0, 1 << 30, rows.numel())) % 100000
+    g = G.from_coo(rows, cols, None, n, 100000, split=64, coalesce=False)
+    it = g.items.long()
+    assert (it[:, 2] - it[:, 1]).max() <= 64
+    lens = it[:, 2] - it[:, 1]
+    assert torch.all(lens[:-1] >= lens[1:])                       # longest first
+    cover = torch.zeros(g.nnz, dtype=torch.int64)
+    for row, b, e, slot in it.tolist():
+        cover[b:e] += 1
+        assert g.rowptr[row] <= b and e <= g.rowptr[row + 1]
+    assert torch.all(cover == 1)
+    assert g.n_items >= n                                          # empty rows still get a record
+    # split rows: slots are consecutive per row and listed in long_rows
+    lr = g.long_rows.long()
+    slots = it[it[:, 3] >= 0]
+    assert slots.shape[0] == g.n_slots == int((lr[:, 2] - lr[:, 1]).sum())
+    for row, s0, s1, _ in lr.tolist():
+        mine = slots[slots[:, 0] == row]
+        assert sorted(mine[:, 3].tolist()) == list(range(s0, s1))
+
+
+def test_transpose_roundtrip():
+    r, c, v = rand_coo(30, 30, 200, 3)
+    g = G.from_coo(r, c, v, 30, 30)
+    assert torch.allclose(g.transpose().to_dense(), g.to_dense().t())
+    assert g.transpose().transpose() is g
+
+
+def test_incidence_from_index():
+    idx = torch.tensor([2, 0, 2, 1])
+    g = G.incidence_from_index(idx, 4)
+    d = g.to_dense()
+    assert d.shape == (4, 4) and d.sum() == 4 and d[2, 0] == 1 and d[2, 2] == 1 and d[3].sum() == 0
+
+
+def test_algorithmic_bytes_formula():
+    r, c, v = rand_coo(10, 10, 30, 5)
+    g = G.from_coo(r, c, v, 10, 10)
+    d = 128
+    assert g.algorithmic_bytes(d) == g.nnz * (4 + 4 + 4 * d) + 11 * 4 + 10 * d * 4

@@ -1,0 +1,159 @@
+"""Pins the oracle (oracle/layers_ref.py) to the golden vectors captured from the reference's
+own classes (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import layers_ref as R
+
+TOL = 1e-6
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, tol=TOL):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), err
+
+
+def test_gcn_layer(golden):
+    g = golden("gcn_layer.npz")
+    n = int(g["n"])
+    adj = R.coo_adj(g["rows"], g["cols"], g["vals"], n, n)
+    x = T(g["x"]).requires_grad_(True)
+    w = T(g["weight"]).requires_grad_(True)
+    b = T(g["bias"]).requires_grad_(True)
+    out = R.graph_convolution(x, adj, w, b)
+    close(out, g["out"])
+    out.backward(T(g["gout"]))
+    close(x.grad, g["gx"]); close(w.grad, g["gw"]); close(b.grad, g["gb"])
+
+
+@pytest.mark.parametrize("d", [16, 64, 128])
+def test_gcn_odefunc(golden, d):
+    g = golden("gcn_odefunc_%d.npz" % d)
+    n = int(g["n"])
+    adj = R.coo_adj(g["rows"], g["cols"], g["vals"], n, n)
+    x = T(g["x"]).requires_grad_(True)
+    ps = [T(g[k]).requires_grad_(True) for k in ("gn_w", "gn_b", "W", "b")]
+    out = R.odefunc(T(g["t"]), x, adj, *ps)
+    close(out, g["out"])
+    out.backward(T(g["gout"]))
+    close(x.grad, g["gx"], 1e-5)
+    for p, k in zip(ps, ("g_gn_w", "g_gn_b", "gW", "gb")):
+        close(p.grad, g[k], 1e-5)
+
+
+def test_gcn_odefunc2(golden):
+    g = golden("gcn_odefunc2.npz")
+    n = int(g["n"])
+    adj = R.coo_adj(g["rows"], g["cols"], g["vals"], n, n)
+    x = T(g["x"]).requires_grad_(True)
+    p = {k.replace("__", "."): T(v).requires_grad_(True) for k, v in g.items()
+         if k.startswith(("norm", "gc"))}
+    out = R.odefunc2(T(g["t"]), x, adj, p)
+    close(out, g["out"])
+    out.backward(T(g["gout"]))
+    close(x.grad, g["gx"], 1e-5)
+    for k, v in p.items():
+        close(v.grad, g["g__" + k.replace(".", "__")], 1e-5)
+
+
+def test_gcn3_cora_logits(golden):
+    gr = golden("cora_graph.npz")
+    g = golden("gcn3_cora.npz")
+    n = int(gr["n"])
+    adj = R.coo_adj(gr["rows"].astype(np.int64), gr["cols"].astype(np.int64), gr["vals"], n, n)
+    feats = torch.zeros(n, int(gr["n_feat"]))
+    feats[T(gr["feat_rows"].astype(np.int64)), T(gr["feat_cols"].astype(np.int64))] = T(gr["feat_vals"])
+    for name, residual in (("GCN3", False), ("RGCN3", True)):
+        w = {k: T(g["%s__%s" % (name, k)]) for k in
+             ("gc1__weight", "gc1__bias", "gc2__weight", "gc2__bias", "gc3__weight", "gc3__bias")}
+        x = torch.relu(R.graph_convolution(feats, adj, w["gc1__weight"], w["gc1__bias"]))
+        r = x
+        x = torch.relu(R.graph_convolution(x, adj, w["gc2__weight"], w["gc2__bias"]))
+        if residual:
+            x = x + r
+        x = R.graph_convolution(x, adj, w["gc3__weight"], w["gc3__bias"])
+        close(torch.log_softmax(x, 1), g[name + "__out"], 1e-5)
+
+
+def test_cora_normalisation(golden):
+    """Row sums of the reference's A_hat = D^-1 (A + I) are 1 (GCN/utils.py:186,205-212)."""
+    gr = golden("cora_graph.npz")
+    n = int(gr["n"])
+    assert n == 2708 and gr["rows"].shape[0] == 13264
+    rs = np.zeros(n, np.float64)
+    np.add.at(rs, gr["rows"], gr["vals"])
+    assert np.abs(rs - 1).max() < 1e-6
+
+
+def _gat_args(g):
+    n = int(g["n"])
+    src, tgt = T(g["src"]).long(), T(g["tgt"]).long()
+    e = src.numel()
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(e)]), torch.ones(e), (n, e))
+    return n, src, tgt, Mtgt
+
+
+def test_gat_layer(golden):
+    g = golden("gat_layer.npz")
+    n, src, tgt, Mtgt = _gat_args(g)
+    x = T(g["x"]).requires_grad_(True)
+    ps = [T(g[k]).requires_grad_(True) for k in ("f_w", "f_b", "w_w", "w_b")]
+    out = R.gat_layer(x, src, tgt, Mtgt, *ps)
+    close(out, g["out"])
+    out.backward(T(g["gout"]))
+    close(x.grad, g["gx"], 1e-5)
+    for p, k in zip(ps, ("g_f_w", "g_f_b", "g_w_w", "g_w_b")):
+        close(p.grad, g[k], 1e-5)
+
+
+def test_gat_odefunc(golden):
+    g = golden("gat_odefunc.npz")
+    n, src, tgt, Mtgt = _gat_args(g)
+    x = T(g["x"]).requires_grad_(True)
+    ps = [T(g[k]).requires_grad_(True) for k in ("gn_w", "gn_b", "f_w", "f_b", "w_w", "w_b")]
+    out = R.gat_odefunc(T(g["t"]), x, src, tgt, Mtgt, *ps)
+    close(out, g["out"])
+    out.backward(T(g["gout"]))
+    close(x.grad, g["gx"], 1e-5)
+
+
+def test_qc_layers(golden):
+    g = golden("qc_layers.npz")
+    n = int(g["n"])
+    Esrc, etgt = T(g["Esrc"]).long(), T(g["etgt"]).long()
+    e = Esrc.numel()
+    Etgt = torch.zeros(n, e)
+    Etgt[etgt, torch.arange(e)] = 1.0
+    h = g["x"].shape[1]
+    for TT in (1, 3):
+        x = T(g["x"]).requires_grad_(True)
+        ed = T(g["edge_data"]).requires_grad_(True)
+        gru = torch.nn.GRUCell(2 * h, h)
+        gru.load_state_dict({k: T(g["T%d__gru__%s" % (TT, k)]) for k in gru.state_dict()})
+        out = R.mpnn_enn_edge(x, Esrc, Etgt, ed, gru, TT)
+        close(out, g["T%d__out" % TT], 1e-5)
+        out.backward(T(g["T%d__gout" % TT]))
+        close(x.grad, g["T%d__gx" % TT], 1e-5)
+        close(ed.grad, g["T%d__gedge" % TT], 1e-5)
+    x = T(g["x"]).requires_grad_(True)
+    ed = T(g["edge_data"]).requires_grad_(True)
+    w = T(g["egc__weight"]).requires_grad_(True)
+    b = T(g["egc__bias"]).requires_grad_(True)
+    out = R.edge_graph_convolution(x, Esrc, Etgt, ed, w, b)
+    close(out, g["egc__out"], 1e-5)
+    out.backward(T(g["egc__gout"]))
+    close(x.grad, g["egc__gx"], 1e-5); close(ed.grad, g["egc__gedge"], 1e-5)
+    close(w.grad, g["egc__gw"], 1e-5); close(b.grad, g["egc__gb"], 1e-5)
+
+
+def test_scatter_add_kat(golden):
+    """QC/torch_scatter.py:207-218 docstring example: a segment-sum known answer."""
+    g = golden("scatter_kat.npz")
+    out = torch.zeros(2, 6).scatter_add_(1, T(g["index"]), T(g["src"]))
+    assert torch.equal(out, T(g["out"]))
