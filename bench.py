@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — full-graph ODE-GCN forward+backward steps/sec at 64 RK4 evals (BASELINE.json metric).
+
+Workload (config C5 of SURVEY.md §8(d), the one the metric is quoted on; fits one GPU):
+  synthetic R-MAT graph, 2^20 nodes / 10 M directed edges (+ self loops, duplicates removed),
+  A_hat = D^-1 (A + I) fp32, features ~ N(0,1) 128-d, hidden 128, 16 classes, dropout 0.5,
+  ODEGCN3 shape (GCN/models.py:204-218): gc1 -> relu -> dropout -> ODEBlock(rk4 3/8 rule,
+  16 steps x 4 stages = 64 f-evals on [0,1]) -> gc3 -> log_softmax -> NLL on 10 % of the nodes,
+  adjoint backward (64 recomputed f-evals + 64 VJPs), Adam(lr .01, wd 5e-4) step
+  (GCN/train_res.py:63-79,126-127).  One "step" = that whole pass over one graph.
+
+Multi-GPU (--gpus N, launched with torch.distributed.run): every rank owns an independent
+R-MAT graph (seed = rank), i.e. a batch of N graphs sharded one per GPU; the only exchange step is
+one flattened RCCL all-reduce of the gradients per step.  scaling = "weak";
+value = N*K / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (SpMM main
+kernel, HIP events recorded around every launch of the timed region by libgraphode's profiler
+hook) and `cpu_baseline` (the oracle timed on the host cores, bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=20, help="log2(nodes) of the R-MAT graph")
+    ap.add_argument("--edges", type=int, default=10_000_000)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--nfeat", type=int, default=128)
+    ap.add_argument("--nclass", type=int, default=16)
+    ap.add_argument("--ode-steps", type=int, default=16, help="rk4 steps on [0,1] (4 evals each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-evals", type=int, default=2, help="f-evals in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, graph_cpu, sd, x_cpu):
+    """Oracle (kind 'port') on the host cores: a bounded sample of the same workload, scaled."""
+    from oracle import layers_ref as R
+    n = graph_cpu["n"]
+    adj = torch.sparse_coo_tensor(torch.stack([graph_cpu["r"], graph_cpu["c"]]), graph_cpu["v"], (n, n))
+    adj = adj.coalesce()
+    p = [sd["gc2.odefunc.norm1.weight"], sd["gc2.odefunc.norm1.bias"], sd["gc2.odefunc.gc1.weight"],
+         sd["gc2.odefunc.gc1.bias"]]
+    with torch.no_grad():
+        h = torch.relu(R.graph_convolution(x_cpu, adj, sd["gc1.weight"], sd["gc1.bias"]))
+        R.odefunc(torch.tensor(0.1), h, adj, *p)                      # warm-up
+        t0 = time.perf_counter()
+        for i in range(args.cpu_evals):
+            R.odefunc(torch.tensor(0.1 * i), h, adj, *p)
+        t_f = (time.perf_counter() - t0) / args.cpu_evals
+    # one f-eval with its VJP (what every adjoint stage costs)
+    pg = [q.clone().requires_grad_(True) for q in p]
+    hg = h.clone().requires_grad_(True)
+    t0 = time.perf_counter()
+    out = R.odefunc(torch.tensor(0.3), hg, adj, *pg)
+    out.backward(torch.ones_like(out))
+    t_fb = time.perf_counter() - t0
+    nfe = 4 * args.ode_steps
+    est = nfe * t_f + nfe * t_fb            # forward solve + adjoint solve (first/last layers ignored)
+    return {"value": 1.0 / est, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d ODEfunc f-evals (%.2f s each) + 1 f-eval with VJP (%.2f s) on the same 2^%d-node graph, "
+                      "scaled to %d fwd + %d adjoint evals per step" % (args.cpu_evals, t_f, t_fb, args.scale, nfe, nfe)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from graph_odenet_amd import _lib, models, ops
+    from graph_odenet_amd.parallel import GradBucket, broadcast_parameters
+    from graph_odenet_amd.synth import rmat_graph
+    lib = _lib.load()
+
+    # ---- inputs: resident in HBM before the timed region ------------------------------------
+    g = rmat_graph(args.scale, args.edges, seed=rank, device=dev)
+    g.transpose()                                   # CSR-by-source for the backward pass, built once
+    n = g.n_rows
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(n, args.nfeat, generator=gen, device=dev)
+    labels = torch.randint(0, args.nclass, (n,), generator=gen, device=dev)
+    idx_train = torch.randperm(n, generator=gen, device=dev)[: n // 10]
+
+    torch.manual_seed(42)
+    model = models.ODEGCN3(nfeat=args.nfeat, nhid=args.hidden, nclass=args.nclass, dropout=0.5,
+                           method="rk4", step_size=1.0 / args.ode_steps).to(dev)
+    broadcast_parameters(model, 0)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    bucket = GradBucket(model)
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    def step():
+        model.train()
+        opt.zero_grad(set_to_none=False)
+        out = model(x, g)
+        loss = torch.nn.functional.nll_loss(out[idx_train], labels[idx_train])
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.nfe = 0
+    cap = args.steps * (3 * 4 * args.ode_steps + 8) + 16
+    prof = lib.gode_prof_create(cap)
+    lib.gode_prof_enable(prof)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.gode_prof_enable(None)
+    nfe_per_step = model.nfe / max(args.steps, 1)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = tmax.item()
+
+    # ---- roofline of the dominant kernel (SpMM main kernel at d = hidden) ---------------------
+    ms = (ctypes.c_float * cap)()
+    dd = (ctypes.c_int64 * cap)()
+    rr = (ctypes.c_int64 * cap)()
+    cnt = lib.gode_prof_read(prof, ms, dd, rr, cap)
+    sel = [ms[i] for i in range(max(cnt, 0)) if dd[i] == args.hidden and rr[i] in (g.n_items, g.transpose().n_items)]
+    lib.gode_prof_destroy(prof)
+    roof = None
+    if sel:
+        avg_ms = sum(sel) / len(sel)
+        b_alg = g.algorithmic_bytes(args.hidden)
+        ach = b_alg / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "spmm_vec4_kernel<%d>" % (args.hidden // 4), "launches_timed": len(sel),
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": b_alg}
+
+    if rank == 0:
+        res = {
+            "metric": "full-graph ODE-GCN forward+backward steps/sec at 64 RK4 evals",
+            "value": round(world * args.steps / elapsed, 4), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RMAT scale-%d / %d edges (+self loops, dedup) row-normalised, d=%d, "
+                                   "ODEGCN3 rk4(3/8) %d steps = %d f-evals fwd, adjoint bwd, Adam; one graph per GPU"
+                                   % (args.scale, args.edges, args.hidden, args.ode_steps, 4 * args.ode_steps),
+                       "nodes": n, "nnz": g.nnz, "nfeat": args.nfeat, "hidden": args.hidden,
+                       "nclass": args.nclass, "nfe_per_step": nfe_per_step,
+                       "parallelism": "dp%d (one graph per rank, 1 gradient all-reduce/step)" % world},
+            "loss": round(float(loss), 5),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rp = g.rowptr.to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1]).cpu()
+            gc = {"n": n, "r": rows, "c": g.col.to(torch.int64).cpu(), "v": g.val.cpu()}
+            res["cpu_baseline"] = cpu_baseline(args, gc, sd_cpu, x.cpu())
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

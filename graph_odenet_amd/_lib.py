@@ -47,6 +47,12 @@ SIGNATURES = {
     "gode_reduce_parts_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
     "gode_colsum_scratch_bytes": (c_i64, [c_i64, c_i64]),
     "gode_colsum_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p, c_p]),
+    "gode_prof_create": (c_p, [c_i]),
+    "gode_prof_destroy": (None, [c_p]),
+    "gode_prof_enable": (None, [c_p]),
+    "gode_prof_reset": (None, [c_p]),
+    "gode_prof_count": (c_i, [c_p]),
+    "gode_prof_read": (c_i, [c_p, c_p, c_p, c_p, c_i]),
 }
 
 _lib = None

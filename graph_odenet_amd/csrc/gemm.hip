@@ -231,19 +231,32 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                     dgs[tt].x += dy.x * xh.x; dgs[tt].y += dy.y * xh.y; dgs[tt].z += dy.z * xh.z; dgs[tt].w += dy.w * xh.w;
                     dbs[tt].x += dy.x; dbs[tt].y += dy.y; dbs[tt].z += dy.z; dbs[tt].w += dy.w;
                 }
+                // ATen's CPU form (group_norm_kernel.cpp, GroupNormBackward): with ds = sum dy*gamma*x and
+                // db = sum dy*gamma over the group,  c2 = (db*mean - ds)*rstd^3/CG,  c3 = -c2*mean - db*rstd/CG,
+                // dx = rstd*gamma*dy + c2*x + c3.  Same algebra as rstd*(dh - mean(dh) - xh*mean(dh*xh));
+                // kept in this form so that the rounding behaves like the reference's on ill-conditioned
+                // groups (1 or 2 channels per group).
+                const float4 px = make_float4(dh.x * x.x, dh.y * x.y, dh.z * x.z, dh.w * x.w);
+                float4 ds, db;
                 if (CG == 1) {
-                    out = make_float4(0.f, 0.f, 0.f, 0.f);
+                    ds = px; db = dh;
                 } else if (CG == 2) {
-                    const float a0 = (dh.x + dh.y) * 0.5f, a1 = (dh.z + dh.w) * 0.5f;
-                    const float b0 = (dh.x * xh.x + dh.y * xh.y) * 0.5f, b1 = (dh.z * xh.z + dh.w * xh.w) * 0.5f;
-                    out = make_float4(rstd.x * (dh.x - a0 - xh.x * b0), rstd.y * (dh.y - a0 - xh.y * b0),
-                                      rstd.z * (dh.z - a1 - xh.z * b1), rstd.w * (dh.w - a1 - xh.w * b1));
+                    ds = make_float4(px.x + px.y, px.x + px.y, px.z + px.w, px.z + px.w);
+                    db = make_float4(dh.x + dh.y, dh.x + dh.y, dh.z + dh.w, dh.z + dh.w);
                 } else {
-                    const float a = group_mean4<(CG < 4 ? 4 : CG)>(dh);
-                    const float b = group_mean4<(CG < 4 ? 4 : CG)>(make_float4(dh.x * xh.x, dh.y * xh.y, dh.z * xh.z, dh.w * xh.w));
-                    out = make_float4(rstd.x * (dh.x - a - xh.x * b), rstd.y * (dh.y - a - xh.y * b),
-                                      rstd.z * (dh.z - a - xh.z * b), rstd.w * (dh.w - a - xh.w * b));
+                    const float a = group_mean4<(CG < 4 ? 4 : CG)>(px) * CG;
+                    const float b = group_mean4<(CG < 4 ? 4 : CG)>(dh) * CG;
+                    ds = make_float4(a, a, a, a); db = make_float4(b, b, b, b);
                 }
+                constexpr float sc = 1.0f / (CG > 0 ? CG : 1);
+                const float4 r3 = make_float4(rstd.x * rstd.x * rstd.x * sc, rstd.y * rstd.y * rstd.y * sc,
+                                              rstd.z * rstd.z * rstd.z * sc, rstd.w * rstd.w * rstd.w * sc);
+                const float4 c2 = make_float4((db.x * mean.x - ds.x) * r3.x, (db.y * mean.y - ds.y) * r3.y,
+                                              (db.z * mean.z - ds.z) * r3.z, (db.w * mean.w - ds.w) * r3.w);
+                const float4 c3 = make_float4(-c2.x * mean.x - db.x * rstd.x * sc, -c2.y * mean.y - db.y * rstd.y * sc,
+                                              -c2.z * mean.z - db.z * rstd.z * sc, -c2.w * mean.w - db.w * rstd.w * sc);
+                out = make_float4(rstd.x * gm.x * dy.x + c2.x * x.x + c3.x, rstd.y * gm.y * dy.y + c2.y * x.y + c3.y,
+                                  rstd.z * gm.z * dy.z + c2.z * x.z + c3.z, rstd.w * gm.w * dy.w + c2.w * x.w + c3.w);
             }
             if (valid)
                 *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) =
@@ -453,14 +466,13 @@ __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_ro
             const int cg = d_in / groups;
             for (int idx = threadIdx.x; idx < RB * groups; idx += 256) {
                 const int rr = idx / groups, gi = idx % groups;
-                const float m = stat[idx * 2], rs = stat[idx * 2 + 1];
-                float a = 0.f, b = 0.f;
+                float dsum = 0.f, bsum = 0.f;      // ds, db of ATen's GroupNorm backward
                 for (int c = 0; c < cg; ++c) {
                     const int cc = gi * cg + c;
                     const float dh = dy[rr * d_in + cc] * (gamma ? gamma[cc] : 1.f);
-                    a += dh; b += dh * (xs[rr * d_in + cc] - m) * rs;
+                    dsum += dh * xs[rr * d_in + cc]; bsum += dh;
                 }
-                red[idx * 2] = a / cg; red[idx * 2 + 1] = b / cg;
+                red[idx * 2] = dsum; red[idx * 2 + 1] = bsum;
             }
             __syncthreads();
             for (int idx = threadIdx.x; idx < RB * d_in; idx += 256) {
@@ -469,9 +481,11 @@ __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_ro
                 if (row >= n_rows) continue;
                 const int gi = c / cg;
                 const float m = stat[(rr * groups + gi) * 2], rs = stat[(rr * groups + gi) * 2 + 1];
-                const float xh = (xs[idx] - m) * rs;
-                const float dh = dy[idx] * (gamma ? gamma[c] : 1.f);
-                dx[(int64_t)row * d_in + c] = out_scale * rs * (dh - red[(rr * groups + gi) * 2] - xh * red[(rr * groups + gi) * 2 + 1]);
+                const float dsum = red[(rr * groups + gi) * 2], bsum = red[(rr * groups + gi) * 2 + 1];
+                const float sc = 1.0f / cg;
+                const float c2 = (bsum * m - dsum) * rs * rs * rs * sc;
+                const float c3 = -c2 * m - bsum * rs * sc;
+                dx[(int64_t)row * d_in + c] = out_scale * (rs * (gamma ? gamma[c] : 1.f) * dy[idx] + c2 * xs[idx] + c3);
             }
             if (dgamma_part) {
                 // per-block partial over the block's rows (accumulated across the grid-stride loop)

@@ -140,6 +140,19 @@ int gode_colsum_f32(float* out, const float* X, int64_t n_rows, int64_t d, float
                     int accumulate, float* scratch /* >= gode_colsum_scratch_bytes */, void* stream);
 int64_t gode_colsum_scratch_bytes(int64_t n_rows, int64_t d);
 
+/* ---- measurement aid (bench.py): HIP-event brackets around the SpMM main kernel ----------
+ * While a profiler is enabled on the calling thread, every gode_spmm_csr_f32 fast-path launch
+ * records a start/stop event pair on its stream (up to `capacity` launches).
+ * gode_prof_read waits for the recorded events and returns the number of launches read, with
+ * per-launch milliseconds, feature width d and record count. */
+void* gode_prof_create(int capacity);
+void  gode_prof_destroy(void* prof);
+void  gode_prof_enable(void* prof /* NULL = off */);
+void  gode_prof_reset(void* prof);
+int   gode_prof_count(void* prof);
+int   gode_prof_read(void* prof, float* ms /* host */, int64_t* d /* host, nullable */,
+                     int64_t* rows /* host, nullable */, int max_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,13 +158,17 @@ def test_gn_time_gemm_fwd_bwd_wgrad(d, groups, n):
     terms = [(1.0, y.to(D)), (h, k1.to(D))]
     g_, b_ = (gam.detach().to(D), bet.detach().to(D)) if groups else (None, None)
     got = ops.gn_time_gemm(terms, n, d, groups, 1e-5, g_, b_, W.detach().to(D), True, t)
-    # at one channel per group the normalised value is rounding noise amplified by 1/sqrt(eps)=316
-    tol = TOL if (groups == 0 or d // max(groups, 1) > 1) else 2e-4
+    # Conditioning: with ONE channel per group GroupNorm's output is beta plus
+    # rounding noise amplified by rstd = 1/sqrt(eps) = 316 and its x-gradient is exactly 0 in real
+    # arithmetic - both sides return noise of size ~316 * 2^-23 * |dy| there; with TWO channels per
+    # group rstd reaches 316 on rows whose two values nearly coincide.  Tolerances follow that.
+    cg = d // groups if groups else 0
+    tol = {0: TOL, 1: 2e-4, 2: 2e-5}.get(cg, TOL)
     close(got, S, tol=tol, what="gn_time_gemm")
     dx, dgp, dbp = ops.gn_time_gemm_bwd(terms, n, d, groups, 1e-5, g_, W.detach().to(D), True, dS.to(D))
-    close(dx, x.grad, tol=max(tol, 2e-5), what="dx")
+    close(dx, x.grad, tol={0: TOL, 1: 2e-3, 2: 1e-4}.get(cg, 2e-5), what="dx")
     if groups:
-        close(dgp.sum(0), gam.grad, tol=5e-5 * max(1, n ** 0.5) if tol > TOL else 2e-5 * max(1, n ** 0.5), what="dgamma")
+        close(dgp.sum(0), gam.grad, tol=(2e-3 if cg == 1 else 2e-5) * max(1, n ** 0.5), what="dgamma")
         close(dbp.sum(0), bet.grad, tol=2e-5 * max(1, n ** 0.5), what="dbeta")
     part = ops.wgrad(terms, n, d, groups, 1e-5, g_, b_, dS.to(D), True)
     gW = part.sum(0).view(d + 1, d)
