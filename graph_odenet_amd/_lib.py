@@ -47,6 +47,14 @@ SIGNATURES = {
     "gode_reduce_parts_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
     "gode_colsum_scratch_bytes": (c_i64, [c_i64, c_i64]),
     "gode_colsum_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p, c_p]),
+    "gode_edge_softmax_scratch_bytes": (c_i64, [c_i64]),
+    "gode_edge_softmax_logits_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "gode_edge_softmax_agg_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_f, c_i64,
+                                            c_p, c_p, c_p, c_p]),
+    "gode_edge_softmax_agg_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p,
+                                            c_i64, c_p, c_p, c_p]),
+    "gode_edge_matvec_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
+    "gode_edge_matvec_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_prof_create": (c_p, [c_i]),
     "gode_prof_destroy": (None, [c_p]),
     "gode_prof_enable": (None, [c_p]),

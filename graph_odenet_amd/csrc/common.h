@@ -38,18 +38,35 @@ static inline bool lincomb_aligned16(const gode_lincomb_t* h) {
     return true;
 }
 
-__device__ __forceinline__ float4 lc_load4(const LinComb& lc, int64_t idx) {
+// Straight-line combination of NT terms: all NT loads are issued before the first use, so their
+// latencies overlap (a loop over a run-time term count makes hipcc wait for each load in turn).
+template <int NT>
+__device__ __forceinline__ float4 lc_load4_n(const LinComb& lc, int64_t idx) {
+    float4 v[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) v[j] = *reinterpret_cast<const float4*>(lc.ptr[j] + idx);
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < GODE_MAX_TERMS; ++j) {
-        if (j < lc.n) {
-            const float4 v = *reinterpret_cast<const float4*>(lc.ptr[j] + idx);
-            const float c = lc.coef[j];
-            r.x = fmaf(c, v.x, r.x); r.y = fmaf(c, v.y, r.y);
-            r.z = fmaf(c, v.z, r.z); r.w = fmaf(c, v.w, r.w);
-        }
+    for (int j = 0; j < NT; ++j) {
+        const float c = lc.coef[j];
+        r.x = fmaf(c, v[j].x, r.x); r.y = fmaf(c, v[j].y, r.y);
+        r.z = fmaf(c, v[j].z, r.z); r.w = fmaf(c, v[j].w, r.w);
     }
     return r;
+}
+
+__device__ __forceinline__ float4 lc_load4(const LinComb& lc, int64_t idx) {
+    switch (lc.n) {          // wave-uniform
+        case 1: return lc_load4_n<1>(lc, idx);
+        case 2: return lc_load4_n<2>(lc, idx);
+        case 3: return lc_load4_n<3>(lc, idx);
+        case 4: return lc_load4_n<4>(lc, idx);
+        case 5: return lc_load4_n<5>(lc, idx);
+        case 6: return lc_load4_n<6>(lc, idx);
+        case 7: return lc_load4_n<7>(lc, idx);
+        case 8: return lc_load4_n<8>(lc, idx);
+        default: return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 __device__ __forceinline__ float lc_load1(const LinComb& lc, int64_t idx) {

@@ -87,6 +87,53 @@ __device__ __forceinline__ float group_mean4(float4 v) {   // mean over the lane
 }
 
 
+// Loads the lane's NJ float4 of one 16-row tile, combining the stage terms.  The switch on the
+// (wave-uniform) term count sits OUTSIDE the j loop so that all NT*NJ loads are in flight together.
+template <int NJ, int NT>
+__device__ __forceinline__ void load_tile_n(const LinComb& lc, int64_t base, float4 (&xv)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += 2) {      // two terms (2*NJ loads) in flight at a time bounds the registers
+        float4 v[2][NJ];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+            if (t0 + tt < NT) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) v[tt][j] = ld4(lc.ptr[t0 + tt] + base + 16 * j);
+            }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+            if (t0 + tt < NT) {
+                const float c = lc.coef[t0 + tt];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    xv[j].x = fmaf(c, v[tt][j].x, xv[j].x); xv[j].y = fmaf(c, v[tt][j].y, xv[j].y);
+                    xv[j].z = fmaf(c, v[tt][j].z, xv[j].z); xv[j].w = fmaf(c, v[tt][j].w, xv[j].w);
+                }
+            }
+    }
+}
+
+template <int NJ>
+__device__ __forceinline__ void load_tile(const LinComb& lc, int64_t base, bool valid, float4 (&xv)[NJ]) {
+    if (!valid) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    switch (lc.n) {
+        case 1: load_tile_n<NJ, 1>(lc, base, xv); break;
+        case 2: load_tile_n<NJ, 2>(lc, base, xv); break;
+        case 3: load_tile_n<NJ, 3>(lc, base, xv); break;
+        case 4: load_tile_n<NJ, 4>(lc, base, xv); break;
+        case 5: load_tile_n<NJ, 5>(lc, base, xv); break;
+        case 6: load_tile_n<NJ, 6>(lc, base, xv); break;
+        case 7: load_tile_n<NJ, 7>(lc, base, xv); break;
+        default: load_tile_n<NJ, 8>(lc, base, xv); break;
+    }
+}
+
 // One 16-row panel: acc[tt] += sum_k Wlds[k][16tt + r] * xb[k]   (k-slot g of step (j,c) carries k = 16j+4g+c).
 // The A operands of step s+1 are read from LDS before the MFMAs of step s are issued, and a
 // scheduling barrier per step keeps hipcc from hoisting all 4*NJ*NJ LDS reads to the top (spills).
@@ -142,11 +189,7 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_
         const int row = tile * 16 + r;
         const bool valid = row < n_rows;
         float4 xv[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) xv[j] = lc_load4(xin, (int64_t)row * D + 16 * j + 4 * g);
-        }
+        load_tile<NJ>(xin, (int64_t)row * D + 4 * g, valid, xv);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) xv[j] = gn_forward<CG>(xv[j], eps, gamma, beta, 16 * j + 4 * g);
 
@@ -207,6 +250,8 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
             gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (valid) gv[j] = ld4(dS + (int64_t)row * D + 16 * j + 4 * g);
         }
+        float4 xt[NJ];      // x tile, fetched before the MFMA phase so that its latency hides under it
+        if (CG != 0) load_tile<NJ>(xin, (int64_t)row * D + 4 * g, valid, xt);
         f32x4 acc[NJ];
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -218,8 +263,7 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
             float4 dy = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
             float4 out = dy;
             if (CG != 0) {
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) x = lc_load4(xin, (int64_t)row * D + c0);
+                const float4 x = xt[tt];
                 float4 mean, rstd;
                 gn_stats<CG>(x, eps, mean, rstd);
                 const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y,
@@ -264,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
         }
     }
     if (CG != 0 && dgamma_part) {
-        const int part = blockIdx.x * 4 + wave;
+        __syncthreads();                       // every wave is done with Wt: reuse LDS for the reduction
+        float* red = smem;                     // [2][4 waves][D]
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) {
             float4 a = dgs[tt], b = dbs[tt];
@@ -274,9 +319,14 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                 b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
             }
             if (r == 0) {
-                *reinterpret_cast<float4*>(dgamma_part + (int64_t)part * D + 16 * tt + 4 * g) = a;
-                *reinterpret_cast<float4*>(dbeta_part + (int64_t)part * D + 16 * tt + 4 * g) = b;
+                *reinterpret_cast<float4*>(red + wave * D + 16 * tt + 4 * g) = a;
+                *reinterpret_cast<float4*>(red + (4 + wave) * D + 16 * tt + 4 * g) = b;
             }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            dgamma_part[(int64_t)blockIdx.x * D + c] = (red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c]);
+            dbeta_part[(int64_t)blockIdx.x * D + c] = (red[4 * D + c] + red[5 * D + c]) + (red[6 * D + c] + red[7 * D + c]);
         }
     }
 }
@@ -314,23 +364,47 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(LinComb xin, int n_rows, 
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int n_tiles = (n_rows + R - 1) / R;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads();
-        for (int rr = trow; rr < R; rr += RPP) {
+    constexpr int NP = (R + RPP - 1) / RPP;    // staging passes per tile (4 at d = 128)
+    float4 xr[NP], gr[NP];
+    // register prefetch of the next tile: its global loads are in flight while the MFMAs of the
+    // current tile run out of LDS.
+    auto prefetch = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int rr = trow + p * RPP;
             const int row = tile * R + rr;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), gg = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < n_rows) {
-                x = lc_load4(xin, (int64_t)row * D + tcol);
-                gg = ld4(dS + (int64_t)row * D + tcol);
+            xr[p] = make_float4(0.f, 0.f, 0.f, 0.f); gr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < R && row < n_rows) gr[p] = ld4(dS + (int64_t)row * D + tcol);
+        }
+        switch (xin.n) {
+#define GODE_PF(NTV) case NTV: _Pragma("unroll") for (int p = 0; p < NP; ++p) { \
+                const int rr = trow + p * RPP; const int row = tile * R + rr; \
+                if (rr < R && row < n_rows) xr[p] = lc_load4_n<NTV>(xin, (int64_t)row * D + tcol); } break;
+            GODE_PF(1) GODE_PF(2) GODE_PF(3) GODE_PF(4) GODE_PF(5) GODE_PF(6) GODE_PF(7)
+            default: _Pragma("unroll") for (int p = 0; p < NP; ++p) {
+                const int rr = trow + p * RPP; const int row = tile * R + rr;
+                if (rr < R && row < n_rows) xr[p] = lc_load4_n<8>(xin, (int64_t)row * D + tcol); } break;
+#undef GODE_PF
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < n_tiles) prefetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();                       // previous tile's MFMAs are done reading LDS
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int rr = trow + p * RPP;
+            if (rr < R) {
+                const int row = tile * R + rr;
+                float4 x = gn_forward<CG>(xr[p], eps, gamma, beta, tcol);     // CG in {0,1,2,4}: group inside the float4
+                if (row >= n_rows) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(Xs + rr * LD + tcol) = x;
+                *reinterpret_cast<float4*>(Gs + rr * LD + tcol) = gr[p];
+                csum.x += gr[p].x; csum.y += gr[p].y; csum.z += gr[p].z; csum.w += gr[p].w;
             }
-            // CG in {0,1,2,4}: group inside the float4
-            x = gn_forward<CG>(x, eps, gamma, beta, tcol);
-            if (row >= n_rows) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(Xs + rr * LD + tcol) = x;
-            *reinterpret_cast<float4*>(Gs + rr * LD + tcol) = gg;
-            csum.x += gg.x; csum.y += gg.y; csum.z += gg.z; csum.w += gg.w;
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < n_tiles) prefetch(tile + gridDim.x);
         if (wave_active) {
 #pragma unroll
             for (int kb = 0; kb < R; kb += 4) {
@@ -630,8 +704,8 @@ extern "C" int gode_gn_time_gemm_f32(const gode_lincomb_t* xin, int64_t n_rows, 
 }
 
 extern "C" int64_t gode_gemm_bwd_parts(int64_t n_rows) {
-    // upper bound valid for both the MFMA path (blocks*4 wave partials) and the generic path
-    int64_t a = fwd_blocks(n_rows) * 4;
+    // upper bound valid for both the MFMA path (one partial per block) and the generic path
+    int64_t a = fwd_blocks(n_rows);
     int64_t b = (n_rows + RB - 1) / RB; if (b > 2048) b = 2048; if (b < 1) b = 1;
     return a > b ? a : b;
 }

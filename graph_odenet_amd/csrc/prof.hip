@@ -1,7 +1,7 @@
 // prof.hip — measurement aid: HIP-event brackets around the dominant kernel (the SpMM main
 // kernel), recorded on the stream the kernel is launched on.  bench.py enables it over its timed
 // region to obtain the live average launch duration that the roofline figure is computed from.
-// Disabled (one thread-local pointer test per launch) unless gode_prof_enable() was called.
+// Disabled (one pointer test per launch) unless gode_prof_enable() was called.
 #include "common.h"
 #include "prof.h"
 #include <vector>
@@ -13,7 +13,8 @@ struct GodeProf {
     std::vector<int64_t> d, rows;
 };
 
-static thread_local GodeProf* g_prof = nullptr;
+// process-global on purpose: torch's autograd engine runs backward on its own thread
+static GodeProf* volatile g_prof = nullptr;
 
 extern "C" void* gode_prof_create(int capacity) {
     if (capacity <= 0) return nullptr;

@@ -65,14 +65,70 @@ __global__ __launch_bounds__(256) void final_sum_kernel(double* out, const doubl
     if (threadIdx.x == 0) out[0] = sm[0];
 }
 
+// out[j] (+)= scale * sum_p part[p][j].  Block = 32 outputs x 8 part-groups; group q adds parts
+// q, q+8, ... (coalesced 128-B reads), the 8 group sums are added in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_parts_kernel(float* out, const float* part, int64_t n_part,
                                                            int64_t len, float scale, int accumulate) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= len) return;
+    __shared__ float sm[8][33];
+    const int jj = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int64_t j = (int64_t)blockIdx.x * 32 + jj;
     float s = 0.f;
-    for (int64_t p = 0; p < n_part; ++p) s += part[p * len + j];
-    s *= scale;
-    out[j] = accumulate ? out[j] + s : s;
+    if (j < len) {
+        int64_t p = q;
+        for (; p + 24 < n_part; p += 32) {
+            const float a0 = part[p * len + j], a1 = part[(p + 8) * len + j];
+            const float a2 = part[(p + 16) * len + j], a3 = part[(p + 24) * len + j];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; p < n_part; p += 8) s += part[p * len + j];
+    }
+    sm[q][jj] = s;
+    __syncthreads();
+    if (q == 0 && j < len) {
+        float t = sm[0][jj];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sm[k][jj];
+        t *= scale;
+        out[j] = accumulate ? out[j] + t : t;
+    }
+}
+
+// column sums with 16-B loads: thread owns 4 columns, TPR = d/4 threads cover a row.
+__global__ __launch_bounds__(256) void colsum4_kernel(float* part, const float* X, int64_t n_rows, int d, int64_t rpb) {
+    const int tpr = d >> 2;
+    const int rows_par = 256 / tpr;
+    const int c4 = (threadIdx.x % tpr) * 4, ph = threadIdx.x / tpr;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = r0 + rpb < n_rows ? r0 + rpb : n_rows;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ph < rows_par) {
+        int64_t r = r0 + ph;
+        for (; r + 3 * rows_par < r1; r += 4 * rows_par) {
+            const float4 a = *reinterpret_cast<const float4*>(X + r * d + c4);
+            const float4 b = *reinterpret_cast<const float4*>(X + (r + rows_par) * d + c4);
+            const float4 c = *reinterpret_cast<const float4*>(X + (r + 2 * rows_par) * d + c4);
+            const float4 e = *reinterpret_cast<const float4*>(X + (r + 3 * rows_par) * d + c4);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+            s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
+        }
+        for (; r < r1; r += rows_par) {
+            const float4 a = *reinterpret_cast<const float4*>(X + r * d + c4);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
+    __shared__ float4 sm[256];
+    sm[threadIdx.x] = (ph < rows_par) ? s : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (ph == 0) {
+        float4 t = sm[threadIdx.x];
+        for (int p = 1; p < rows_par; ++p) {
+            const float4 a = sm[p * tpr + threadIdx.x];
+            t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+        }
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.x * d + c4) = t;
+    }
 }
 
 // column sums, stage 1: block b sums rows [b*rpb, (b+1)*rpb) -> part[b][d]
@@ -179,7 +235,7 @@ extern "C" int gode_reduce_parts_f32(float* out, const float* part, int64_t n_pa
     if (n_part < 0 || len < 0) return GODE_E_SHAPE;
     if (len == 0) return 0;
     if (!out || (n_part > 0 && !part)) return GODE_E_NULLPTR;
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
                        out, part, n_part, len, scale, accumulate);
     GODE_LAUNCH_CHECK();
     return 0;
@@ -197,7 +253,10 @@ extern "C" int gode_colsum_f32(float* out, const float* X, int64_t n_rows, int64
     hipStream_t s = (hipStream_t)stream;
     const int64_t nb = colsum_blocks(n_rows);
     const int64_t rpb = (n_rows + nb - 1) / nb;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nb), dim3(256), 0, s, scratch, X, n_rows, (int)d, rpb > 0 ? rpb : 1);
+    if (d % 4 == 0 && d <= 1024 && !(((uintptr_t)X) & 15) && !(((uintptr_t)scratch) & 15))
+        hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)nb), dim3(256), 0, s, scratch, X, n_rows, (int)d, rpb > 0 ? rpb : 1);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nb), dim3(256), 0, s, scratch, X, n_rows, (int)d, rpb > 0 ? rpb : 1);
     GODE_LAUNCH_CHECK();
     return gode_reduce_parts_f32(out, scratch, nb, d, scale, accumulate, stream);
 }

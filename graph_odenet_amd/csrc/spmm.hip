@@ -109,7 +109,18 @@ __global__ __launch_bounds__(256) void spmm_finish_vec4_kernel(
     if (gid >= n_long) return;
     const int4 lr = long_rows[gid];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = lr.y; s < lr.z; ++s) {
+    int s = lr.y;
+    for (; s + 3 < lr.z; s += 4) {          // 4 independent loads in flight, added in slot order
+        const float4 p0 = *reinterpret_cast<const float4*>(partial + (int64_t)s * (LPR * 4) + lane * 4);
+        const float4 p1 = *reinterpret_cast<const float4*>(partial + (int64_t)(s + 1) * (LPR * 4) + lane * 4);
+        const float4 p2 = *reinterpret_cast<const float4*>(partial + (int64_t)(s + 2) * (LPR * 4) + lane * 4);
+        const float4 p3 = *reinterpret_cast<const float4*>(partial + (int64_t)(s + 3) * (LPR * 4) + lane * 4);
+        acc.x += p0.x; acc.y += p0.y; acc.z += p0.z; acc.w += p0.w;
+        acc.x += p1.x; acc.y += p1.y; acc.z += p1.z; acc.w += p1.w;
+        acc.x += p2.x; acc.y += p2.y; acc.z += p2.z; acc.w += p2.w;
+        acc.x += p3.x; acc.y += p3.y; acc.z += p3.z; acc.w += p3.w;
+    }
+    for (; s < lr.z; ++s) {
         const float4 p = *reinterpret_cast<const float4*>(partial + (int64_t)s * (LPR * 4) + lane * 4);
         acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
     }

@@ -1,0 +1,152 @@
+"""GAT-family layers with the reference's names and API (GAT/layers.py:11-127):
+
+    GraphConvolution(in_features, out_features, bias=True, act=F.relu, eps=1e-6)
+        .f = nn.Linear(2*in, out)   .w = nn.Linear(2*in, 1)      (the `bias` argument is accepted and
+        .forward(x, src, tgt, Mtgt)                               ignored, exactly as in the reference)
+    FixedGraphConvolution(...).set_adj(src, tgt, Mtgt); .forward(x)
+
+The reference gathers h = [x[src] | x[tgt]] (E x 2i) and applies f and w per edge.  Here f and w are
+applied per NODE (one dense GEMM on N rows, `x @ [Wf_src | Wf_tgt | ww_src | ww_tgt]`), and the
+per-edge work (logit, global-max shift, exp, per-target normalised sum of relu messages) runs in the
+HIP kernels of csrc/edge.hip; the scatter back to the nodes in the backward pass is two SpMM
+launches over the source / target incidence matrices.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.module import Module
+
+from . import ops
+from .graph import as_graph, incidence_from_index
+
+_edge_cache = {}
+
+
+class EdgeGraph:
+    """(src, tgt, Mtgt) normalised once: int32 indices, CSR of Mtgt, incidence CSR by src and by tgt."""
+
+    def __init__(self, src, tgt, Mtgt):
+        self.n = Mtgt.shape[0] if torch.is_tensor(Mtgt) else Mtgt.n_rows
+        self.E = src.numel()
+        self.src = src.to(torch.int32).contiguous()
+        self.tgt = tgt.to(torch.int32).contiguous()
+        self.Mt = as_graph(Mtgt)
+        if self.Mt.n_cols != self.E:
+            raise ValueError("Mtgt must be N x E with E = len(src)")
+        cols = self.Mt.col.to(torch.int64)
+        if cols.numel() and torch.bincount(cols, minlength=self.E).max().item() > 1:
+            raise NotImplementedError("Mtgt with more than one entry per edge column is not supported")
+        self.Ms_inc = incidence_from_index(self.src, self.n)     # N x E, row = src[e]
+        self.Mt_inc = incidence_from_index(self.tgt, self.n)     # N x E, row = tgt[e]
+
+
+def edge_graph(src, tgt, Mtgt):
+    key = (id(src), id(tgt), id(Mtgt))
+    hit = _edge_cache.get(key)
+    if hit is not None and hit[0] is src and hit[1] is tgt and hit[2] is Mtgt:
+        return hit[3]
+    g = EdgeGraph(src, tgt, Mtgt)
+    if len(_edge_cache) > 64:
+        _edge_cache.clear()
+    _edge_cache[key] = (src, tgt, Mtgt, g)     # strong refs: ids stay valid while cached
+    return g
+
+
+class _EdgeAttentionFn(torch.autograd.Function):
+    """out = per-target softmax-weighted sum of relu messages, from node-level projections P (N x (2o+2))."""
+
+    @staticmethod
+    def forward(ctx, eg, P, bf, bw, o, eps):
+        P = P.contiguous()
+        a, amax = ops.edge_softmax_logits(P, o, bw, eg.src, eg.tgt)
+        out, w, den = ops.edge_softmax_agg_fwd(eg.Mt, eg.src, eg.tgt, P, o, bf, a, amax, eps)
+        ctx.eg, ctx.o = eg, o
+        ctx.save_for_backward(P, bf, a, amax, w, den, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        P, bf, a, amax, w, den, out = ctx.saved_tensors
+        eg, o = ctx.eg, ctx.o
+        dz, da = ops.edge_softmax_agg_bwd(eg.Mt, eg.src, eg.tgt, P, o, bf, w, den, out, dout.contiguous())
+        # path through the global max (GAT/layers.py:47): d amax = -sum_e da_e, routed to the arg-max edge
+        if eg.E > 0:
+            idx = torch.argmax(a)
+            da[idx] -= da.sum()
+        dP = torch.zeros_like(P)
+        dP[:, :o] = ops.spmm(eg.Ms_inc, dz)                     # sum over edges leaving each node
+        dP[:, o:2 * o] = ops.spmm(eg.Mt_inc, dz)                # sum over edges entering each node
+        da2 = da.view(-1, 1).contiguous()
+        dP[:, 2 * o] = ops.spmm(eg.Ms_inc, da2).view(-1)
+        dP[:, 2 * o + 1] = ops.spmm(eg.Mt_inc, da2).view(-1)
+        dbf = torch.empty_like(bf)
+        ops.colsum_(dbf, dz)
+        dbw = da.sum().reshape(1)
+        return None, dP, dbf, dbw, None, None
+
+
+def _gat_forward(layer, x, src, tgt, Mtgt):
+    if layer.act is not F.relu:
+        raise NotImplementedError("graph_odenet_amd GAT layer: only act=F.relu (the reference default) is fused")
+    eg = edge_graph(src, tgt, Mtgt)
+    i, o = layer.in_features, layer.out_features
+    Wf, ww = layer.f.weight, layer.w.weight                      # (o, 2i), (1, 2i)
+    Wcat = torch.cat([Wf[:, :i].t(), Wf[:, i:].t(), ww[:, :i].t(), ww[:, i:].t()], 1)   # i x (2o+2)
+    P = torch.mm(x, Wcat)                                        # node-level projections (dense GEMM)
+    return _EdgeAttentionFn.apply(eg, P, layer.f.bias, layer.w.bias, o, layer.eps)
+
+
+class GraphConvolution(Module):
+    """GAT layer (reference: GAT/layers.py:11-63)."""
+
+    def __init__(self, in_features, out_features, bias=True, act=F.relu, eps=1e-6):
+        super(GraphConvolution, self).__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.f = nn.Linear(2 * in_features, out_features)
+        self.w = nn.Linear(2 * in_features, 1)
+        self.eps = eps
+        self.act = act
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.f.weight)
+        nn.init.xavier_uniform_(self.w.weight)
+
+    def forward(self, x, src, tgt, Mtgt):
+        return _gat_forward(self, x, src, tgt, Mtgt)
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
+
+
+class FixedGraphConvolution(Module):
+    """GAT layer with (src, tgt, Mtgt) held as attributes (reference: GAT/layers.py:67-127)."""
+
+    def __init__(self, in_features, out_features, bias=True, act=F.relu, eps=1e-6):
+        super(FixedGraphConvolution, self).__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.f = nn.Linear(2 * in_features, out_features)
+        self.w = nn.Linear(2 * in_features, 1)
+        self.eps = eps
+        self.act = act
+        self.reset_parameters()
+        self.src = torch.Tensor([[1]])
+        self.tgt = torch.Tensor([[1]])
+        self.Mtgt = torch.Tensor([[1]])
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.f.weight)
+        nn.init.xavier_uniform_(self.w.weight)
+
+    def set_adj(self, src, tgt, Mtgt):
+        self.src = src
+        self.tgt = tgt
+        self.Mtgt = Mtgt
+
+    def forward(self, x):
+        return _gat_forward(self, x, self.src, self.tgt, self.Mtgt)
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

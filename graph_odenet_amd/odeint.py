@@ -141,6 +141,7 @@ class _OdeintAdjoint(torch.autograd.Function):
         ans = torch.stack(outs)
         ctx.func, ctx.tl, ctx.rtol, ctx.atol, ctx.method, ctx.options = func, tl, rtol, atol, method, options
         ctx.mk_adj = mk_adj
+        ctx.fwd = fwd
         ctx.n_params = len(params)
         ctx.save_for_backward(ans)
         return ans
@@ -150,7 +151,9 @@ class _OdeintAdjoint(torch.autograd.Function):
         (ans,) = ctx.saved_tensors
         func, tl = ctx.func, ctx.tl
         adj = ctx.mk_adj()
+        fwd = ctx.fwd
         grad_out = grad_out.contiguous()
+        ctx_tmp = torch.empty_like(ans[0])
         stats = Dopri5Stats()
         with torch.no_grad():
             comps = adj.new_state(ans[-1]) if hasattr(adj, "new_state") else None
@@ -161,9 +164,14 @@ class _OdeintAdjoint(torch.autograd.Function):
             comps[1].copy_(grad_out[-1])
             for i in range(len(tl) - 1, 0, -1):
                 comps[0].copy_(ans[i])
+                if ctx.method != "rk4":
+                    # dL/dt at the output time enters the adaptive error control (torchdiffeq evaluates
+                    # func once more here); a fixed grid never looks at it, so rk4 skips the eval.
+                    fwd.eval(tl[i], [[(1.0, ans[i])]], [ctx_tmp])
+                    stats.nfe += 1
+                    comps[2].sub_((ctx_tmp * grad_out[i]).sum().reshape(1))
                 _integrate(adj, comps, tl[i], tl[i - 1], ctx.rtol, ctx.atol, ctx.method, ctx.options, stats)
-                if i - 1 > 0 or True:
-                    comps[1].add_(grad_out[i - 1])
+                comps[1].add_(grad_out[i - 1])
         _bump_nfe(func, stats.nfe if getattr(adj, "fused", False) else 0)
         pg = adj.param_grads(comps) if hasattr(adj, "param_grads") else comps[3:]
         return (None, None, None, None, None, None, comps[1], *pg)

@@ -205,3 +205,67 @@ def colsum_(out, X, scale=1.0, accumulate=False):
     check(lib.gode_colsum_f32(ptr(out), ptr(X), n, d, float(scale), 1 if accumulate else 0, ptr(sc), stream_ptr()),
           "gode_colsum_f32")
     return out
+
+
+# ---- GAT-style edge attention ---------------------------------------------------------------
+def edge_softmax_logits(P, o, bw, src, tgt):
+    """a[e] = P[src,2o] + P[tgt,2o+1] + bw ; returns (a[E], amax[1])."""
+    lib = _lib.load()
+    _need(P, "P"); _need(bw, "bw"); _need(src, "src", torch.int32); _need(tgt, "tgt", torch.int32)
+    E = src.numel()
+    a = torch.empty(E, dtype=torch.float32, device=P.device)
+    amax = torch.empty(1, dtype=torch.float32, device=P.device)
+    sc = _scratch(P.device, lib.gode_edge_softmax_scratch_bytes(E))
+    check(lib.gode_edge_softmax_logits_f32(ptr(P), P.shape[1], o, ptr(bw), ptr(src), ptr(tgt), E, ptr(a), ptr(amax),
+                                           ptr(sc), stream_ptr()), "gode_edge_softmax_logits_f32")
+    return a, amax
+
+
+def edge_softmax_agg_fwd(Mt, src, tgt, P, o, bf, a, amax, eps):
+    lib = _lib.load()
+    _need(P, "P"); _need(bf, "bf"); _need(a, "a"); _need(amax, "amax")
+    n = Mt.n_rows
+    out = torch.empty(n, o, dtype=torch.float32, device=P.device)
+    w = torch.zeros(src.numel(), dtype=torch.float32, device=P.device)
+    den = torch.empty(n, dtype=torch.float32, device=P.device)
+    check(lib.gode_edge_softmax_agg_f32_fwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ptr(P),
+                                            P.shape[1], o, ptr(bf), ptr(a), ptr(amax), float(eps), n, ptr(out),
+                                            ptr(w), ptr(den), stream_ptr()), "gode_edge_softmax_agg_f32_fwd")
+    return out, w, den
+
+
+def edge_softmax_agg_bwd(Mt, src, tgt, P, o, bf, w, den, out, dout):
+    lib = _lib.load()
+    _need(dout, "dout"); _need(out, "out")
+    E = src.numel()
+    dz = torch.zeros(E, o, dtype=torch.float32, device=P.device)
+    da = torch.zeros(E, dtype=torch.float32, device=P.device)
+    check(lib.gode_edge_softmax_agg_f32_bwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ptr(P),
+                                            P.shape[1], o, ptr(bf), ptr(w), ptr(den), ptr(out), ptr(dout), Mt.n_rows,
+                                            ptr(dz), ptr(da), stream_ptr()), "gode_edge_softmax_agg_f32_bwd")
+    return dz, da
+
+
+# ---- QC edge-conditioned messages ---------------------------------------------------------------
+def edge_matvec_fwd(Mt, src, A, X):
+    """M[v] = sum_{(e,val) in row v} val * A[e] @ X[src[e]]."""
+    lib = _lib.load()
+    _need(A, "edge_data"); _need(X, "x"); _need(src, "Esrc", torch.int32)
+    h = X.shape[1]
+    if A.dim() != 3 or A.shape[1] != h or A.shape[2] != h or A.shape[0] != src.numel():
+        raise ValueError("edge_matvec: edge_data must be E x h x h with h = %d, got %s" % (h, tuple(A.shape)))
+    out = torch.empty(Mt.n_rows, h, dtype=torch.float32, device=X.device)
+    check(lib.gode_edge_matvec_f32_fwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(A), ptr(X), h, h,
+                                       Mt.n_rows, ptr(out), h, stream_ptr()), "gode_edge_matvec_f32_fwd")
+    return out
+
+
+def edge_matvec_bwd(edge_row, edge_val, src, A, X, dM, want_dA=True, want_dx=True):
+    lib = _lib.load()
+    _need(dM, "dM")
+    E, h = src.numel(), X.shape[1]
+    dA = torch.empty_like(A) if want_dA else None
+    dxe = torch.empty(E, h, dtype=torch.float32, device=X.device) if want_dx else None
+    check(lib.gode_edge_matvec_f32_bwd(ptr(edge_row), ptr(edge_val), ptr(src), ptr(A), ptr(X), h, ptr(dM), h, h, E,
+                                       ptr(dA), ptr(dxe), stream_ptr()), "gode_edge_matvec_f32_bwd")
+    return dA, dxe

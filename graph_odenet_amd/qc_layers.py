@@ -1,0 +1,132 @@
+"""QC (QM9) edge-conditioned layers with the reference's names and API:
+
+    MPNN_enn_edge(edge_data_dim, node_data_hidden_dim=200).set_T(t); .forward(x, Esrc, Etgt, edge_data)
+                                                                       (QC/mpnn.py:5-32)
+    EdgeGraphConvolution(in_features, out_features, node_layers=1, edge_layers=1, bias=True)
+        .forward(input, Esrc, Etgt, edge_data)                        (QC/layers.py:114-154)
+
+`Etgt` is the reference's DENSE N x E incidence (QC/datasets/utils.py:214); it is converted once per
+tensor object to CSR (values kept).  The message step M = Etgt @ bmm(edge_data, x[Esrc]) runs in
+csrc/edge.hip without materialising the E x h edge messages; the GRU update stays a dense PyTorch
+cell (out of the hot-path scope).
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.modules.module import Module
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .graph import as_graph, incidence_from_index
+
+_cache = {}
+
+
+class _EdgeSet:
+    def __init__(self, Esrc, Etgt):
+        self.Mt = as_graph(Etgt)                          # N x E CSR with values
+        self.E = Esrc.numel()
+        self.n = self.Mt.n_rows
+        if self.Mt.n_cols != self.E:
+            raise ValueError("Etgt must be N x E with E = len(Esrc)")
+        self.src = Esrc.to(torch.int32).contiguous()
+        self.Ms_inc = incidence_from_index(self.src, self.n)
+        # per-edge target row / value for the backward kernel (-1: edge not attached to any node)
+        rp = self.Mt.rowptr.to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(self.n, device=rp.device), rp[1:] - rp[:-1])
+        cols = self.Mt.col.to(torch.int64)
+        if cols.numel() and torch.bincount(cols, minlength=self.E).max().item() > 1:
+            raise NotImplementedError("Etgt with more than one entry per edge column is not supported")
+        self.edge_row = torch.full((self.E,), -1, dtype=torch.int32, device=rp.device)
+        self.edge_row[cols] = rows.to(torch.int32)
+        self.edge_val = torch.zeros(self.E, dtype=torch.float32, device=rp.device)
+        self.edge_val[cols] = self.Mt.val if self.Mt.val is not None else 1.0
+
+
+def _edges(Esrc, Etgt):
+    key = (id(Esrc), id(Etgt))
+    hit = _cache.get(key)
+    if hit is not None and hit[0] is Esrc and hit[1] is Etgt:
+        return hit[2]
+    es = _EdgeSet(Esrc, Etgt)
+    if len(_cache) > 64:
+        _cache.clear()
+    _cache[key] = (Esrc, Etgt, es)
+    return es
+
+
+class _EdgeMessageFn(torch.autograd.Function):
+    """M = Etgt @ bmm(edge_data, x[Esrc])   (QC/mpnn.py:27-29 == QC/layers.py:143-145)."""
+
+    @staticmethod
+    def forward(ctx, es, x, edge_data):
+        x = x.contiguous()
+        edge_data = edge_data.contiguous()
+        ctx.es = es
+        ctx.save_for_backward(x, edge_data)
+        return ops.edge_matvec_fwd(es.Mt, es.src, edge_data, x)
+
+    @staticmethod
+    def backward(ctx, dM):
+        x, A = ctx.saved_tensors
+        es = ctx.es
+        dA, dxe = ops.edge_matvec_bwd(es.edge_row, es.edge_val, es.src, A, x, dM.contiguous(),
+                                      want_dA=ctx.needs_input_grad[2], want_dx=ctx.needs_input_grad[1])
+        dx = ops.spmm(es.Ms_inc, dxe) if dxe is not None else None
+        return None, dx, dA
+
+
+def edge_message(x, Esrc, Etgt, edge_data):
+    return _EdgeMessageFn.apply(_edges(Esrc, Etgt), x, edge_data)
+
+
+class MPNN_enn_edge(nn.Module):
+    """QC/mpnn.py:5-32."""
+
+    def __init__(self, edge_data_dim, node_data_hidden_dim=200):
+        super(MPNN_enn_edge, self).__init__()
+        self.e_d = edge_data_dim
+        self.h_d = node_data_hidden_dim
+        self.update_net = nn.GRUCell(self.h_d * 2, self.h_d)
+        self.T = 8
+
+    def set_T(self, t):
+        self.T = t
+
+    def forward(self, x, Esrc, Etgt, edge_data):
+        for t in range(self.T):
+            node_msg = edge_message(x, Esrc, Etgt, edge_data)
+            x = self.update_net(torch.cat([x, node_msg], 1), x)
+        return x
+
+
+class EdgeGraphConvolution(Module):
+    """QC/layers.py:114-154."""
+
+    def __init__(self, in_features, out_features, node_layers=1, edge_layers=1, bias=True):
+        super(EdgeGraphConvolution, self).__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = Parameter(torch.empty(in_features, out_features))
+        if bias:
+            self.bias = Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def forward(self, input, Esrc, Etgt, edge_data):
+        support = torch.mm(input, self.weight)
+        output = edge_message(support, Esrc, Etgt, edge_data)
+        if self.bias is not None:
+            return output + self.bias
+        return output
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

@@ -140,8 +140,46 @@ int gode_colsum_f32(float* out, const float* X, int64_t n_rows, int64_t d, float
                     int accumulate, float* scratch /* >= gode_colsum_scratch_bytes */, void* stream);
 int64_t gode_colsum_scratch_bytes(int64_t n_rows, int64_t d);
 
+/* ---- GAT-style edge attention (GAT/layers.py:40-55, :104-120) --------------------------
+ * The two Linear layers of the reference act on h = [x[src] | x[tgt]]; the caller applies them at
+ * node level: P (n_nodes x ldp, ldp >= 2o+2) = x * [Wf_src^T | Wf_tgt^T | ww_src^T | ww_tgt^T].
+ *   a[e]   = P[src[e], 2o] + P[tgt[e], 2o+1] + bw[0]         amax[0] = max_e a[e]   (GLOBAL max, :47)
+ *   w[e]   = exp(a[e] - amax)
+ *   out[v] = sum_k val[k]*w[e_k]*relu(P[src,0:o] + P[tgt,o:2o] + bf) / (sum_k val[k]*w[e_k] + eps)
+ * over the entries k of row v of Mtgt in CSR form (rowptr, eid = column = edge id, val or NULL = 1).
+ * den_out[v] holds the denominator, w_out[e] the unnormalised weight (both needed by the backward).
+ * Backward returns dz (E x o: gradient w.r.t. the pre-activation z_e) and da (E: gradient w.r.t. a[e]
+ * through w only; the caller adds the path through the global max and scatters both to the nodes
+ * with gode_spmm_csr_f32 over the src / tgt incidence matrices). */
+int64_t gode_edge_softmax_scratch_bytes(int64_t n_edges);
+int gode_edge_softmax_logits_f32(const float* P, int64_t ldp, int64_t o, const float* bw /* nullable */,
+                                 const int32_t* src, const int32_t* tgt, int64_t n_edges,
+                                 float* a, float* amax, float* scratch, void* stream);
+int gode_edge_softmax_agg_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
+                                  const int32_t* src, const int32_t* tgt,
+                                  const float* P, int64_t ldp, int64_t o, const float* bf /* nullable */,
+                                  const float* a, const float* amax, float eps, int64_t n_rows,
+                                  float* out, float* w_out, float* den_out, void* stream);
+int gode_edge_softmax_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, const float* val,
+                                  const int32_t* src, const int32_t* tgt,
+                                  const float* P, int64_t ldp, int64_t o, const float* bf,
+                                  const float* w, const float* den, const float* out, const float* dout,
+                                  int64_t n_rows, float* dz, float* da, void* stream);
+
+/* ---- QC edge-conditioned messages (QC/mpnn.py:27-29, QC/layers.py:143-145) ----------------
+ * out[v,:] = sum_k val[k] * A[e_k] (h x h, row-major) * X[src[e_k], :]   over row v of Etgt (CSR).
+ * Backward (one block per edge): dm = edge_val[e] * dM[edge_row[e], :] (edge_row < 0: edge unused),
+ *   dA[e] = dm (x) X[src[e]]   (nullable),   dxe[e,:] = A[e]^T dm   (nullable; the caller sums dxe
+ *   per source node with gode_spmm_csr_f32 over the src incidence matrix). */
+int gode_edge_matvec_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
+                             const int32_t* src, const float* A, const float* X, int64_t ldx,
+                             int64_t h, int64_t n_rows, float* out, int64_t ldo, void* stream);
+int gode_edge_matvec_f32_bwd(const int32_t* edge_row, const float* edge_val, const int32_t* src,
+                             const float* A, const float* X, int64_t ldx, const float* dM, int64_t ldm,
+                             int64_t h, int64_t n_edges, float* dA, float* dxe, void* stream);
+
 /* ---- measurement aid (bench.py): HIP-event brackets around the SpMM main kernel ----------
- * While a profiler is enabled on the calling thread, every gode_spmm_csr_f32 fast-path launch
+ * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 fast-path launch
  * records a start/stop event pair on its stream (up to `capacity` launches).
  * gode_prof_read waits for the recorded events and returns the number of launches read, with
  * per-launch milliseconds, feature width d and record count. */

@@ -245,21 +245,27 @@ class _Adjoint(torch.autograd.Function):
             vt = vj[0] if vj[0] is not None else torch.zeros_like(tt)
             vy = vj[1] if vj[1] is not None else torch.zeros_like(y)
             vp = [v if v is not None else torch.zeros_like(p) for v, p in zip(vj[2:], params)]
-            return (fe.detach(), vy, vt.reshape(()), *vp)
+            # torchdiffeq keeps ONE flat tensor for all parameter adjoints (error ratio over all of them)
+            flat = torch.cat([v.reshape(-1) for v in vp]) if vp else torch.zeros(0, dtype=y.dtype)
+            return (fe.detach(), vy, vt.reshape(()), flat)
 
         with torch.no_grad():
             adj_y = grad_out[-1].clone()
             adj_t = torch.zeros((), dtype=t.dtype)
-            adj_p = [torch.zeros_like(p) for p in params]
+            adj_p = torch.zeros(sum(p.numel() for p in params), dtype=grad_out.dtype)
             for i in range(len(t) - 1, 0, -1):
                 f_i = func(t[i], ans[i])
                 adj_t = adj_t - (f_i * grad_out[i]).sum()
-                state = (ans[i], adj_y, adj_t, *adj_p)
+                state = (ans[i], adj_y, adj_t, adj_p)
                 sol = odeint(aug, state, torch.stack([t[i], t[i - 1]]), ctx.rtol, ctx.atol, ctx.method, ctx.options)
                 adj_y = sol[1][1] + grad_out[i - 1]
                 adj_t = sol[2][1]
-                adj_p = [s[1] for s in sol[3:]]
-        return (None, None, None, None, None, None, adj_y, *adj_p)
+                adj_p = sol[3][1]
+        out_p, o = [], 0
+        for p_ in params:
+            out_p.append(adj_p[o:o + p_.numel()].view_as(p_))
+            o += p_.numel()
+        return (None, None, None, None, None, None, adj_y, *out_p)
 
 
 def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):

@@ -142,6 +142,8 @@ def test_gn_time_gemm_fwd_bwd_wgrad(d, groups, n):
     """GroupNorm + time column + GEMM against plain torch CPU ops (GCN/models.py:175-177 + layers.py:70)."""
     from graph_odenet_amd import ops
     import torch.nn.functional as F
+    if n == 1 and groups == d:
+        pytest.skip("torch's own group_norm refuses one value per group at batch 1")
     torch.manual_seed(d * 7 + n)
     y, k1 = torch.randn(n, d), torch.randn(n, d)
     h = 0.3
