@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_round.sh output directory into the small text/JSON files kept under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "gpurun_out", "profiles_" + tag)
+os.makedirs(prof, exist_ok=True)
+
+KPAT = re.compile(r"(spmm\w+<\d+>|gn_gemm\w+<\d+, \d+>|wgrad_kernel<\d+, \d+>|reduce_parts_kernel|colsum4?_kernel|lincomb\d_kernel|"
+                  r"ratio_sumsq_kernel<\d>|gat_\w+|edge_matvec\w+|final_\w+)")
+
+
+def short(name):
+    m = KPAT.search(name)
+    return m.group(1) if m else name.split("(")[0][-60:]
+
+
+# 1) kernel stats
+lines = []
+for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py   (round %s)" % tag)
+    lines.append("# %-46s %7s %12s %12s %7s" % ("kernel", "calls", "avg_us", "total_ms", "pct"))
+    for r in rows[:25]:
+        lines.append("%-48s %7s %12.1f %12.2f %6.1f%%" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                        float(r["TotalDurationNs"]) / 1e6, 100 * float(r["TotalDurationNs"]) / tot))
+if os.path.exists(out + "/bench_stats.log"):
+    last = open(out + "/bench_stats.log").read().strip().splitlines()
+    js = [l for l in last if l.startswith("{")]
+    if js:
+        lines.append("# bench line of the same (profiled) run:")
+        lines.append(js[-1])
+open(os.path.join(prof, "%s_bench_kernel_stats.txt" % tag), "w").write("\n".join(lines) + "\n")
+
+
+# 2) PMC
+def pmc(dirpat):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(out + "/" + dirpat + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+res = {}
+txt = ["# rocprofv3 --pmc passes (one counter group per pass) over python bench.py --steps 1 --warmup 0 (round %s)" % tag]
+for d in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_TCC_HIT_sum_TCC_MISS_sum"):
+    for k, cs in sorted(pmc(d).items()):
+        if not KPAT.search(k):
+            continue
+        for c, v in cs.items():
+            res.setdefault(k, {})[c] = (sum(v) / len(v), len(v))
+for k, cs in sorted(res.items()):
+    txt.append(k)
+    for c, (m, n) in sorted(cs.items()):
+        txt.append("    %-14s mean=%.5g (n=%d)%s" % (c, m, n, "  [KB]" if c.endswith("SIZE") else ""))
+cal = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for k, cs in pmc("cal_" + c).items():
+        if c in cs:
+            cal.setdefault(k, {})[c] = sum(cs[c]) / len(cs[c])
+n, d = 1 << 20, 128
+known = {"lincomb4_kernel": (2 * n * d * 4, n * d * 4), "spmm_vec4_kernel<32>": (n * d * 4 + n * 24, n * d * 4)}
+txt.append("# calibration (tools/calibrate_fetch.py): counter KB*1024 vs known bytes")
+corr = {}
+for k, (rd, wr) in known.items():
+    if k in cal:
+        f = cal[k].get("FETCH_SIZE", 0) * 1024
+        w = cal[k].get("WRITE_SIZE", 0) * 1024
+        txt.append("    %-24s FETCH %.4g B vs known read %.4g B -> x%.3f ; WRITE %.4g B vs known %.4g B -> x%.3f" % (
+            k, f, rd, rd / f if f else float("nan"), w, wr, wr / w if w else float("nan")))
+        corr[k] = (rd / f if f else None, wr / w if w else None)
+sp = res.get("spmm_vec4_kernel<32>")
+if sp and "FETCH_SIZE" in sp and "WRITE_SIZE" in sp:
+    fcorr = (corr.get("spmm_vec4_kernel<32>") or (2.0, 1.0))[0] or 2.0
+    wcorr = (corr.get("spmm_vec4_kernel<32>") or (2.0, 1.0))[1] or 1.0
+    hbm = sp["FETCH_SIZE"][0] * 1024 * fcorr + sp["WRITE_SIZE"][0] * 1024 * wcorr
+    txt.append("# spmm_vec4_kernel<32>: HBM-side bytes per launch = FETCH_SIZE*1024*%.3f + WRITE_SIZE*1024*%.3f = %.4g B" % (fcorr, wcorr, hbm))
+    json.dump({"hbm_bytes_per_launch": int(hbm), "fetch_kb": sp["FETCH_SIZE"][0], "write_kb": sp["WRITE_SIZE"][0],
+               "fetch_correction": fcorr, "write_correction": wcorr, "round": tag,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), corrected by the permutation-SpMM calibration"},
+              open(os.path.join(prof, "spmm_traffic.json"), "w"), indent=1)
+open(os.path.join(prof, "%s_pmc_traffic.txt" % tag), "w").write("\n".join(txt) + "\n")
+print("\n".join(lines[:14]))
+print("\n".join(txt))
