@@ -18,6 +18,7 @@
 // Bounds: fwd/bwd-data read + write one N x d operand each (HBM) against
 // 2*N*d*d flop on the fp32 MFMA pipe (157 TFLOP/s peak) - near the ridge at d=128.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -25,22 +26,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxBlocks = 512;   // 2 blocks per CU
 
+// diagnostic build aid (GODE_GEMM_DEBUG & 16): per-wave phase cycle sums, read back with gode_debug_read
+__device__ unsigned long long g_stamps[2048 * 8];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // GroupNorm statistics of the 4 values a lane holds.  CG = channels per group.
 // CG = 1,2,4: the group is inside the float4.  CG = 8,16: spread over lane groups
 // g (xor 16 / xor 32).  mean/rstd are returned per component.
+// 1/sqrt(v): v_rsq_f32 (1 ulp) + one Newton step -> within 1 ulp of the correctly rounded value; the
+// IEEE sqrtf + divide sequence it replaces costs ~40 dependent VALU instructions per group.
+__device__ __forceinline__ float rsqrt_nr(float v) {
+    float r = __builtin_amdgcn_rsqf(v);
+    r = r * fmaf(-0.5f * v * r, r, 1.5f);
+    return r;
+}
+
 template <int CG>
 __device__ __forceinline__ void gn_stats(const float4 x, float eps, float4& mean, float4& rstd) {
     if (CG == 1) {
         mean = x;
-        const float r = 1.0f / sqrtf(eps);
+        const float r = rsqrt_nr(eps);
         rstd = make_float4(r, r, r, r);
     } else if (CG == 2) {
         const float m0 = (x.x + x.y) * 0.5f, m1 = (x.z + x.w) * 0.5f;
         const float v0 = ((x.x - m0) * (x.x - m0) + (x.y - m0) * (x.y - m0)) * 0.5f;
         const float v1 = ((x.z - m1) * (x.z - m1) + (x.w - m1) * (x.w - m1)) * 0.5f;
-        const float r0 = 1.0f / sqrtf(v0 + eps), r1 = 1.0f / sqrtf(v1 + eps);
+        const float r0 = rsqrt_nr(v0 + eps), r1 = rsqrt_nr(v1 + eps);
         mean = make_float4(m0, m0, m1, m1);
         rstd = make_float4(r0, r0, r1, r1);
     } else {
@@ -52,7 +69,7 @@ __device__ __forceinline__ void gn_stats(const float4 x, float eps, float4& mean
         float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
         if (CG >= 8) q += __shfl_xor(q, 16, 64);
         if (CG >= 16) q += __shfl_xor(q, 32, 64);
-        const float r = 1.0f / sqrtf(q * (1.0f / CG) + eps);
+        const float r = rsqrt_nr(q * (1.0f / CG) + eps);
         mean = make_float4(m, m, m, m);
         rstd = make_float4(r, r, r, r);
     }
@@ -79,6 +96,48 @@ __device__ __forceinline__ float4 gn_forward(const float4 x, float eps, const fl
 }
 
 template <int CG>
+__device__ __forceinline__ float4 gn_forward_v(const float4 x, float eps, const float4 gm, const float4 bt) {
+    if (CG == 0) return x;
+    float4 mean, rstd;
+    gn_stats<CG>(x, eps, mean, rstd);
+    return make_float4(gn_apply1(x.x, mean.x, rstd.x, gm.x, bt.x), gn_apply1(x.y, mean.y, rstd.y, gm.y, bt.y),
+                       gn_apply1(x.z, mean.z, rstd.z, gm.z, bt.z), gn_apply1(x.w, mean.w, rstd.w, gm.w, bt.w));
+}
+
+// Block prologue: W1 (d x d, without the time row) -> LDS with row stride d+4, as 16-byte loads that are all
+// in flight together (TRANSPOSE: Wlds[n][i] = W1[i][n] for the VJP); gamma / beta / time row -> LDS vectors.
+template <int D, int NTHREADS, bool TRANSPOSE>
+__device__ __forceinline__ void fill_w_lds(float* Wl, const float* __restrict__ W, int has_time) {
+    constexpr int LDW = D + 4;
+    constexpr int N4 = D * D / 4;
+    constexpr int IT = (N4 + NTHREADS - 1) / NTHREADS;
+    float4 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < N4) v[it] = ld4(W + (int64_t)has_time * D + (int64_t)idx * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = threadIdx.x + it * NTHREADS;
+        if (idx < N4) {
+            const int k = idx / (D / 4), n = (idx % (D / 4)) * 4;
+            if (!TRANSPOSE) {
+                *reinterpret_cast<float4*>(Wl + k * LDW + n) = v[it];
+            } else {
+                Wl[(n + 0) * LDW + k] = v[it].x; Wl[(n + 1) * LDW + k] = v[it].y;
+                Wl[(n + 2) * LDW + k] = v[it].z; Wl[(n + 3) * LDW + k] = v[it].w;
+            }
+        }
+    }
+}
+template <int D, int NTHREADS>
+__device__ __forceinline__ void fill_vec_lds(float* dst, const float* __restrict__ src, float fill) {
+    for (int c = threadIdx.x; c < D; c += NTHREADS) dst[c] = src ? src[c] : fill;
+}
+
+template <int CG>
 __device__ __forceinline__ float group_mean4(float4 v) {   // mean over the lane's group (CG >= 4)
     float s = (v.x + v.y) + (v.z + v.w);
     if (CG >= 8) s += __shfl_xor(s, 16, 64);
@@ -89,21 +148,21 @@ __device__ __forceinline__ float group_mean4(float4 v) {   // mean over the lane
 
 // Loads the lane's NJ float4 of one 16-row tile, combining the stage terms.  The switch on the
 // (wave-uniform) term count sits OUTSIDE the j loop so that all NT*NJ loads are in flight together.
-template <int NJ, int NT>
+template <int NJ, int NT, int TC = 2>
 __device__ __forceinline__ void load_tile_n(const LinComb& lc, int64_t base, float4 (&xv)[NJ]) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int t0 = 0; t0 < NT; t0 += 2) {      // two terms (2*NJ loads) in flight at a time bounds the registers
-        float4 v[2][NJ];
+    for (int t0 = 0; t0 < NT; t0 += TC) {     // TC terms (TC*NJ loads) in flight at a time bounds the registers
+        float4 v[TC][NJ];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < TC; ++tt)
             if (t0 + tt < NT) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) v[tt][j] = ld4(lc.ptr[t0 + tt] + base + 16 * j);
             }
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < TC; ++tt)
             if (t0 + tt < NT) {
                 const float c = lc.coef[t0 + tt];
 #pragma unroll
@@ -115,7 +174,7 @@ __device__ __forceinline__ void load_tile_n(const LinComb& lc, int64_t base, flo
     }
 }
 
-template <int NJ>
+template <int NJ, int TC = 2>
 __device__ __forceinline__ void load_tile(const LinComb& lc, int64_t base, bool valid, float4 (&xv)[NJ]) {
     if (!valid) {
 #pragma unroll
@@ -123,43 +182,58 @@ __device__ __forceinline__ void load_tile(const LinComb& lc, int64_t base, bool 
         return;
     }
     switch (lc.n) {
-        case 1: load_tile_n<NJ, 1>(lc, base, xv); break;
-        case 2: load_tile_n<NJ, 2>(lc, base, xv); break;
-        case 3: load_tile_n<NJ, 3>(lc, base, xv); break;
-        case 4: load_tile_n<NJ, 4>(lc, base, xv); break;
-        case 5: load_tile_n<NJ, 5>(lc, base, xv); break;
-        case 6: load_tile_n<NJ, 6>(lc, base, xv); break;
-        case 7: load_tile_n<NJ, 7>(lc, base, xv); break;
-        default: load_tile_n<NJ, 8>(lc, base, xv); break;
+        case 1: load_tile_n<NJ, 1, TC>(lc, base, xv); break;
+        case 2: load_tile_n<NJ, 2, TC>(lc, base, xv); break;
+        case 3: load_tile_n<NJ, 3, TC>(lc, base, xv); break;
+        case 4: load_tile_n<NJ, 4, TC>(lc, base, xv); break;
+        case 5: load_tile_n<NJ, 5, TC>(lc, base, xv); break;
+        case 6: load_tile_n<NJ, 6, TC>(lc, base, xv); break;
+        case 7: load_tile_n<NJ, 7, TC>(lc, base, xv); break;
+        default: load_tile_n<NJ, 8, TC>(lc, base, xv); break;
     }
 }
 
 // One 16-row panel: acc[tt] += sum_k Wlds[k][16tt + r] * xb[k]   (k-slot g of step (j,c) carries k = 16j+4g+c).
 // The A operands of step s+1 are read from LDS before the MFMAs of step s are issued, and a
 // scheduling barrier per step keeps hipcc from hoisting all 4*NJ*NJ LDS reads to the top (spills).
-template <int NJ>
+template <int NJ, bool PIPE = true>
 __device__ __forceinline__ void mfma_panel(const float* wl /* Wlds + 4g*LDW + r */, const float4 (&xv)[NJ], f32x4 (&acc)[NJ]) {
     constexpr int LDW = 16 * NJ + 4;
-    float a_cur[NJ], a_nxt[NJ];
+    if (PIPE) {
+        // ping-pong operand registers: step s multiplies out of a[s&1] while a[(s+1)&1] is being read
+        // from LDS (indices are compile-time after unrolling, so no register moves are generated)
+        float a[2][NJ];
 #pragma unroll
-    for (int tt = 0; tt < NJ; ++tt) a_cur[tt] = wl[16 * tt];
+        for (int tt = 0; tt < NJ; ++tt) a[0][tt] = wl[16 * tt];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const float xb[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int s = 4 * j + c;
+        for (int s = 0; s < 4 * NJ; ++s) {
+            const int j = s / 4, c = s % 4;
+            const float xb = c == 0 ? xv[j].x : (c == 1 ? xv[j].y : (c == 2 ? xv[j].z : xv[j].w));
             if (s + 1 < 4 * NJ) {
                 const int jn = (s + 1) / 4, cn = (s + 1) % 4;
 #pragma unroll
-                for (int tt = 0; tt < NJ; ++tt) a_nxt[tt] = wl[(16 * jn + cn) * LDW + 16 * tt];
+                for (int tt = 0; tt < NJ; ++tt) a[(s + 1) & 1][tt] = wl[(16 * jn + cn) * LDW + 16 * tt];
             }
 #pragma unroll
             for (int tt = 0; tt < NJ; ++tt)
-                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[tt], xb[c], acc[tt], 0, 0, 0);
-#pragma unroll
-            for (int tt = 0; tt < NJ; ++tt) a_cur[tt] = a_nxt[tt];
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tt], xb, acc[tt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // 4 waves per SIMD: the other waves cover the LDS latency, so no register double-buffering
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float xb[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float a[NJ];
+#pragma unroll
+                for (int tt = 0; tt < NJ; ++tt) a[tt] = wl[(16 * j + c) * LDW + 16 * tt];
+#pragma unroll
+                for (int tt = 0; tt < NJ; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], xb[c], acc[tt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }
@@ -167,55 +241,98 @@ __device__ __forceinline__ void mfma_panel(const float* wl /* Wlds + 4g*LDW + r 
 // ---------------------------------------------------------------------------------
 // forward:  S[row, :] = t*W[0,:] + GN(x[row,:]) * W[1:, :]
 // ---------------------------------------------------------------------------------
-template <int NJ, int CG>   // d = 16*NJ
-__global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_rows, float eps,
+// Lane layouts of a 16-row tile (wave64):
+//   memory layout  ("M"): lane m -> row m>>2, 16-byte chunk m&3 of each 64-byte column block j.  Adjacent
+//                         lanes touch adjacent 16 B, so one wave instruction is 16 runs of 64 contiguous
+//                         bytes (loads AND stores are issued in this layout);
+//   MFMA layout    ("F"): lane f -> row f&15, k-slot / column quad f>>4 (fixed by v_mfma_f32_16x16x4_f32).
+// A direct global access in layout F puts adjacent lanes 512 B apart: 64 separate 16-B requests per
+// instruction (measured: 1 TB/s).  The two layouts hold the same (row, chunk) set, so one ds_bpermute per
+// register converts between them: F-lane (g, r) takes from M-lane 4r+g; M-lane m takes from F-lane
+// (m&3)*16 + (m>>2).  Term combination and GroupNorm act per float4 and are done in layout M.
+__device__ __forceinline__ float4 to_mfma_layout(const float4 v, int src_m_lane_x4) {
+    return make_float4(__int_as_float(__builtin_amdgcn_ds_bpermute(src_m_lane_x4, __float_as_int(v.x))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src_m_lane_x4, __float_as_int(v.y))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src_m_lane_x4, __float_as_int(v.z))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src_m_lane_x4, __float_as_int(v.w))));
+}
+__device__ __forceinline__ float4 acc_to_mem_layout(const f32x4 a, int src_f_lane_x4) {
+    return make_float4(__int_as_float(__builtin_amdgcn_ds_bpermute(src_f_lane_x4, __float_as_int(a[0]))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src_f_lane_x4, __float_as_int(a[1]))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src_f_lane_x4, __float_as_int(a[2]))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute(src_f_lane_x4, __float_as_int(a[3]))));
+}
+
+template <int NJ, int CG, int NW>   // d = 16*NJ, NW waves per block
+__global__ __launch_bounds__(64 * NW, (NW == 12 ? 3 : NW / 2)) void gn_gemm_fwd_kernel(LinComb xin, int n_rows, float eps,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ W, int has_time, float t,
-                                                             float* __restrict__ S)
+                                                             float* __restrict__ S, int dbg)
 {
     constexpr int D = 16 * NJ;
     constexpr int LDW = D + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ws = smem;
-    for (int idx = threadIdx.x; idx < D * D; idx += 256) {
-        const int k = idx / D, n = idx % D;
-        Ws[k * LDW + n] = W[(int64_t)(k + has_time) * D + n];
-    }
+    float* Gs = smem + D * LDW;          // gamma | beta | t * W[0,:]
+    float* Bs = Gs + D;
+    float* T0 = Bs + D;
+    fill_w_lds<D, 64 * NW, false>(Ws, W, has_time);
+    fill_vec_lds<D, 64 * NW>(Gs, gamma, 1.f);
+    fill_vec_lds<D, 64 * NW>(Bs, beta, 0.f);
+    for (int c = threadIdx.x; c < D; c += 64 * NW) T0[c] = has_time ? t * W[c] : 0.f;
     __syncthreads();
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int r = l & 15, g = l >> 4;          // MFMA layout
+    const int mr = l >> 2, mg = l & 3;         // memory layout
+    const int to_f = (4 * r + g) * 4, to_m = (mg * 16 + mr) * 4;
     const int n_tiles = (n_rows + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
-        const int row = tile * 16 + r;
+    // The two blocks that share a CU run the same program; started together their waves reach the
+    // VALU-heavy prologue (combine, GroupNorm, layout change) and the MFMA phase in lockstep and then
+    // queue on one matrix pipe.  Half a tile period of skew for the second wave of blocks lets one
+    // SIMD partner compute while the other loads / normalises.
+    if (dbg & 8) { if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(80); }
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    const bool st = dbg & 16;
+    const unsigned long long t_begin = st ? stamp() : 0;
+    for (int tile = blockIdx.x * NW + wave; tile < n_tiles; tile += gridDim.x * NW) {
+        unsigned long long t0 = st ? stamp() : 0;
+        const int row = tile * 16 + mr;
         const bool valid = row < n_rows;
         float4 xv[NJ];
-        load_tile<NJ>(xin, (int64_t)row * D + 4 * g, valid, xv);
+        load_tile<NJ, (NW > 4 ? 1 : 2)>(xin, (int64_t)row * D + 4 * mg, valid && !(dbg & 4), xv);
+        if (st) { const unsigned long long t1 = stamp(); ph[0] += t1 - t0; t0 = t1; }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) xv[j] = gn_forward<CG>(xv[j], eps, gamma, beta, 16 * j + 4 * g);
-
+        for (int j = 0; j < NJ; ++j) {
+            xv[j] = gn_forward_v<CG>(xv[j], eps, ld4(Gs + 16 * j + 4 * mg), ld4(Bs + 16 * j + 4 * mg));
+            xv[j] = to_mfma_layout(xv[j], to_f);
+        }
+        if (st) { const unsigned long long t1 = stamp(); ph[1] += t1 - t0; t0 = t1; }
         f32x4 acc[NJ];
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) {
-            if (has_time) {
-                const float4 w0 = ld4(W + 16 * tt + 4 * g);
-                acc[tt] = (f32x4){t * w0.x, t * w0.y, t * w0.z, t * w0.w};
-            } else {
-                acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            const float4 w0 = ld4(T0 + 16 * tt + 4 * g);
+            acc[tt] = (f32x4){w0.x, w0.y, w0.z, w0.w};
         }
-        mfma_panel<NJ>(Ws + 4 * g * LDW + r, xv, acc);
-        if (valid) {
+        if (!(dbg & 1)) mfma_panel<NJ, (NW <= 4)>(Ws + 4 * g * LDW + r, xv, acc);
+        else { _Pragma("unroll") for (int tt = 0; tt < NJ; ++tt) { acc[tt][0] += xv[tt].x; acc[tt][1] += xv[tt].y; acc[tt][2] += xv[tt].z; acc[tt][3] += xv[tt].w; } }
+        if (st) { const unsigned long long t1 = stamp(); ph[2] += t1 - t0; t0 = t1; }
 #pragma unroll
-            for (int tt = 0; tt < NJ; ++tt)
-                *reinterpret_cast<float4*>(S + (int64_t)row * D + 16 * tt + 4 * g) =
-                    make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+        for (int tt = 0; tt < NJ; ++tt) {
+            const float4 o = acc_to_mem_layout(acc[tt], to_m);
+            if (valid && (!(dbg & 2) || o.x == 12345.678f)) *reinterpret_cast<float4*>(S + (int64_t)row * D + 16 * tt + 4 * mg) = o;
         }
+        if (st) { const unsigned long long t1 = stamp(); ph[3] += t1 - t0; }
+    }
+    if (st && l == 0) {
+        const int wid = blockIdx.x * NW + wave;
+        if (wid < 2048) { for (int q = 0; q < 4; ++q) g_stamps[wid * 8 + q] = ph[q]; g_stamps[wid * 8 + 4] = stamp() - t_begin; }
     }
 }
 
 // ---------------------------------------------------------------------------------
 // VJP w.r.t. x:  dxn = dS * W1^T ; dx = GN'(x)^T dxn ; out = out_scale*dx
-// per-wave partial sums of dgamma / dbeta.
+// one partial sum of dgamma / dbeta per block.
 // ---------------------------------------------------------------------------------
 template <int NJ, int CG>
 __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_rows, float eps,
@@ -230,37 +347,41 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
     constexpr int LDW = D + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wt = smem;   // Wt[n][i] = W1[i][n]
-    for (int idx = threadIdx.x; idx < D * D; idx += 256) {
-        const int i = idx / D, n = idx % D;
-        Wt[n * LDW + i] = W[(int64_t)(i + has_time) * D + n];
-    }
+    float* Gs = smem + D * LDW;
+    fill_w_lds<D, 256, true>(Wt, W, has_time);
+    fill_vec_lds<D, 256>(Gs, gamma, 1.f);
     __syncthreads();
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int r = l & 15, g = l >> 4;          // MFMA layout
+    const int mr = l >> 2, mg = l & 3;         // memory layout
+    const int to_f = (4 * r + g) * 4, to_m = (mg * 16 + mr) * 4;
     const int n_tiles = (n_rows + 15) / 16;
-    float4 dgs[NJ], dbs[NJ];
+    float4 dgs[NJ], dbs[NJ];                   // memory layout: channels 16tt + 4mg .. +3 of row mr
 #pragma unroll
     for (int j = 0; j < NJ; ++j) { dgs[j] = make_float4(0.f, 0.f, 0.f, 0.f); dbs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
 
     for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
-        const int row = tile * 16 + r;
+        const int row = tile * 16 + mr;
         const bool valid = row < n_rows;
         float4 gv[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) gv[j] = ld4(dS + (int64_t)row * D + 16 * j + 4 * g);
+            if (valid) gv[j] = ld4(dS + (int64_t)row * D + 16 * j + 4 * mg);
         }
-        float4 xt[NJ];      // x tile, fetched before the MFMA phase so that its latency hides under it
-        if (CG != 0) load_tile<NJ>(xin, (int64_t)row * D + 4 * g, valid, xt);
+        float4 xt[NJ];      // x tile (memory layout), fetched before the MFMA phase so that its latency hides under it
+        if (CG != 0) load_tile<NJ>(xin, (int64_t)row * D + 4 * mg, valid, xt);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) gv[j] = to_mfma_layout(gv[j], to_f);
         f32x4 acc[NJ];
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         mfma_panel<NJ>(Wt + 4 * g * LDW + r, gv, acc);
-        // acc[tt] = dxn[row][16tt+4g .. +3]
+        // acc[tt] (MFMA layout) = dxn[row r][16tt+4g .. +3]  ->  memory layout for GroupNorm backward + store
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) {
-            const int c0 = 16 * tt + 4 * g;
-            float4 dy = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+            const int c0 = 16 * tt + 4 * mg;
+            const float4 dy = acc_to_mem_layout(acc[tt], to_m);
             float4 out = dy;
             if (CG != 0) {
                 const float4 x = xt[tt];
@@ -268,8 +389,7 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                 gn_stats<CG>(x, eps, mean, rstd);
                 const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y,
                                               (x.z - mean.z) * rstd.z, (x.w - mean.w) * rstd.w);
-                float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (gamma) gm = ld4(gamma + c0);
+                const float4 gm = ld4(Gs + c0);
                 const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
                 if (valid) {
                     dgs[tt].x += dy.x * xh.x; dgs[tt].y += dy.y * xh.y; dgs[tt].z += dy.z * xh.z; dgs[tt].w += dy.w * xh.w;
@@ -288,8 +408,8 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                     ds = make_float4(px.x + px.y, px.x + px.y, px.z + px.w, px.z + px.w);
                     db = make_float4(dh.x + dh.y, dh.x + dh.y, dh.z + dh.w, dh.z + dh.w);
                 } else {
-                    const float a = group_mean4<(CG < 4 ? 4 : CG)>(px) * CG;
-                    const float b = group_mean4<(CG < 4 ? 4 : CG)>(dh) * CG;
+                    const float a = (px.x + px.y) + (px.z + px.w);
+                    const float b = (dh.x + dh.y) + (dh.z + dh.w);
                     ds = make_float4(a, a, a, a); db = make_float4(b, b, b, b);
                 }
                 constexpr float sc = 1.0f / (CG > 0 ? CG : 1);
@@ -309,18 +429,18 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
     }
     if (CG != 0 && dgamma_part) {
         __syncthreads();                       // every wave is done with Wt: reuse LDS for the reduction
-        float* red = smem;                     // [2][4 waves][D]
+        float* red = smem;                     // [2][4 waves][D]  (Gs lies behind Wt and is not touched)
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) {
             float4 a = dgs[tt], b = dbs[tt];
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
+            for (int o = 4; o < 64; o <<= 1) {  // lanes with equal mg (l & 3) hold the same channels
                 a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
                 b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
             }
-            if (r == 0) {
-                *reinterpret_cast<float4*>(red + wave * D + 16 * tt + 4 * g) = a;
-                *reinterpret_cast<float4*>(red + (4 + wave) * D + 16 * tt + 4 * g) = b;
+            if (mr == 0) {
+                *reinterpret_cast<float4*>(red + wave * D + 16 * tt + 4 * mg) = a;
+                *reinterpret_cast<float4*>(red + (4 + wave) * D + 16 * tt + 4 * mg) = b;
             }
         }
         __syncthreads();
@@ -363,6 +483,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(LinComb xin, int n_rows, 
         for (int b = 0; b < NJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    const float4 gmv = (gamma && tcol < D) ? ld4(gamma + tcol) : make_float4(1.f, 1.f, 1.f, 1.f);   // this thread's columns
+    const float4 btv = (beta && tcol < D) ? ld4(beta + tcol) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int n_tiles = (n_rows + R - 1) / R;
     constexpr int NP = (R + RPP - 1) / RPP;    // staging passes per tile (4 at d = 128)
     float4 xr[NP], gr[NP];
@@ -396,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(LinComb xin, int n_rows, 
             const int rr = trow + p * RPP;
             if (rr < R) {
                 const int row = tile * R + rr;
-                float4 x = gn_forward<CG>(xr[p], eps, gamma, beta, tcol);     // CG in {0,1,2,4}: group inside the float4
+                float4 x = gn_forward_v<CG>(xr[p], eps, gmv, btv);            // CG in {0,1,2,4}: group inside the float4
                 if (row >= n_rows) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(Xs + rr * LD + tcol) = x;
                 *reinterpret_cast<float4*>(Gs + rr * LD + tcol) = gr[p];
@@ -640,6 +762,17 @@ int64_t fwd_blocks(int64_t n_rows) {
     if (b > kMaxBlocks) b = kMaxBlocks;
     return b;
 }
+int64_t blocks_nw(int64_t n_rows, int nw, int64_t cap) {
+    int64_t b = ((n_rows + 15) / 16 + nw - 1) / nw;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return b;
+}
+int gemm_dbg() { static int d = [] { const char* e = getenv("GODE_GEMM_DEBUG"); return e ? atoi(e) : 0; }(); return d; }
+int fwd_waves() {      // tuning switch (read once): GODE_GEMM_WAVES=4|8|12 waves per block
+    static int w = [] { const char* e = getenv("GODE_GEMM_WAVES"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 12) ? v : 4; }();
+    return w;
+}
 int64_t wgrad_blocks(int64_t n_rows) {
     int64_t b = (n_rows + 31) / 32;
     if (b < 1) b = 1;
@@ -684,12 +817,17 @@ extern "C" int gode_gn_time_gemm_f32(const gode_lincomb_t* xin, int64_t n_rows, 
                     (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15));
     if (cg >= 0 && al) {
         const int nj = (int)(d_in / 16);
-        const size_t lds = (size_t)d_in * (d_in + 4) * sizeof(float);
+        const size_t lds = ((size_t)d_in * (d_in + 4) + 3 * d_in) * sizeof(float);
         const int64_t blocks = fwd_blocks(n_rows);
+#define GODE_FWD_LAUNCH(NJV, CGV, NWV, NBLK)                                                        \
+        { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV, NWV>, lds); if (rc) return rc;                  \
+          hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV, NWV>), dim3((unsigned)(NBLK)), dim3(64 * NWV), lds, s, \
+                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S, gemm_dbg()); }
 #define GODE_FWD(NJV, CGV)                                                                          \
-        { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
-          hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
-                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S);                 \
+        { const int nw = fwd_waves();                                                               \
+          if (nw == 12) GODE_FWD_LAUNCH(NJV, CGV, 12, blocks_nw(n_rows, 12, 256))                   \
+          else if (nw == 8) GODE_FWD_LAUNCH(NJV, CGV, 8, blocks_nw(n_rows, 8, 512))                 \
+          else GODE_FWD_LAUNCH(NJV, CGV, 4, blocks)                                                 \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_FWD)
 #undef GODE_FWD
@@ -735,7 +873,8 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
                     (!dgamma_part || (!(((uintptr_t)dgamma_part) & 15) && !(((uintptr_t)dbeta_part) & 15)));
     if (cg >= 0 && al) {
         const int nj = (int)(d_in / 16);
-        const size_t lds = (size_t)d_in * (d_in + 4) * sizeof(float);
+        size_t lds = ((size_t)d_in * (d_in + 4) + d_in) * sizeof(float);
+        if (lds < (size_t)8 * d_in * sizeof(float)) lds = (size_t)8 * d_in * sizeof(float);
         const int64_t blocks = fwd_blocks(n_rows);
 #define GODE_BWD(NJV, CGV)                                                                          \
         { rc = set_lds(gn_gemm_bwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
@@ -789,4 +928,8 @@ extern "C" int gode_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t
                        (int)groups, eps, gamma, beta, dS, (int)d_out, has_time, dW_part);
     GODE_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gode_debug_read(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
 }
