@@ -21,6 +21,12 @@ class LinComb(ctypes.Structure):
                 ("ptr", ctypes.c_void_p * GODE_MAX_TERMS)]
 
 
+class SpmmEpilogue(ctypes.Structure):
+    """Mirror of gode_spmm_epilogue_t."""
+    _fields_ = [("bias", ctypes.c_void_p), ("relu", ctypes.c_int32), ("alpha", ctypes.c_float),
+                ("pre", LinComb), ("cot", LinComb), ("Y2", ctypes.c_void_p)]
+
+
 c_i64 = ctypes.c_int64
 c_p = ctypes.c_void_p
 c_f = ctypes.c_float
@@ -31,7 +37,7 @@ SIGNATURES = {
     "gode_abi_version": (c_i, []),
     "gode_error_string": (ctypes.c_char_p, [c_i]),
     "gode_spmm_csr_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64,
-                                c_i64, c_i64, c_p, c_i, ctypes.POINTER(LinComb), c_p, c_p]),
+                                c_i64, c_i64, ctypes.POINTER(SpmmEpilogue), c_p]),
     "gode_lincomb_f32": (c_i, [c_p, ctypes.POINTER(LinComb), c_i64, c_p]),
     "gode_rk_errnorm_scratch_bytes": (c_i64, []),
     "gode_rk_errnorm_f32": (c_i, [c_p, c_p, c_p, ctypes.POINTER(LinComb), c_f, c_f, c_i64, c_p, c_p]),
@@ -40,7 +46,7 @@ SIGNATURES = {
                                     c_p, c_i64, c_i, c_f, c_p, c_p]),
     "gode_gemm_bwd_parts": (c_i64, [c_i64]),
     "gode_gn_time_gemm_bwd_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p,
-                                        c_p, c_i64, c_i, c_p, c_f, c_p, c_p, c_p, c_p]),
+                                        c_p, c_i64, c_i, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p]),
     "gode_wgrad_parts": (c_i64, [c_i64]),
     "gode_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
                              c_p, c_i64, c_i, c_p, c_p]),

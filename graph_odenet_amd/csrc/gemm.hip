@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ W, int has_time,
                                                              const float* __restrict__ dS, float out_scale,
-                                                             float* __restrict__ dx,
+                                                             LinComb pre, float* __restrict__ dx,
                                                              float* __restrict__ dgamma_part,
                                                              float* __restrict__ dbeta_part)
 {
@@ -422,9 +422,14 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                 out = make_float4(rstd.x * gm.x * dy.x + c2.x * x.x + c3.x, rstd.y * gm.y * dy.y + c2.y * x.y + c3.y,
                                   rstd.z * gm.z * dy.z + c2.z * x.z + c3.z, rstd.w * gm.w * dy.w + c2.w * x.w + c3.w);
             }
-            if (valid)
-                *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) =
-                    make_float4(out_scale * out.x, out_scale * out.y, out_scale * out.z, out_scale * out.w);
+            if (valid) {
+                float4 o = make_float4(out_scale * out.x, out_scale * out.y, out_scale * out.z, out_scale * out.w);
+                if (pre.n > 0) {     // fused RK solution combine of the adjoint component
+                    const float4 pv = lc_load4(pre, (int64_t)row * D + c0);
+                    o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+                }
+                *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) = o;
+            }
         }
     }
     if (CG != 0 && dgamma_part) {
@@ -636,8 +641,8 @@ __global__ __launch_bounds__(256) void gn_gemm_fwd_generic(LinComb xin, int n_ro
 
 __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_rows, int d_in, int groups, float eps,
                                                            const float* gamma, const float* W, int d_out,
-                                                           int has_time, const float* dS, float out_scale, float* dx,
-                                                           float* dgamma_part, float* dbeta_part)
+                                                           int has_time, const float* dS, float out_scale, LinComb pre,
+                                                           float* dx, float* dgamma_part, float* dbeta_part)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                       // raw x  [RB][d_in]
@@ -681,7 +686,8 @@ __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_ro
                 const float sc = 1.0f / cg;
                 const float c2 = (bsum * m - dsum) * rs * rs * rs * sc;
                 const float c3 = -c2 * m - bsum * rs * sc;
-                dx[(int64_t)row * d_in + c] = out_scale * (rs * (gamma ? gamma[c] : 1.f) * dy[idx] + c2 * xs[idx] + c3);
+                dx[(int64_t)row * d_in + c] = out_scale * (rs * (gamma ? gamma[c] : 1.f) * dy[idx] + c2 * xs[idx] + c3) +
+                                              (pre.n > 0 ? lc_load1(pre, (int64_t)row * d_in + c) : 0.f);
             }
             if (dgamma_part) {
                 // per-block partial over the block's rows (accumulated across the grid-stride loop)
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_ro
             for (int idx = threadIdx.x; idx < RB * d_in; idx += 256) {
                 const int rr = idx / d_in, c = idx % d_in;
                 const int row = blk * RB + rr;
-                if (row < n_rows) dx[(int64_t)row * d_in + c] = out_scale * dy[idx];
+                if (row < n_rows) dx[(int64_t)row * d_in + c] = out_scale * dy[idx] + (pre.n > 0 ? lc_load1(pre, (int64_t)row * d_in + c) : 0.f);
             }
         }
     }
@@ -850,16 +856,19 @@ extern "C" int64_t gode_gemm_bwd_parts(int64_t n_rows) {
 
 extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d_in, int32_t groups,
                                          float eps, const float* gamma, const float* W, int64_t d_out,
-                                         int has_time, const float* dS, float out_scale, float* dx,
+                                         int has_time, const float* dS, float out_scale,
+                                         const gode_lincomb_t* pre, float* dx,
                                          float* dgamma_part, float* dbeta_part, void* stream)
 {
     int rc = check_common(xin, n_rows, d_in, groups, d_out); if (rc) return rc;
     if (n_rows == 0) return 0;
     if (!W || !dS || !dx) return GODE_E_NULLPTR;
     if ((dgamma_part == nullptr) != (dbeta_part == nullptr)) return GODE_E_NULLPTR;
+    if (pre && pre->n > 0) { rc = check_lincomb(pre, true); if (rc) return rc; } else pre = nullptr;
     has_time = has_time ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     LinComb lc = make_lincomb(xin);
+    LinComb lpre = make_lincomb(pre);
     const int64_t n_part = gode_gemm_bwd_parts(n_rows);
     if (dgamma_part && groups > 0) {
         hipError_t e = hipMemsetAsync(dgamma_part, 0, (size_t)n_part * d_in * sizeof(float), s);
@@ -868,7 +877,7 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
         if (e != hipSuccess) return (int)e;
     }
     const int cg = fast_cg(d_in, d_out, groups);
-    const bool al = lincomb_aligned16(xin) && !(((uintptr_t)dS) & 15) && !(((uintptr_t)dx) & 15) &&
+    const bool al = lincomb_aligned16(xin) && lincomb_aligned16(pre) && !(((uintptr_t)dS) & 15) && !(((uintptr_t)dx) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) &&
                     (!dgamma_part || (!(((uintptr_t)dgamma_part) & 15) && !(((uintptr_t)dbeta_part) & 15)));
     if (cg >= 0 && al) {
@@ -879,7 +888,7 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
 #define GODE_BWD(NJV, CGV)                                                                          \
         { rc = set_lds(gn_gemm_bwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
           hipLaunchKernelGGL((gn_gemm_bwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
-                             lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, dx, dgamma_part, dbeta_part); \
+                             lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part); \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_BWD)
 #undef GODE_BWD
@@ -889,7 +898,7 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
     rc = set_lds(gn_gemm_bwd_generic, lds); if (rc) return rc;
     int64_t blocks = (n_rows + RB - 1) / RB; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gn_gemm_bwd_generic, dim3((unsigned)blocks), dim3(256), lds, s, lc, (int)n_rows, (int)d_in,
-                       (int)groups, eps, gamma, W, (int)d_out, has_time, dS, out_scale, dx, dgamma_part, dbeta_part);
+                       (int)groups, eps, gamma, W, (int)d_out, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part);
     GODE_LAUNCH_CHECK();
     return 0;
 }

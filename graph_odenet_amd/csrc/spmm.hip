@@ -21,6 +21,8 @@ namespace {
 struct Epilogue {
     const float* bias;
     int relu;
+    float alpha;     // Y = (sum pre) + alpha * act(Z + bias)
+    LinComb pre;     // n == 0: Y = alpha * act(Z + bias)
     LinComb cot;
     float* Y2;
 };
@@ -34,6 +36,13 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& ep, float4 z, in
     }
     float4 y = z;
     if (ep.relu) { y.x = fmaxf(z.x, 0.f); y.y = fmaxf(z.y, 0.f); y.z = fmaxf(z.z, 0.f); y.w = fmaxf(z.w, 0.f); }
+    if (ep.pre.n > 0) {          // fused RK solution combine: rows of the pre-terms have ld = d
+        const float4 p = lc_load4(ep.pre, (int64_t)row * d + lane * 4);
+        y.x = fmaf(ep.alpha, y.x, p.x); y.y = fmaf(ep.alpha, y.y, p.y);
+        y.z = fmaf(ep.alpha, y.z, p.z); y.w = fmaf(ep.alpha, y.w, p.w);
+    } else if (ep.alpha != 1.f) {
+        y.x *= ep.alpha; y.y *= ep.alpha; y.z *= ep.alpha; y.w *= ep.alpha;
+    }
     *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + lane * 4) = y;
     if (ep.Y2) {
         const int64_t o = (int64_t)row * d + lane * 4;
@@ -131,7 +140,10 @@ __global__ __launch_bounds__(256) void spmm_finish_vec4_kernel(
 __device__ __forceinline__ void epilogue_store1(const Epilogue& ep, float z, int row, int c, int64_t d,
                                                 float* Y, int64_t ldy) {
     if (ep.bias) z += ep.bias[c];
-    Y[(int64_t)row * ldy + c] = ep.relu ? fmaxf(z, 0.f) : z;
+    float y = ep.relu ? fmaxf(z, 0.f) : z;
+    if (ep.pre.n > 0) y = fmaf(ep.alpha, y, lc_load1(ep.pre, (int64_t)row * d + c));
+    else y *= ep.alpha;
+    Y[(int64_t)row * ldy + c] = y;
     if (ep.Y2) {
         const int64_t o = (int64_t)row * d + c;
         const float g = lc_load1(ep.cot, o);
@@ -207,8 +219,7 @@ extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
                                  const int32_t* long_rows, int64_t n_long, float* partial,
                                  const float* X, int64_t ldx, float* Y, int64_t ldy,
                                  int64_t n_rows, int64_t d,
-                                 const float* bias, int relu,
-                                 const gode_lincomb_t* cot, float* Y2, void* stream)
+                                 const gode_spmm_epilogue_t* epi, void* stream)
 {
     if (n_rows < 0 || d <= 0 || ldx < d || ldy < d) return GODE_E_SHAPE;
     if (n_rows == 0) return 0;
@@ -217,15 +228,21 @@ extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
     if (!items) { n_items = n_rows; n_long = 0; }
     if (n_items < 0 || n_items > INT32_MAX || n_long < 0 || n_long > INT32_MAX) return GODE_E_RANGE;
     if (n_long > 0 && (!long_rows || !partial)) return GODE_E_NULLPTR;
+    const float* bias = epi ? epi->bias : nullptr;
+    float* Y2 = epi ? epi->Y2 : nullptr;
+    const gode_lincomb_t* cot = (epi && Y2) ? &epi->cot : nullptr;
+    const gode_lincomb_t* pre = (epi && epi->pre.n > 0) ? &epi->pre : nullptr;
     if (Y2) { int rc = check_lincomb(cot, true); if (rc) return rc; }
+    if (pre) { int rc = check_lincomb(pre, true); if (rc) return rc; }
     hipStream_t s = (hipStream_t)stream;
 
     Epilogue ep;
-    ep.bias = bias; ep.relu = relu; ep.cot = make_lincomb(Y2 ? cot : nullptr); ep.Y2 = Y2;
+    ep.bias = bias; ep.relu = epi ? epi->relu : 0; ep.alpha = epi ? epi->alpha : 1.f;
+    ep.pre = make_lincomb(pre); ep.cot = make_lincomb(cot); ep.Y2 = Y2;
 
     const bool al = !(((uintptr_t)X) & 15) && !(((uintptr_t)Y) & 15) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
                     (!bias || !(((uintptr_t)bias) & 15)) && (!partial || !(((uintptr_t)partial) & 15)) &&
-                    (!Y2 || (!(((uintptr_t)Y2) & 15) && lincomb_aligned16(cot)));
+                    (!Y2 || (!(((uintptr_t)Y2) & 15) && lincomb_aligned16(cot))) && lincomb_aligned16(pre);
     const int4* it4 = reinterpret_cast<const int4*>(items);
     const int4* lr4 = reinterpret_cast<const int4*>(long_rows);
     if (al && d % 4 == 0) {

@@ -60,6 +60,13 @@ class GcnOdeField(Field):
         ops.gn_time_gemm(terms[0], w.n, s.d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
         ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0])
 
+    def eval_combine(self, t, terms, pre, coef, out):
+        """Last RK stage: out[0] = (sum pre[0]) + coef * f(t, sum terms[0]) without materialising f."""
+        s, w = self.s, self.w
+        ops.gn_time_gemm(terms[0], w.n, s.d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
+        ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0], pre_terms=pre[0], alpha=coef)
+        return (0,)
+
 
 class GcnOdeAdjointField(Field):
     """Components: [y, a, a_t, W, b, gamma, beta] (b may be absent -> never, FixedGC always has bias here)."""
@@ -82,6 +89,15 @@ class GcnOdeAdjointField(Field):
         return [m[k] for k in self.params_order]
 
     def eval(self, t, terms, out):
+        self._stage(t, terms, out, None, 0.0)
+
+    def eval_combine(self, t, terms, pre, coef, out):
+        """Last RK stage: the new y and a are written by the producing launches (SpMM epilogue / GEMM-VJP
+        epilogue); the small components get their k in `out` and are combined by the caller."""
+        self._stage(t, terms, out, pre, coef)
+        return (0, 1)
+
+    def _stage(self, t, terms, out, pre, coef):
         s, w = self.s, self.w
         dZ, dS = w.bwd()
         n, d = w.n, s.d
@@ -89,10 +105,12 @@ class GcnOdeAdjointField(Field):
         ops.gn_time_gemm(y_terms, n, d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
         # k_y = relu(A S + b);  dZ = (-a) * mask
         ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0],
-                 cot_terms=[(-c, x) for (c, x) in terms[1]], out2=dZ)
+                 cot_terms=[(-c, x) for (c, x) in terms[1]], out2=dZ,
+                 pre_terms=pre[0] if pre is not None else None, alpha=coef if pre is not None else 1.0)
         ops.spmm(s.graph.transpose(), dZ, out=dS)                       # dS = A^T dZ
         _, dgp, dbp = ops.gn_time_gemm_bwd(y_terms, n, d, s.groups, s.eps, s.gamma, s.W, True, dS,
-                                           out_scale=1.0, out=out[1])   # k_a = -a^T df/dy
+                                           out_scale=coef if pre is not None else 1.0, out=out[1],
+                                           pre_terms=pre[1] if pre is not None else None)   # k_a = -a^T df/dy
         part = ops.wgrad(y_terms, n, d, s.groups, s.eps, s.gamma, s.beta, dS, True)
         ops.reduce_parts_(out[3].view(-1), part)                        # row 0 = colsum(dS)
         out[2].copy_((out[3][0] * s.W[0]).sum().reshape(1))             # a_t' = -a^T df/dt

@@ -117,12 +117,12 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     method = _method(method)
     fwd, _, _ = _fields(func, y0)
     stats = Dopri5Stats()
-    y = y0.detach().contiguous().clone()
-    outs = [y.clone()]
+    ys = [y0.detach().contiguous().clone()]
+    outs = [ys[0].clone()]
     with torch.no_grad():
         for i in range(1, len(tl)):
-            _integrate(fwd, [y], tl[i - 1], tl[i], rtol, atol, method, options, stats)
-            outs.append(y.clone())
+            _integrate(fwd, ys, tl[i - 1], tl[i], rtol, atol, method, options, stats)
+            outs.append(ys[0].clone())
     _bump_nfe(func, stats.nfe if getattr(fwd, "fused", False) else 0)
     return torch.stack(outs)
 
@@ -132,11 +132,11 @@ class _OdeintAdjoint(torch.autograd.Function):
     def forward(ctx, func, tl, rtol, atol, method, options, y0, *params):
         fwd, mk_adj, plist = _fields(func, y0)
         stats = Dopri5Stats()
-        y = y0.detach().contiguous().clone()
-        outs = [y.clone()]
+        ys = [y0.detach().contiguous().clone()]
+        outs = [ys[0].clone()]
         for i in range(1, len(tl)):
-            _integrate(fwd, [y], tl[i - 1], tl[i], rtol, atol, method, options, stats)
-            outs.append(y.clone())
+            _integrate(fwd, ys, tl[i - 1], tl[i], rtol, atol, method, options, stats)
+            outs.append(ys[0].clone())
         _bump_nfe(func, stats.nfe if getattr(fwd, "fused", False) else 0)
         ans = torch.stack(outs)
         ctx.func, ctx.tl, ctx.rtol, ctx.atol, ctx.method, ctx.options = func, tl, rtol, atol, method, options

@@ -34,8 +34,8 @@ def _need_terms(terms, name):
     return n
 
 
-def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None):
-    """Y = relu?(A @ X + bias); optionally out2 = (sum cot_terms) * (A@X+bias > 0)."""
+def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None, pre_terms=None, alpha=1.0):
+    """Y = (sum pre_terms) + alpha * relu?(A @ X + bias); optionally out2 = (sum cot_terms) * (A@X+bias > 0)."""
     lib = _lib.load()
     _need(X, "X")
     _need(bias, "bias")
@@ -50,22 +50,30 @@ def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None):
         _need(out, "out")
         if tuple(out.shape) != (graph.n_rows, d):
             raise ValueError("spmm: out has wrong shape")
-    lc = None
-    if cot_terms is not None:
-        if _need_terms(cot_terms, "cot") != graph.n_rows * d:
-            raise ValueError("spmm: cotangent terms have wrong size")
-        lc = lincomb(cot_terms)
-        if out2 is None:
-            out2 = torch.empty(graph.n_rows, d, dtype=torch.float32, device=X.device)
-        _need(out2, "out2")
+    ep = None
+    if bias is not None or relu or cot_terms is not None or pre_terms is not None or alpha != 1.0:
+        ep = _lib.SpmmEpilogue()
+        ep.bias = bias.data_ptr() if bias is not None else None
+        ep.relu = 1 if relu else 0
+        ep.alpha = float(alpha)
+        if pre_terms is not None:
+            if _need_terms(pre_terms, "pre") != graph.n_rows * d:
+                raise ValueError("spmm: pre terms have wrong size")
+            ep.pre = lincomb(pre_terms)
+        if cot_terms is not None:
+            if _need_terms(cot_terms, "cot") != graph.n_rows * d:
+                raise ValueError("spmm: cotangent terms have wrong size")
+            ep.cot = lincomb(cot_terms)
+            if out2 is None:
+                out2 = torch.empty(graph.n_rows, d, dtype=torch.float32, device=X.device)
+            _need(out2, "out2")
+            ep.Y2 = out2.data_ptr()
     partial = graph.partial(d)
     rc = lib.gode_spmm_csr_f32(ptr(graph.rowptr), ptr(graph.col), ptr(graph.val),
                                ptr(graph.items), graph.n_items,
                                ptr(graph.long_rows), graph.n_long, ptr(partial),
                                ptr(X), d, ptr(out), d, graph.n_rows, d,
-                               ptr(bias), 1 if relu else 0,
-                               ctypes.byref(lc) if lc is not None else None, ptr(out2) if lc is not None else None,
-                               stream_ptr())
+                               ctypes.byref(ep) if ep is not None else None, stream_ptr())
     check(rc, "gode_spmm_csr_f32")
     return (out, out2) if cot_terms is not None else out
 
@@ -144,8 +152,9 @@ def gn_time_gemm(x_terms, n_rows, d_in, groups, eps, gamma, beta, W, has_time, t
 
 
 def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS, out_scale=1.0, out=None,
-                     want_affine_grads=True):
-    """Returns (dx, dgamma_part, dbeta_part); parts are [n_part, d_in] block partials (or None)."""
+                     want_affine_grads=True, pre_terms=None):
+    """Returns (dx, dgamma_part, dbeta_part); parts are [n_part, d_in] block partials (or None).
+    With pre_terms the first output is (sum pre_terms) + out_scale * dx."""
     lib = _lib.load()
     _need(W, "W"); _need(gamma, "gamma"); _need(dS, "dS")
     if _need_terms(x_terms, "x") != n_rows * d_in:
@@ -160,8 +169,14 @@ def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS,
         dg = torch.empty(n_part, d_in, dtype=torch.float32, device=W.device)
         db = torch.empty(n_part, d_in, dtype=torch.float32, device=W.device)
     lc = lincomb(x_terms)
+    pre = None
+    if pre_terms is not None:
+        if _need_terms(pre_terms, "pre") != n_rows * d_in:
+            raise ValueError("gn_time_gemm_bwd: pre terms have wrong size")
+        pre = lincomb(pre_terms)
     check(lib.gode_gn_time_gemm_bwd_f32(ctypes.byref(lc), n_rows, d_in, groups, float(eps), ptr(gamma), ptr(W),
-                                        d_out, 1 if has_time else 0, ptr(dS), float(out_scale), ptr(out),
+                                        d_out, 1 if has_time else 0, ptr(dS), float(out_scale),
+                                        ctypes.byref(pre) if pre is not None else None, ptr(out),
                                         ptr(dg), ptr(db), stream_ptr()), "gode_gn_time_gemm_bwd_f32")
     return out, dg, db
 

@@ -89,17 +89,32 @@ def uniform_grid(t0, t1, step_size):
 
 
 def integrate_rk4(field, y, t0, t1, n_steps, work=None):
-    """In-place 3/8-rule integration of the component list y from t0 to t1. Returns nfe."""
+    """3/8-rule integration of the component list y from t0 to t1.  Returns nfe.
+
+    The entries of the list `y` hold the result on return; they may have been re-bound to other
+    buffers (a fused field writes y + h*sum(b_i k_i) straight from the launch that produces the last
+    stage and the solution / stage buffers swap roles), so callers read `y[c]` afterwards."""
     ks = work if work is not None else _alloc_like(y, 4)
     h = (t1 - t0) / n_steps
     nfe = 0
+    nc = len(y)
+    fused = getattr(field, "eval_combine", None)
     for i in range(n_steps):
         t = t0 + i * h
-        for s in range(4):
+        for s in range(3):
             field.eval(t + RK38_C[s] * h, _stage_terms(y, ks, RK38_A[s], h), ks[s])
-            nfe += 1
-        for c in range(len(y)):
-            ops.lincomb_(y[c], [(1.0, y[c])] + [(h * RK38_B[s], ks[s][c]) for s in range(4)])
+        done = ()
+        if fused is not None:
+            pre = [[(1.0, y[c])] + [(h * RK38_B[s], ks[s][c]) for s in range(3)] for c in range(nc)]
+            done = fused(t + RK38_C[3] * h, _stage_terms(y, ks, RK38_A[3], h), pre, h * RK38_B[3], ks[3])
+        else:
+            field.eval(t + RK38_C[3] * h, _stage_terms(y, ks, RK38_A[3], h), ks[3])
+        nfe += 4
+        for c in range(nc):
+            if c in done:
+                y[c], ks[3][c] = ks[3][c], y[c]        # ks[3][c] already holds the new solution
+            else:
+                ops.lincomb_(y[c], [(1.0, y[c])] + [(h * RK38_B[s], ks[s][c]) for s in range(4)])
     return nfe
 
 

@@ -57,9 +57,12 @@ int         gode_abi_version(void);
 const char* gode_error_string(int code);   /* host string, static storage */
 
 /* ---- sparse aggregation -------------------------------------------------
- * Z = A * X (+ bias);  Y = relu ? max(Z,0) : Z
+ * Z = A * X (+ bias);  Y = (sum_j pre.coef[j]*pre.ptr[j]) + alpha * (relu ? max(Z,0) : Z)
+ *   (pre.n == 0: no pre-term; used to fold the Runge-Kutta solution combine
+ *    y + h*sum(b_i k_i) into the launch that produces the last stage k_s);
  * optional second output  Y2 = (sum_j cot.coef[j]*cot.ptr[j]) * (Z > 0)
- * (the relu-masked cotangent the adjoint pass needs; cot rows have ld = d).
+ *   (the relu-masked cotangent the adjoint pass needs).  pre / cot rows have ld = d.
+ * epi == NULL: Y = Z.
  *
  * A is CSR (rowptr[n_rows+1], col[nnz], val[nnz] or NULL = all ones).
  * `items` (nullable) is the nnz-balanced work list built once per graph by
@@ -70,13 +73,21 @@ const char* gode_error_string(int code);   /* host string, static storage */
  * records of 4 int32 {row, first_slot, last_slot_exclusive, 0}.
  * With items == NULL every row is one record (n_items ignored).
  */
+typedef struct gode_spmm_epilogue {
+    const float*   bias;    /* nullable, [d] */
+    int32_t        relu;
+    float          alpha;   /* 1 for a plain product */
+    gode_lincomb_t pre;     /* host-side struct; n == 0 = absent */
+    gode_lincomb_t cot;     /* used when Y2 != NULL */
+    float*         Y2;      /* nullable */
+} gode_spmm_epilogue_t;
+
 int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                       const int32_t* items, int64_t n_items,
                       const int32_t* long_rows, int64_t n_long, float* partial,
                       const float* X, int64_t ldx, float* Y, int64_t ldy,
                       int64_t n_rows, int64_t d,
-                      const float* bias, int relu,
-                      const gode_lincomb_t* cot /* host, nullable */, float* Y2,
+                      const gode_spmm_epilogue_t* epi /* host, nullable */,
                       void* stream);
 
 /* ---- Runge-Kutta elementwise steps -------------------------------------- */
@@ -109,7 +120,8 @@ int gode_gn_time_gemm_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, 
                           float* S, void* stream);
 
 /* VJP of the above w.r.t. x:  dxn = dS * W[has_time:,:]^T ; dx = GroupNorm'(x)^T dxn
- * out[i,:] = out_scale * dx[i,:]   (out_scale = 1 for a plain VJP).
+ * out[i,:] = (sum_j pre.coef[j]*pre.ptr[j][i,:]) + out_scale * dx[i,:]
+ *   (out_scale = 1, pre = NULL for a plain VJP; pre folds the RK combine of the adjoint state).
  * Also accumulates (when non-NULL) the per-row reductions needed for the
  * parameter gradients into fp32 buffers of block partials:
  *   dgamma_part/dbeta_part : [n_part][d_in]   (n_part = gode_gemm_bwd_parts(n_rows))
@@ -118,7 +130,8 @@ int64_t gode_gemm_bwd_parts(int64_t n_rows);
 int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d_in,
                               int32_t groups, float eps, const float* gamma,
                               const float* W, int64_t d_out, int has_time,
-                              const float* dS, float out_scale, float* dx,
+                              const float* dS, float out_scale,
+                              const gode_lincomb_t* pre /* host, nullable */, float* dx,
                               float* dgamma_part, float* dbeta_part, void* stream);
 
 /* dW = [1 | xn]^T * dS  ((d_in+has_time) x d_out) as n_part block partials

@@ -37,7 +37,5 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     assert lib.gode_lincomb_f32(None, None, -1, None) == -2        # GODE_E_SHAPE
     assert lib.gode_lincomb_f32(None, None, 4, None) == -1         # GODE_E_NULLPTR
-    assert lib.gode_spmm_csr_f32(None, None, None, None, 0, None, 0, None, None, 4, None, 4, 3, 8,
-                                 None, 0, None, None, None) == -2  # ldx < d
-    assert lib.gode_spmm_csr_f32(None, None, None, None, 0, None, 0, None, None, 8, None, 8, 3, 8,
-                                 None, 0, None, None, None) == -1  # null pointers
+    assert lib.gode_spmm_csr_f32(None, None, None, None, 0, None, 0, None, None, 4, None, 4, 3, 8, None, None) == -2  # ldx < d
+    assert lib.gode_spmm_csr_f32(None, None, None, None, 0, None, 0, None, None, 8, None, 8, 3, 8, None, None) == -1  # null pointers
