@@ -1,0 +1,73 @@
+"""Differentiable building blocks over the C ABI (torch.autograd.Function wrappers).
+
+    gn_time_linear(x, t, W, gamma, beta, groups, eps)   S = [t | GroupNorm(x)] @ W     (GCN/models.py:175-177 + layers.py:70)
+    graph_aggregate(graph, S, bias, relu)                relu?(A @ S + bias)             (GCN/layers.py:71-75, models.py:178)
+
+Used by modules that are not covered by a fused ODE field (ODEfunc2, stand-alone calls).
+"""
+import torch
+
+from . import ops
+
+
+class _GnTimeLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, W, gamma, beta, groups, eps, has_time):
+        x = x.contiguous()
+        n, d = x.shape
+        S = ops.gn_time_gemm([(1.0, x)], n, d, groups, eps, gamma, beta, W, has_time, t)
+        ctx.meta = (t, groups, eps, has_time)
+        ctx.has_affine = gamma is not None
+        ctx.save_for_backward(x, W, gamma, beta)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        x, W, gamma, beta = ctx.saved_tensors
+        t, groups, eps, has_time = ctx.meta
+        n, d = x.shape
+        dS = dS.contiguous()
+        dx, dgp, dbp = ops.gn_time_gemm_bwd([(1.0, x)], n, d, groups, eps, gamma, W, has_time, dS,
+                                            want_affine_grads=ctx.has_affine)
+        part = ops.wgrad([(1.0, x)], n, d, groups, eps, gamma, beta, dS, has_time)
+        gW = torch.empty_like(W)
+        ops.reduce_parts_(gW.view(-1), part)
+        if has_time:
+            gW[0].mul_(t)
+        gg = gb = None
+        if ctx.has_affine and dgp is not None:
+            gg = torch.empty_like(gamma)
+            gb = torch.empty_like(beta)
+            ops.reduce_parts_(gg, dgp)
+            ops.reduce_parts_(gb, dbp)
+        return dx, None, gW, gg, gb, None, None, None
+
+
+def gn_time_linear(x, t, W, gamma=None, beta=None, groups=0, eps=1e-5, has_time=True):
+    return _GnTimeLinearFn.apply(x, float(t), W, gamma, beta, int(groups), float(eps), bool(has_time))
+
+
+class _GraphAggregateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph, S, bias, relu):
+        S = S.contiguous()
+        out = ops.spmm(graph, S, bias=bias, relu=relu)
+        ctx.graph, ctx.relu, ctx.has_bias = graph, relu, bias is not None
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = g.contiguous()
+        dZ = g * (out > 0).to(g.dtype) if ctx.relu else g
+        dS = ops.spmm(ctx.graph.transpose(), dZ)
+        gb = None
+        if ctx.has_bias:
+            gb = torch.empty(out.shape[1], dtype=torch.float32, device=out.device)
+            ops.colsum_(gb, dZ)
+        return None, dS, gb, None
+
+
+def graph_aggregate(graph, S, bias=None, relu=False):
+    return _GraphAggregateFn.apply(graph, S, bias, bool(relu))

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .functional import gn_time_linear, graph_aggregate
 from .gcn_ode import GcnOdeAdjointField, GcnOdeField, GcnOdeSpec, _Shared, odefunc_apply
 from .graph import as_graph
 from .layers import FixedGraphConvolution, GraphConvolution
@@ -238,3 +239,101 @@ class ODEGCN3fullnorm(nn.Module):
     @nfe.setter
     def nfe(self, value):
         self.gc2.nfe = value
+
+
+class ODEfunc2(nn.Module):
+    """GCN/models.py:551-575: two stacked (FixedGC -> relu -> GroupNorm) with the time column re-attached
+    before each graph convolution.  The first GroupNorm is folded into the prologue of the second
+    dense product; the trailing one has no consumer inside f and stays a PyTorch op."""
+
+    def __init__(self, dim, dropout):
+        super(ODEfunc2, self).__init__()
+        self.norm1 = nn.GroupNorm(min(32, dim), dim)
+        self.norm2 = nn.GroupNorm(min(32, dim), dim)
+        self.gc1 = FixedGraphConvolution(dim + 1, dim)
+        self.gc2 = FixedGraphConvolution(dim + 1, dim)
+        self.dropout = dropout
+        self.nfe = 0
+
+    def set_adj(self, adj):
+        self.gc1.set_adj(adj)
+        self.gc2.set_adj(adj)
+
+    def forward(self, t, x):
+        self.nfe += 1
+        g = as_graph(self.gc1.adj)
+        s1 = gn_time_linear(x, float(t), self.gc1.weight)                          # [t | x] W1
+        h1 = graph_aggregate(g, s1, self.gc1.bias, relu=True)                      # relu(A . + b1)
+        s2 = gn_time_linear(h1, float(t), self.gc2.weight, self.norm1.weight, self.norm1.bias,
+                            self.norm1.num_groups, self.norm1.eps)                 # [t | norm1(h1)] W2
+        h2 = graph_aggregate(as_graph(self.gc2.adj), s2, self.gc2.bias, relu=True)
+        return self.norm2(h2)
+
+
+class GCNK(nn.Module):
+    """GCN/models.py:255-278."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=2):
+        super(GCNK, self).__init__()
+        if nlayers < 2:
+            raise ValueError("Can't make a GCN with less than 2 layers")
+        self.n_layers = nlayers
+        self.gcs = nn.ModuleList([GraphConvolution(nfeat, nhid)] +
+                                 [GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)] +
+                                 [GraphConvolution(nhid, nclass)])
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        for gc in self.gcs[:-1]:
+            x = F.relu(gc(x, adj))
+            x = F.dropout(x, self.dropout, training=self.training)
+        x = self.gcs[-1](x, adj)
+        return F.log_softmax(x, dim=1)
+
+
+class ODEK1(nn.Module):
+    """GCN/models.py:524-548: first layer, (nlayers-2) ODE blocks, last layer."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=3, method=None, step_size=None):
+        super(ODEK1, self).__init__()
+        if nlayers < 3:
+            raise ValueError("Can't make a Residual GCN with less than 3 layers")
+        self.n_layers = nlayers
+        self.gcs = nn.ModuleList([GraphConvolution(nfeat, nhid)] +
+                                 [ODEBlock(ODEfunc(nhid), method=method, step_size=step_size) for _ in range(nlayers - 2)] +
+                                 [GraphConvolution(nhid, nclass)])
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gcs[0](x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        for gc in self.gcs[1:-1]:
+            x = gc(x, adj)
+        x = self.gcs[-1](x, adj)
+        return F.log_softmax(x, dim=1)
+
+
+class ODEK2(nn.Module):
+    """GCN/models.py:577-600.  Quirk Q1 of SURVEY.md is reproduced on purpose: the reference passes
+    `dropout` as the ODEBlock tolerance (`ODEBlock(ODEfunc2(nhid, dropout), dropout)`, :587)."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=4, method=None, step_size=None):
+        super(ODEK2, self).__init__()
+        if nlayers < 4:
+            raise ValueError("Can't make a Residual GCN with less than 4 layers using 2 layers for each residual block")
+        self.n_layers = nlayers
+        self.gcs = nn.ModuleList(
+            [GraphConvolution(nfeat, nhid)] +
+            [ODEBlock(ODEfunc2(nhid, dropout), dropout, method=method, step_size=step_size)
+             for _ in range((nlayers - 2) // 2)] +
+            ([ODEBlock(ODEfunc(nhid), method=method, step_size=step_size)] if nlayers % 2 == 1 else []) +
+            [GraphConvolution(nhid, nclass)])
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.relu(self.gcs[0](x, adj))
+        x = F.dropout(x, self.dropout, training=self.training)
+        for gc in self.gcs[1:-1]:
+            x = gc(x, adj)
+        x = self.gcs[-1](x, adj)
+        return F.log_softmax(x, dim=1)

@@ -12,6 +12,7 @@ What is captured (inputs AND expected outputs, fp32):
   gat_odefunc.npz    GAT ODEfunc fwd + VJP                                   (GAT/models.py:161-179)
   qc_layers.npz      MPNN_enn_edge (T=1,3) and EdgeGraphConvolution fwd + grads (QC/mpnn.py, QC/layers.py)
   scatter_kat.npz    the scatter_add docstring known-answer vector           (QC/torch_scatter.py:207-218)
+  pubmed_graph_sym.npz  Pubmed topology, D^-1/2 (A+I) D^-1/2                 (GCN-dense-paper/utils.py:70-110)
 
 `torchdiffeq` is absent from the image; an EMPTY stand-in module object is registered so
 that `models.py` imports.  No solver is ever called through it (parity at the solver
@@ -233,5 +234,35 @@ def main():
          out=np.array([[0, 0, 4, 3, 3, 0], [2, 4, 4, 0, 0, 0]], dtype=np.float32))
 
 
+def pubmed_topology():
+    """C2: Pubmed's real topology through the dense-paper normalisation
+    (GCN-dense-paper/utils.py:70-110: normalize_adj(adj + I)).  Features are absent from the reference
+    checkout (`.MISSING_LARGE_BLOBS`), so only the graph is captured."""
+    import pickle as pkl
+    import networkx as nx
+    import scipy.sparse as sp
+    sys.path.insert(0, os.path.join(REF, "GCN-dense-paper"))
+    for n in ("utils",):
+        sys.modules.pop(n, None)
+    utils = importlib.import_module("utils")
+    sys.path.pop(0)
+    with open(os.path.join(REF, "data", "ind.pubmed.graph"), "rb") as f:
+        graph = pkl.load(f, encoding="latin1")
+    adj = nx.adjacency_matrix(nx.from_dict_of_lists(graph))
+    adj = utils.normalize_adj(adj + sp.eye(adj.shape[0])).tocoo().astype(np.float32)
+    save("pubmed_graph_sym.npz", rows=adj.row.astype(np.int32), cols=adj.col.astype(np.int32), vals=adj.data,
+         n=adj.shape[0])
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("GOLDEN_ONLY") == "pubmed":
+        sys.dont_write_bytecode = True
+        import scipy.sparse.linalg as spla
+        alias = types.ModuleType("scipy.sparse.linalg.eigen.arpack")
+        alias.eigsh = spla.eigsh
+        sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
+        sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
+        pubmed_topology()
+    else:
+        main()
+        pubmed_topology()

@@ -85,6 +85,44 @@ def test_odefunc_fwd_vjp_vs_reference_golden(golden, d):
         close(f.norm1.weight.grad, g["g_gn_w"], 5e-5, "g gamma")
 
 
+def test_odefunc2_fwd_vjp_vs_reference_golden(golden):
+    """A4: ODEfunc2.forward (GCN/models.py:565-575) against the vector captured from the reference class."""
+    from graph_odenet_amd.models import ODEfunc2
+    g = golden("gcn_odefunc2.npz")
+    n, d = int(g["n"]), g["x"].shape[1]
+    f = ODEfunc2(d, 0.5).to(dev())
+    f.load_state_dict({k.replace("__", "."): T(v) for k, v in g.items() if k.startswith(("norm", "gc"))})
+    f.set_adj(coo(g, n).to(dev()))
+    x = T(g["x"]).to(dev()).requires_grad_(True)
+    out = f(torch.tensor(float(g["t"])), x)
+    # d = 64: two channels per group.  x_hat = (a-b)/2 / sqrt((a-b)^2/4 + eps) has slope up to
+    # 1/(2 sqrt(eps)) = 158 where the two relu outputs nearly coincide, and f ENDS with such a norm, so
+    # 1e-7-level input differences surface as ~1e-5..1e-4 in the output (the reference's own property).
+    close(out, g["out"], 2e-4, "odefunc2 fwd")
+    out.backward(T(g["gout"]).to(dev()))
+    close(x.grad, g["gx"], 5e-3, "gx")            # ill-conditioned GroupNorm backward (see test_oracle_golden)
+    close(f.gc2.bias.grad, g["g__gc2__bias"], 5e-3, "g gc2.bias")
+    close(f.gc1.weight.grad, g["g__gc1__weight"], 5e-3, "g gc1.weight")
+
+
+def test_odek_models_run():
+    """ODEK1 / ODEK2 compose the same blocks (GCN/models.py:524-600); ODEK2 reproduces quirk Q1 (tol = dropout)."""
+    from graph_odenet_amd import models
+    torch.manual_seed(0)
+    n = 300
+    r = torch.randint(0, n, (2000,)); c = torch.randint(0, n, (2000,))
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), torch.rand(2000) / 8, (n, n)).to(dev())
+    x = torch.randn(n, 20, device=dev())
+    m1 = models.ODEK1(nfeat=20, nhid=64, nclass=4, dropout=0.0, nlayers=4, method="rk4", step_size=0.25).to(dev())
+    m2 = models.ODEK2(nfeat=20, nhid=64, nclass=4, dropout=0.5, nlayers=5, method="rk4", step_size=0.5).to(dev())
+    assert m2.gcs[1].tol == 0.5
+    for m in (m1, m2):
+        out = m(x, adj)
+        assert out.shape == (n, 4) and torch.isfinite(out).all()
+        out.sum().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
 def cora(golden):
     gr = golden("cora_graph.npz")
     n = int(gr["n"])
@@ -211,6 +249,41 @@ def test_odegcn3_dopri5_vs_oracle_on_cora(golden):
     for k, p in m.named_parameters():
         close(p.grad, ref_g[k], 5e-2, "grad " + k)
     assert 8 <= nfe_f <= 400 and m.nfe >= 8
+
+
+def test_pubmed_dense_paper_dopri5_vs_oracle(golden):
+    """C2: Pubmed's real topology, symmetric normalisation, adjacency passed DENSE as GCN-dense-paper does
+    (utils.py:87), ODEBlock with the reference's default dopri5 (rtol=atol=1e-5), d=16 (--hidden default).
+    Features are synthetic (the reference checkout lacks ind.pubmed.allx): row-normalised sparse Bernoulli,
+    density 10 %, F=500, seed 0."""
+    from graph_odenet_amd import models
+    from oracle import layers_ref as R, solver_ref as S
+    g = golden("pubmed_graph_sym.npz")
+    n = int(g["n"])
+    assert n == 19717 and g["rows"].shape[0] == 108365
+    idx = torch.stack([T(g["rows"].astype(np.int64)), T(g["cols"].astype(np.int64))])
+    adj_sp = torch.sparse_coo_tensor(idx, T(g["vals"]), (n, n))
+    gen = torch.Generator().manual_seed(0)
+    x = (torch.rand(n, 500, generator=gen) < 0.1).float()
+    x = x / x.sum(1, keepdim=True).clamp_min(1)
+    torch.manual_seed(1)
+    m = models.ODEGCN3(nfeat=500, nhid=16, nclass=3, dropout=0.0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+
+    class F(torch.nn.Module):
+        def forward(self, t, h):
+            return R.odefunc(t, h, adj_sp, sd["gc2.odefunc.norm1.weight"], sd["gc2.odefunc.norm1.bias"],
+                             sd["gc2.odefunc.gc1.weight"], sd["gc2.odefunc.gc1.bias"])
+    with torch.no_grad():
+        h = torch.relu(R.graph_convolution(x, adj_sp, sd["gc1.weight"], sd["gc1.bias"]))
+        h = S.odeint(F(), h, torch.tensor([0., 1.]), 1e-5, 1e-5)[1]
+        ref = torch.log_softmax(R.graph_convolution(h, adj_sp, sd["gc3.weight"], sd["gc3.bias"]), 1)
+    m = m.to(dev()).eval()
+    adj_dense = adj_sp.to(dev()).to_dense()          # 19717^2 fp32 = 1.55 GB, as the reference holds it
+    with torch.no_grad():
+        out = m(x.to(dev()), adj_dense)
+    assert m.nfe >= 8
+    close(out, ref, 1e-4, "pubmed dopri5 logits")
 
 
 def test_generic_module_through_solver():
