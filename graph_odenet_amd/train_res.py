@@ -1,0 +1,158 @@
+"""Training harness for the citation graphs with the reference's command line and output format
+(GCN/train_res.py:17-158), on the MI355X path.
+
+    python -m graph_odenet_amd.train_res --model ode3 --dataset cora [--runs N] [--method rk4 --step_size 0.0625]
+
+Same flags, defaults, seeding rule (seed applied only when --runs 1), per-epoch line, `Run #i Test --`
+line and closing summary, so GCN/results/basic/{stats,make_table}.py parse its stdout unchanged.
+Additions: --method/--step_size/--tol for the ODE block, --data_dir for raw Planetoid files (default:
+the loader outputs captured in tests/golden), and, when launched with torch.distributed.run, the
+independent `--runs` are sharded over the ranks (one GPU each; the only collective is the final sum
+of loss / accuracy / time).
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import models
+from .data import load_captured, load_planetoid
+from .parallel import shard_range
+
+MODELS = {"gcn2": models.GCN, "gcn3": models.GCN3, "gcn3norm": models.GCN3, "res3": models.RGCN3,
+          "ode3": models.ODEGCN3, "res3norm": models.RGCN3norm, "res3fullnorm": models.RGCN3fullnorm,
+          "ode3norm": models.ODEGCN3fullnorm}     # "gcn3norm" -> GCN3 as in the reference's model_dict (Q2)
+
+
+def accuracy(output, labels):
+    return (output.max(1)[1] == labels).double().mean()
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--no-cuda', action='store_true', default=False)
+    p.add_argument('--fastmode', action='store_true', default=False)
+    p.add_argument('--seed', type=int, default=42)
+    p.add_argument('--epochs', type=int, default=200)
+    p.add_argument('--runs', type=int, default=1)
+    p.add_argument('--lr', type=float, default=0.01)
+    p.add_argument('--weight_decay', type=float, default=5e-4)
+    p.add_argument('--hidden', type=int, default=16)
+    p.add_argument('--dropout', type=float, default=0.5)
+    p.add_argument('--dataset', choices=["cora", "citeseer", "pubmed"], default="cora")
+    p.add_argument('--model', choices=sorted(MODELS), default="res3")
+    p.add_argument('--method', choices=["dopri5", "rk4"], default=None)
+    p.add_argument('--step_size', type=float, default=None)
+    p.add_argument('--tol', type=float, default=1e-5)
+    p.add_argument('--data_dir', default=None)
+    p.add_argument('--norm', choices=["row", "sym", "sum"], default="row")
+    return p
+
+
+class Trainer:
+    def __init__(self, args, data, device, verbose):
+        self.args, self.verbose, self.device = args, verbose, device
+        self.adj, self.x, self.y, self.itr, self.iva, self.ite = (t.to(device) for t in data)
+        self.is_ode = "ode" in args.model
+
+    def new_model(self):
+        a = self.args
+        kw = dict(nfeat=self.x.shape[1], nhid=a.hidden, nclass=int(self.y.max().item()) + 1, dropout=a.dropout)
+        if self.is_ode:
+            kw.update(method=a.method, step_size=a.step_size, tol=a.tol)
+        model = MODELS[a.model](**kw).to(self.device)
+        opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
+        return model, opt
+
+    def epoch(self, model, opt, ep):
+        t0 = time.time()
+        model.nfe = 0
+        model.train()
+        opt.zero_grad()
+        out = model(self.x, self.adj)
+        nfe_f = model.nfe
+        model.nfe = 0
+        loss = F.nll_loss(out[self.itr], self.y[self.itr])
+        acc = accuracy(out[self.itr], self.y[self.itr])
+        loss.backward()
+        opt.step()
+        nfe_b = model.nfe
+        model.nfe = 0
+        if not self.args.fastmode:
+            model.eval()
+            with torch.no_grad():
+                out = model(self.x, self.adj)
+        lv = F.nll_loss(out[self.iva], self.y[self.iva])
+        av = accuracy(out[self.iva], self.y[self.iva])
+        if self.verbose:
+            print('Epoch: {:04d}'.format(ep + 1), 'loss_train: {:.4f}'.format(loss.item()),
+                  'acc_train: {:.4f}'.format(acc.item()), 'loss_val: {:.4f}'.format(lv.item()),
+                  'acc_val: {:.4f}'.format(av.item()), 'time: {:.4f}s'.format(time.time() - t0),
+                  "" if not self.is_ode else 'nfe_f: {}'.format(nfe_f),
+                  "" if not self.is_ode else 'nfe_b: {}'.format(nfe_b))
+        return lv.item(), av.item()
+
+    def test(self, model):
+        model.eval()
+        with torch.no_grad():
+            out = model(self.x, self.adj)
+        lt = F.nll_loss(out[self.ite], self.y[self.ite]).item()
+        at = accuracy(out[self.ite], self.y[self.ite]).item()
+        if self.verbose:
+            print("Test set results:", "loss= {:.4f}".format(lt), "accuracy= {:.4f}".format(at))
+        return lt, at
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.no_cuda or not torch.cuda.is_available():
+        raise SystemExit("graph_odenet_amd.train_res needs the GPU: the hot path has no CPU implementation")
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.runs == 1:
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+        torch.cuda.manual_seed(args.seed)
+    data = load_planetoid(args.dataset, args.data_dir, args.norm) if args.data_dir else load_captured(args.dataset)
+    tr = Trainer(args, data, device, verbose=(args.runs == 1 and rank == 0))
+    lo, hi = shard_range(args.runs, rank, world)
+    tot = torch.zeros(3, dtype=torch.float64, device=device)
+    model = None
+    for run in range(lo, hi):
+        if args.runs > 1:
+            torch.manual_seed(args.seed + run)          # independent replicas: seed = base + run
+        model, opt = tr.new_model()
+        t0 = time.time()
+        for ep in range(args.epochs):
+            tr.epoch(model, opt, ep)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        lt, at = tr.test(model)
+        if args.runs > 1:
+            print("Run #{run} Test -- time: {time}s acc: {acc:.2f}%".format(run=run, time=dt, acc=100 * at), flush=True)
+        tot += torch.tensor([lt, at, dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tot)
+    tot = (tot / max(args.runs, 1)).tolist()
+    if rank == 0:
+        print("Optimization on dataset \"{dataset}\" Finished!".format(dataset=args.dataset))
+        if model is not None:
+            print("#Parameters: {param_count}".format(param_count=sum(p.numel() for p in model.parameters() if p.requires_grad)))
+        print("Average time elapsed: {:.4f}s".format(tot[2]))
+        print("Test set results:", "avg loss= {:.4f}".format(tot[0]), "avg accuracy= {:.4f}".format(tot[1]))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
