@@ -93,6 +93,8 @@ def _gat_forward(layer, x, src, tgt, Mtgt):
     Wf, ww = layer.f.weight, layer.w.weight                      # (o, 2i), (1, 2i)
     Wcat = torch.cat([Wf[:, :i].t(), Wf[:, i:].t(), ww[:, :i].t(), ww[:, i:].t()], 1)   # i x (2o+2)
     P = torch.mm(x, Wcat)                                        # node-level projections (dense GEMM)
+    if eg.E == 0:                                                # no edges: every node is 0 / eps = 0
+        return torch.zeros(x.shape[0], o, dtype=x.dtype, device=x.device) + 0.0 * P.sum()
     return _EdgeAttentionFn.apply(eg, P, layer.f.bias, layer.w.bias, o, layer.eps)
 
 
