@@ -122,33 +122,15 @@ class GraphConvolution(Module):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
 
 
-class FixedGraphConvolution(Module):
-    """GAT layer with (src, tgt, Mtgt) held as attributes (reference: GAT/layers.py:67-127)."""
+class FixedGraphConvolution(GraphConvolution):
+    """The same layer with (src, tgt, Mtgt) held as attributes (reference: GAT/layers.py:67-127)."""
 
     def __init__(self, in_features, out_features, bias=True, act=F.relu, eps=1e-6):
-        super(FixedGraphConvolution, self).__init__()
-        self.in_features = in_features
-        self.out_features = out_features
-        self.f = nn.Linear(2 * in_features, out_features)
-        self.w = nn.Linear(2 * in_features, 1)
-        self.eps = eps
-        self.act = act
-        self.reset_parameters()
-        self.src = torch.Tensor([[1]])
-        self.tgt = torch.Tensor([[1]])
-        self.Mtgt = torch.Tensor([[1]])
-
-    def reset_parameters(self):
-        nn.init.xavier_uniform_(self.f.weight)
-        nn.init.xavier_uniform_(self.w.weight)
+        super(FixedGraphConvolution, self).__init__(in_features, out_features, bias, act, eps)
+        self.src = self.tgt = self.Mtgt = torch.Tensor([[1]])
 
     def set_adj(self, src, tgt, Mtgt):
-        self.src = src
-        self.tgt = tgt
-        self.Mtgt = Mtgt
+        self.src, self.tgt, self.Mtgt = src, tgt, Mtgt
 
     def forward(self, x):
         return _gat_forward(self, x, self.src, self.tgt, self.Mtgt)
-
-    def __repr__(self):
-        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'

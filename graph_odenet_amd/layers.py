@@ -75,33 +75,16 @@ class GraphConvolution(Module):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
 
 
-class FixedGraphConvolution(Module):
-    """GCN layer with the adjacency held as an attribute so an ODE solver can call f(t, x)
-    (reference: GCN/layers.py:46-83; `adj` is a plain attribute there too, Q3)."""
+class FixedGraphConvolution(GraphConvolution):
+    """The same layer with the adjacency held as a plain attribute, so that an ODE solver can call
+    f(t, x) (reference: GCN/layers.py:46-83; `adj` is not a buffer there either)."""
 
     def __init__(self, in_features, out_features, bias=True):
-        super(FixedGraphConvolution, self).__init__()
-        self.in_features = in_features
-        self.out_features = out_features
-        self.weight = Parameter(torch.empty(in_features, out_features))
-        if bias:
-            self.bias = Parameter(torch.empty(out_features))
-        else:
-            self.register_parameter('bias', None)
-        self.reset_parameters()
+        super(FixedGraphConvolution, self).__init__(in_features, out_features, bias)
         self.adj = torch.Tensor([[1]])
-
-    def reset_parameters(self):
-        stdv = 1. / math.sqrt(self.weight.size(1))
-        self.weight.data.uniform_(-stdv, stdv)
-        if self.bias is not None:
-            self.bias.data.uniform_(-stdv, stdv)
-
-    def forward(self, input):
-        return _GraphConvFn.apply(as_graph(self.adj), input.contiguous(), self.weight, self.bias)
 
     def set_adj(self, adj):
         self.adj = adj
 
-    def __repr__(self):
-        return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
+    def forward(self, input):
+        return GraphConvolution.forward(self, input, self.adj)

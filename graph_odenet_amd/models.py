@@ -1,6 +1,18 @@
-"""Model classes of the reference's GCN family with the same names, constructor kwargs
+"""GCN-family model zoo with the reference's class names, constructor kwargs
 (nfeat=, nhid=, nclass=, dropout=[, nlayers=]), sub-module / state_dict key names and
-forward(x, adj) API (GCN/models.py), built on graph_odenet_amd.layers and our solver.
+forward(x, adj) API (reference: GCN/models.py), built on graph_odenet_amd.layers and our solver.
+
+Design: the reference writes every variant out by hand (22 near-identical classes).  Here a model
+is a short *plan* - a tuple of steps interpreted by `_PlanModel.forward` - so a variant is its
+constructor (which fixes the attribute names the state_dict needs) plus one line of plan:
+
+    ("gc", name)     x = self.<name>(x, *graph)          graph convolution / ODE block
+    ("relu",)        x = relu(x)
+    ("drop",)        x = dropout(x, p=self.dropout, training=self.training)
+    ("norm", name)   x = self.<name>(x)                  GroupNorm
+    ("save",)        r = x                               residual tap
+    ("add",)         x = x + r
+    ("head", n)      x = x[:, :n]                        (ODEGCN2-style truncation)
 
 Extensions (default to the reference's behaviour): ODEBlock(odefunc, tol=1e-5, method=None,
 step_size=None) - method=None is adaptive dopri5 with rtol=atol=tol exactly as
@@ -18,115 +30,63 @@ from .layers import FixedGraphConvolution, GraphConvolution
 from .odeint import odeint_adjoint as odeint
 
 
-class GCN(nn.Module):
-    """GCN/models.py:8-20."""
+def _gn(dim):
+    return nn.GroupNorm(min(32, dim), dim)
 
-    def __init__(self, nfeat, nhid, nclass, dropout):
-        super(GCN, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = GraphConvolution(nhid, nclass)
-        self.dropout = dropout
 
-    def forward(self, x, adj):
-        x = F.relu(self.gc1(x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        x = self.gc2(x, adj)
+class _PlanModel(nn.Module):
+    """Interprets `self.plan`; the trailing log_softmax is common to every reference model."""
+    plan = ()
+    ode_attr = None          # name of the attribute holding the ODEBlock (for the nfe property)
+
+    def run_plan(self, x, graph_args):
+        saved = None
+        for step in self.plan:
+            op = step[0]
+            if op == "gc":
+                x = getattr(self, step[1])(x, *graph_args)
+            elif op == "relu":
+                x = F.relu(x)
+            elif op == "drop":
+                x = F.dropout(x, self.dropout, training=self.training)
+            elif op == "norm":
+                x = getattr(self, step[1])(x)
+            elif op == "save":
+                saved = x
+            elif op == "add":
+                x = x + saved
+            elif op == "head":
+                x = x[:, :step[1]]
+            else:
+                raise ValueError("unknown plan step %r" % (step,))
         return F.log_softmax(x, dim=1)
 
-
-class GCN3(nn.Module):
-    """GCN/models.py:66-81."""
-
-    def __init__(self, nfeat, nhid, nclass, dropout):
-        super(GCN3, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = GraphConvolution(nhid, nhid)
-        self.gc3 = GraphConvolution(nhid, nclass)
-        self.dropout = dropout
-
     def forward(self, x, adj):
-        x = F.relu(self.gc1(x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        x = F.relu(self.gc2(x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        x = self.gc3(x, adj)
-        return F.log_softmax(x, dim=1)
+        return self.run_plan(x, (adj,))
+
+    # `model.nfe = 0` is executed on every model by the harness (GCN/train_res.py:64); ODE models
+    # forward it to their block, the others just keep the number.
+    @property
+    def nfe(self):
+        return getattr(self, self.ode_attr).nfe if self.ode_attr else self.__dict__.get("_nfe", 0)
+
+    @nfe.setter
+    def nfe(self, value):
+        if self.ode_attr:
+            getattr(self, self.ode_attr).nfe = value
+        else:
+            self.__dict__["_nfe"] = value
 
 
-class RGCN3(nn.Module):
-    """GCN/models.py:101-118."""
-
-    def __init__(self, nfeat, nhid, nclass, dropout):
-        super(RGCN3, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = GraphConvolution(nhid, nhid)
-        self.gc3 = GraphConvolution(nhid, nclass)
-        self.dropout = dropout
-
-    def forward(self, x, adj):
-        x = F.relu(self.gc1(x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        r = x
-        x = F.relu(self.gc2(x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        x = x + r
-        x = self.gc3(x, adj)
-        return F.log_softmax(x, dim=1)
-
-
-class RGCN3norm(nn.Module):
-    """GCN/models.py:120-138."""
-
-    def __init__(self, nfeat, nhid, nclass, dropout):
-        super(RGCN3norm, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = GraphConvolution(nhid, nhid)
-        self.norm2 = nn.GroupNorm(min(32, nhid), nhid)
-        self.gc3 = GraphConvolution(nhid, nclass)
-        self.dropout = dropout
-
-    def forward(self, x, adj):
-        x = F.relu(self.gc1(x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        r = x
-        x = F.relu(self.gc2(x, adj))
-        x = self.norm2(x)
-        x = x + r
-        x = self.gc3(x, adj)
-        return F.log_softmax(x, dim=1)
-
-
-class RGCN3fullnorm(nn.Module):
-    """GCN/models.py:140-159."""
-
-    def __init__(self, nfeat, nhid, nclass, dropout):
-        super(RGCN3fullnorm, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.norm1 = nn.GroupNorm(min(32, nhid), nhid)
-        self.gc2 = GraphConvolution(nhid, nhid)
-        self.norm2 = nn.GroupNorm(min(32, nhid), nhid)
-        self.gc3 = GraphConvolution(nhid, nclass)
-        self.dropout = dropout
-
-    def forward(self, x, adj):
-        x = F.relu(self.gc1(x, adj))
-        x = self.norm1(x)
-        r = x
-        x = F.relu(self.gc2(x, adj))
-        x = self.norm2(x)
-        x = x + r
-        x = self.gc3(x, adj)
-        return F.log_softmax(x, dim=1)
-
-
+# ---- the ODE function and block ----------------------------------------------------------------
 class ODEfunc(nn.Module):
-    """GCN/models.py:161-179: relu(gc1([t | norm1(x)])), counting calls in `nfe`."""
+    """f(t, x) = relu(gc1([t | norm1(x)])), counting calls in `nfe` (reference: GCN/models.py:161-179)."""
 
     _gode_counts_nfe = True
 
     def __init__(self, dim):
         super(ODEfunc, self).__init__()
-        self.norm1 = nn.GroupNorm(min(32, dim), dim)
+        self.norm1 = _gn(dim)
         self.gc1 = FixedGraphConvolution(dim + 1, dim)
         self.nfe = 0
         self._shared = None
@@ -143,113 +103,31 @@ class ODEfunc(nn.Module):
         return odefunc_apply(self.gc1.adj, float(t), x, self.gc1.weight, self.gc1.bias, self.norm1.weight,
                              self.norm1.bias, self.norm1.num_groups, self.norm1.eps)
 
-    # hook used by graph_odenet_amd.odeint: fused forward / adjoint fields
     def gode_fields(self, y0):
+        """Hook for graph_odenet_amd.odeint: fused forward / adjoint fields (None -> autograd path)."""
         if self.gc1.bias is None or y0.dim() != 2:
             return None
+        plist = [p for p in self.parameters() if p.requires_grad]
+        if len(plist) != 4:
+            return None           # frozen parameters: take the generic autograd path
         spec = self._spec()
         sh = self._shared
         if sh is None or sh.n != y0.shape[0] or sh.d != y0.shape[1] or sh.S.device != y0.device:
             sh = self._shared = _Shared(spec.graph, spec.d, y0.device)
         names = {id(self.norm1.weight): "gamma", id(self.norm1.bias): "beta",
                  id(self.gc1.weight): "W", id(self.gc1.bias): "b"}
-        plist = [p for p in self.parameters() if p.requires_grad]
-        if len(plist) != 4:
-            return None           # frozen parameters: take the generic autograd path
         order = [names[id(p)] for p in plist]
         return GcnOdeField(spec, sh), (lambda: GcnOdeAdjointField(spec, sh, order)), tuple(plist)
 
 
-class ODEBlock(nn.Module):
-    """GCN/models.py:181-201."""
-
-    def __init__(self, odefunc, tol=1e-5, method=None, step_size=None):
-        super(ODEBlock, self).__init__()
-        self.odefunc = odefunc
-        self.integration_time = torch.tensor([0, 1]).float()
-        self.tol = tol
-        self.method = method
-        self.step_size = step_size
-
-    def forward(self, x, adj):
-        self.integration_time = self.integration_time.type_as(x)
-        self.odefunc.set_adj(adj)
-        options = {"step_size": self.step_size} if self.step_size is not None else None
-        out = odeint(self.odefunc, x, self.integration_time, rtol=self.tol, atol=self.tol,
-                     method=self.method, options=options)
-        return out[1]
-
-    @property
-    def nfe(self):
-        return self.odefunc.nfe
-
-    @nfe.setter
-    def nfe(self, value):
-        self.odefunc.nfe = value
-
-
-class ODEGCN3(nn.Module):
-    """GCN/models.py:204-226 (the north-star model: gc1 -> ODEBlock -> gc3)."""
-
-    def __init__(self, nfeat, nhid, nclass, dropout, method=None, step_size=None, tol=1e-5):
-        super(ODEGCN3, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = ODEBlock(ODEfunc(nhid), tol=tol, method=method, step_size=step_size)
-        self.gc3 = GraphConvolution(nhid, nclass)
-        self.dropout = dropout
-
-    def forward(self, x, adj):
-        x = F.relu(self.gc1(x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        x = self.gc2(x, adj)
-        x = self.gc3(x, adj)
-        return F.log_softmax(x, dim=1)
-
-    @property
-    def nfe(self):
-        return self.gc2.nfe
-
-    @nfe.setter
-    def nfe(self, value):
-        self.gc2.nfe = value
-
-
-class ODEGCN3fullnorm(nn.Module):
-    """GCN/models.py:229-253."""
-
-    def __init__(self, nfeat, nhid, nclass, dropout, method=None, step_size=None, tol=1e-5):
-        super(ODEGCN3fullnorm, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.norm1 = nn.GroupNorm(min(32, nhid), nhid)
-        self.gc2 = ODEBlock(ODEfunc(nhid), tol=tol, method=method, step_size=step_size)
-        self.gc3 = GraphConvolution(nhid, nclass)
-        self.dropout = dropout
-
-    def forward(self, x, adj):
-        x = F.relu(self.gc1(x, adj))
-        x = self.norm1(x)
-        x = self.gc2(x, adj)
-        x = self.gc3(x, adj)
-        return F.log_softmax(x, dim=1)
-
-    @property
-    def nfe(self):
-        return self.gc2.nfe
-
-    @nfe.setter
-    def nfe(self, value):
-        self.gc2.nfe = value
-
-
 class ODEfunc2(nn.Module):
-    """GCN/models.py:551-575: two stacked (FixedGC -> relu -> GroupNorm) with the time column re-attached
-    before each graph convolution.  The first GroupNorm is folded into the prologue of the second
-    dense product; the trailing one has no consumer inside f and stays a PyTorch op."""
+    """Two stacked (FixedGC -> relu -> GroupNorm), time column re-attached before each convolution
+    (reference: GCN/models.py:551-575).  norm1 is folded into the prologue of the second dense product;
+    norm2 has no consumer inside f and stays a PyTorch op."""
 
     def __init__(self, dim, dropout):
         super(ODEfunc2, self).__init__()
-        self.norm1 = nn.GroupNorm(min(32, dim), dim)
-        self.norm2 = nn.GroupNorm(min(32, dim), dim)
+        self.norm1, self.norm2 = _gn(dim), _gn(dim)
         self.gc1 = FixedGraphConvolution(dim + 1, dim)
         self.gc2 = FixedGraphConvolution(dim + 1, dim)
         self.dropout = dropout
@@ -261,79 +139,213 @@ class ODEfunc2(nn.Module):
 
     def forward(self, t, x):
         self.nfe += 1
-        g = as_graph(self.gc1.adj)
-        s1 = gn_time_linear(x, float(t), self.gc1.weight)                          # [t | x] W1
-        h1 = graph_aggregate(g, s1, self.gc1.bias, relu=True)                      # relu(A . + b1)
-        s2 = gn_time_linear(h1, float(t), self.gc2.weight, self.norm1.weight, self.norm1.bias,
-                            self.norm1.num_groups, self.norm1.eps)                 # [t | norm1(h1)] W2
-        h2 = graph_aggregate(as_graph(self.gc2.adj), s2, self.gc2.bias, relu=True)
-        return self.norm2(h2)
+        t = float(t)
+        h = graph_aggregate(as_graph(self.gc1.adj), gn_time_linear(x, t, self.gc1.weight), self.gc1.bias, relu=True)
+        s = gn_time_linear(h, t, self.gc2.weight, self.norm1.weight, self.norm1.bias,
+                           self.norm1.num_groups, self.norm1.eps)
+        h = graph_aggregate(as_graph(self.gc2.adj), s, self.gc2.bias, relu=True)
+        return self.norm2(h)
 
 
-class GCNK(nn.Module):
-    """GCN/models.py:255-278."""
+class ODEBlock(nn.Module):
+    """y(1) of y' = odefunc(t, y), y(0) = x (reference: GCN/models.py:181-201)."""
 
+    def __init__(self, odefunc, tol=1e-5, method=None, step_size=None):
+        super(ODEBlock, self).__init__()
+        self.odefunc = odefunc
+        self.integration_time = torch.tensor([0, 1]).float()
+        self.tol = tol
+        self.method = method
+        self.step_size = step_size
+
+    def forward(self, x, *graph):
+        self.integration_time = self.integration_time.type_as(x)
+        self.odefunc.set_adj(*graph)
+        options = None if self.step_size is None else {"step_size": self.step_size}
+        return odeint(self.odefunc, x, self.integration_time, rtol=self.tol, atol=self.tol,
+                      method=self.method, options=options)[1]
+
+    @property
+    def nfe(self):
+        return self.odefunc.nfe
+
+    @nfe.setter
+    def nfe(self, value):
+        self.odefunc.nfe = value
+
+
+# ---- fixed-depth variants (reference: GCN/models.py:8-253) ----------------------------------------
+class GCN(_PlanModel):
+    plan = (("gc", "gc1"), ("relu",), ("drop",), ("gc", "gc2"))
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(GCN, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc2 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+
+class RGCN2(_PlanModel):
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(RGCN2, self).__init__()
+        if nhid < nclass:
+            raise ValueError("nhid must be equal or larger than nclass")
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc2 = GraphConvolution(nhid, nhid)
+        self.nclass = nclass
+        self.dropout = dropout
+        self.plan = (("gc", "gc1"), ("relu",), ("drop",), ("save",), ("gc", "gc2"), ("add",), ("head", nclass))
+
+
+class ODEGCN2(_PlanModel):
+    """The reference's forward reads self.nclass which its __init__ never sets; it is set here."""
+    ode_attr = "gc2"
+
+    def __init__(self, nfeat, nhid, nclass, dropout, method=None, step_size=None, tol=1e-5):
+        super(ODEGCN2, self).__init__()
+        if nhid < nclass:
+            raise ValueError("nhid must be equal or larger than nclass")
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc2 = ODEBlock(ODEfunc(nhid), tol=tol, method=method, step_size=step_size)
+        self.nclass = nclass
+        self.dropout = dropout
+        self.plan = (("gc", "gc1"), ("relu",), ("gc", "gc2"), ("head", nclass))
+
+
+class _Three(_PlanModel):
+    """gc1 (nfeat->nhid), gc2 (nhid->nhid or ODE block), gc3 (nhid->nclass) + optional GroupNorms."""
+
+    def __init__(self, nfeat, nhid, nclass, dropout, norms=(), ode=None):
+        super(_Three, self).__init__()
+        self.gc1 = GraphConvolution(nfeat, nhid)
+        if "norm1" in norms:
+            self.norm1 = _gn(nhid)
+        self.gc2 = GraphConvolution(nhid, nhid) if ode is None else ODEBlock(ODEfunc(nhid), **ode)
+        if "norm2" in norms:
+            self.norm2 = _gn(nhid)
+        self.gc3 = GraphConvolution(nhid, nclass)
+        self.dropout = dropout
+
+
+class GCN3(_Three):
+    plan = (("gc", "gc1"), ("relu",), ("drop",), ("gc", "gc2"), ("relu",), ("drop",), ("gc", "gc3"))
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(GCN3, self).__init__(nfeat, nhid, nclass, dropout)
+
+
+class GCN3norm(_Three):
+    plan = (("gc", "gc1"), ("relu",), ("drop",), ("gc", "gc2"), ("relu",), ("norm", "norm2"), ("gc", "gc3"))
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(GCN3norm, self).__init__(nfeat, nhid, nclass, dropout, norms=("norm2",))
+
+
+class RGCN3(_Three):
+    plan = (("gc", "gc1"), ("relu",), ("drop",), ("save",), ("gc", "gc2"), ("relu",), ("drop",), ("add",), ("gc", "gc3"))
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(RGCN3, self).__init__(nfeat, nhid, nclass, dropout)
+
+
+class RGCN3norm(_Three):
+    plan = (("gc", "gc1"), ("relu",), ("drop",), ("save",), ("gc", "gc2"), ("relu",), ("norm", "norm2"), ("add",),
+            ("gc", "gc3"))
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(RGCN3norm, self).__init__(nfeat, nhid, nclass, dropout, norms=("norm2",))
+
+
+class RGCN3fullnorm(_Three):
+    plan = (("gc", "gc1"), ("relu",), ("norm", "norm1"), ("save",), ("gc", "gc2"), ("relu",), ("norm", "norm2"),
+            ("add",), ("gc", "gc3"))
+
+    def __init__(self, nfeat, nhid, nclass, dropout):
+        super(RGCN3fullnorm, self).__init__(nfeat, nhid, nclass, dropout, norms=("norm1", "norm2"))
+
+
+class ODEGCN3(_Three):
+    """The north-star model: gc1 -> relu -> dropout -> ODEBlock -> gc3 (reference: GCN/models.py:204-226)."""
+    plan = (("gc", "gc1"), ("relu",), ("drop",), ("gc", "gc2"), ("gc", "gc3"))
+    ode_attr = "gc2"
+
+    def __init__(self, nfeat, nhid, nclass, dropout, method=None, step_size=None, tol=1e-5):
+        super(ODEGCN3, self).__init__(nfeat, nhid, nclass, dropout, ode=dict(tol=tol, method=method, step_size=step_size))
+
+
+class ODEGCN3fullnorm(_Three):
+    plan = (("gc", "gc1"), ("relu",), ("norm", "norm1"), ("gc", "gc2"), ("gc", "gc3"))
+    ode_attr = "gc2"
+
+    def __init__(self, nfeat, nhid, nclass, dropout, method=None, step_size=None, tol=1e-5):
+        super(ODEGCN3fullnorm, self).__init__(nfeat, nhid, nclass, dropout, norms=("norm1",),
+                                              ode=dict(tol=tol, method=method, step_size=step_size))
+
+
+# ---- depth-parametrised variants (reference: GCN/models.py:255-600) -------------------------------
+class _Deep(_PlanModel):
+    """`self.gcs` ModuleList: first layer, a list of middle blocks, last layer."""
+
+    def _build(self, nfeat, nhid, nclass, dropout, middle):
+        self.gcs = nn.ModuleList([GraphConvolution(nfeat, nhid)] + list(middle) + [GraphConvolution(nhid, nclass)])
+        self.dropout = dropout
+
+    @property
+    def nfe(self):
+        return sum(b.nfe for b in self.gcs if isinstance(b, ODEBlock))
+
+    @nfe.setter
+    def nfe(self, value):
+        for b in self.gcs:
+            if isinstance(b, ODEBlock):
+                b.nfe = value
+
+
+class GCNK(_Deep):
     def __init__(self, nfeat, nhid, nclass, dropout, nlayers=2):
         super(GCNK, self).__init__()
         if nlayers < 2:
             raise ValueError("Can't make a GCN with less than 2 layers")
         self.n_layers = nlayers
-        self.gcs = nn.ModuleList([GraphConvolution(nfeat, nhid)] +
-                                 [GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)] +
-                                 [GraphConvolution(nhid, nclass)])
-        self.dropout = dropout
+        self._build(nfeat, nhid, nclass, dropout, [GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)])
 
     def forward(self, x, adj):
         for gc in self.gcs[:-1]:
-            x = F.relu(gc(x, adj))
-            x = F.dropout(x, self.dropout, training=self.training)
-        x = self.gcs[-1](x, adj)
-        return F.log_softmax(x, dim=1)
+            x = F.dropout(F.relu(gc(x, adj)), self.dropout, training=self.training)
+        return F.log_softmax(self.gcs[-1](x, adj), dim=1)
 
 
-class ODEK1(nn.Module):
-    """GCN/models.py:524-548: first layer, (nlayers-2) ODE blocks, last layer."""
+class _OdeDeep(_Deep):
+    def forward(self, x, adj):
+        x = F.dropout(F.relu(self.gcs[0](x, adj)), self.dropout, training=self.training)
+        for block in self.gcs[1:-1]:
+            x = block(x, adj)
+        return F.log_softmax(self.gcs[-1](x, adj), dim=1)
+
+
+class ODEK1(_OdeDeep):
+    """First layer, (nlayers-2) ODE blocks, last layer."""
 
     def __init__(self, nfeat, nhid, nclass, dropout, nlayers=3, method=None, step_size=None):
         super(ODEK1, self).__init__()
         if nlayers < 3:
             raise ValueError("Can't make a Residual GCN with less than 3 layers")
         self.n_layers = nlayers
-        self.gcs = nn.ModuleList([GraphConvolution(nfeat, nhid)] +
-                                 [ODEBlock(ODEfunc(nhid), method=method, step_size=step_size) for _ in range(nlayers - 2)] +
-                                 [GraphConvolution(nhid, nclass)])
-        self.dropout = dropout
-
-    def forward(self, x, adj):
-        x = F.relu(self.gcs[0](x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        for gc in self.gcs[1:-1]:
-            x = gc(x, adj)
-        x = self.gcs[-1](x, adj)
-        return F.log_softmax(x, dim=1)
+        self._build(nfeat, nhid, nclass, dropout,
+                    [ODEBlock(ODEfunc(nhid), method=method, step_size=step_size) for _ in range(nlayers - 2)])
 
 
-class ODEK2(nn.Module):
-    """GCN/models.py:577-600.  Quirk Q1 of SURVEY.md is reproduced on purpose: the reference passes
-    `dropout` as the ODEBlock tolerance (`ODEBlock(ODEfunc2(nhid, dropout), dropout)`, :587)."""
+class ODEK2(_OdeDeep):
+    """Blocks of ODEfunc2 (+ one ODEfunc block when nlayers is odd).  Quirk Q1 of SURVEY.md is kept on
+    purpose: the reference passes `dropout` as the ODEBlock tolerance (GCN/models.py:587)."""
 
     def __init__(self, nfeat, nhid, nclass, dropout, nlayers=4, method=None, step_size=None):
         super(ODEK2, self).__init__()
         if nlayers < 4:
             raise ValueError("Can't make a Residual GCN with less than 4 layers using 2 layers for each residual block")
         self.n_layers = nlayers
-        self.gcs = nn.ModuleList(
-            [GraphConvolution(nfeat, nhid)] +
-            [ODEBlock(ODEfunc2(nhid, dropout), dropout, method=method, step_size=step_size)
-             for _ in range((nlayers - 2) // 2)] +
-            ([ODEBlock(ODEfunc(nhid), method=method, step_size=step_size)] if nlayers % 2 == 1 else []) +
-            [GraphConvolution(nhid, nclass)])
-        self.dropout = dropout
-
-    def forward(self, x, adj):
-        x = F.relu(self.gcs[0](x, adj))
-        x = F.dropout(x, self.dropout, training=self.training)
-        for gc in self.gcs[1:-1]:
-            x = gc(x, adj)
-        x = self.gcs[-1](x, adj)
-        return F.log_softmax(x, dim=1)
+        middle = [ODEBlock(ODEfunc2(nhid, dropout), dropout, method=method, step_size=step_size)
+                  for _ in range((nlayers - 2) // 2)]
+        if nlayers % 2 == 1:
+            middle.append(ODEBlock(ODEfunc(nhid), method=method, step_size=step_size))
+        self._build(nfeat, nhid, nclass, dropout, middle)

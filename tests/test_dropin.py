@@ -63,7 +63,8 @@ def test_gat_shims(shim_path):
     assert list(inspect.signature(lay.forward).parameters) == ["x", "src", "tgt", "Mtgt"]
     m = models.ODEGCN3(nfeat=10, nhid=16, nclass=3, dropout=0.5)
     assert "gc2.odefunc.gc1.f.weight" in m.state_dict() and "gc2.odefunc.gc1.w.bias" in m.state_dict()
-    assert list(inspect.signature(m.gc2.forward).parameters) == ["x", "src", "tgt", "Mtgt"]
+    assert list(inspect.signature(m.forward).parameters) == ["x", "src", "tgt", "Mtgt"]
+    assert list(inspect.signature(m.gc2.odefunc.set_adj).parameters) == ["src", "tgt", "Mtgt"]
 
 
 def test_qc_shims(shim_path):
