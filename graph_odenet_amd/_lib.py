@@ -27,6 +27,29 @@ class SpmmEpilogue(ctypes.Structure):
                 ("pre", LinComb), ("cot", LinComb), ("Y2", ctypes.c_void_p)]
 
 
+class Graph(ctypes.Structure):
+    """Mirror of gode_graph_t."""
+    _fields_ = [("rowptr", ctypes.c_void_p), ("col", ctypes.c_void_p), ("val", ctypes.c_void_p),
+                ("items", ctypes.c_void_p), ("n_items", ctypes.c_int64),
+                ("long_rows", ctypes.c_void_p), ("n_long", ctypes.c_int64), ("partial", ctypes.c_void_p),
+                ("n_rows", ctypes.c_int64), ("nnz", ctypes.c_int64)]
+
+
+class GcnOdeFunc(ctypes.Structure):
+    """Mirror of gode_gcn_odefunc_t."""
+    _fields_ = [("A", Graph), ("AT", Graph), ("n", ctypes.c_int64), ("d", ctypes.c_int64),
+                ("groups", ctypes.c_int32), ("eps", ctypes.c_float),
+                ("W", ctypes.c_void_p), ("b", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p)]
+
+
+class Rk4Workspace(ctypes.Structure):
+    """Mirror of gode_rk4_workspace_t."""
+    _fields_ = [("S", ctypes.c_void_p), ("dZ", ctypes.c_void_p), ("dS", ctypes.c_void_p),
+                ("ky", ctypes.c_void_p * 4), ("ka", ctypes.c_void_p * 4), ("ktheta", ctypes.c_void_p * 4),
+                ("wpart", ctypes.c_void_p), ("gpart", ctypes.c_void_p), ("bpart", ctypes.c_void_p),
+                ("colsum_scratch", ctypes.c_void_p)]
+
+
 c_i64 = ctypes.c_int64
 c_p = ctypes.c_void_p
 c_f = ctypes.c_float
@@ -61,6 +84,11 @@ SIGNATURES = {
                                             c_i64, c_p, c_p, c_p]),
     "gode_edge_matvec_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
     "gode_edge_matvec_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "gode_gcn_ode_theta_len": (c_i64, [c_i64]),
+    "gode_gcn_ode_rk4_forward": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, ctypes.POINTER(c_p), ctypes.POINTER(Rk4Workspace),
+                                       c_f, c_f, ctypes.c_int32, c_p]),
+    "gode_gcn_ode_rk4_adjoint": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p),
+                                       ctypes.POINTER(Rk4Workspace), c_f, c_f, ctypes.c_int32, c_p]),
     "gode_prof_create": (c_p, [c_i]),
     "gode_prof_destroy": (None, [c_p]),
     "gode_prof_enable": (None, [c_p]),

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                                                              const float* __restrict__ dS, float out_scale,
                                                              LinComb pre, float* __restrict__ dx,
                                                              float* __restrict__ dgamma_part,
-                                                             float* __restrict__ dbeta_part)
+                                                             float* __restrict__ dbeta_part, int n_part)
 {
     constexpr int D = 16 * NJ;
     constexpr int LDW = D + 4;
@@ -453,6 +453,9 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
             dgamma_part[(int64_t)blockIdx.x * D + c] = (red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c]);
             dbeta_part[(int64_t)blockIdx.x * D + c] = (red[4 * D + c] + red[5 * D + c]) + (red[6 * D + c] + red[7 * D + c]);
         }
+        // the caller's buffers hold gode_gemm_bwd_parts() rows: zero the ones no block owns
+        for (int p = gridDim.x + blockIdx.x; p < n_part; p += gridDim.x)
+            for (int c = threadIdx.x; c < D; c += 256) { dgamma_part[(int64_t)p * D + c] = 0.f; dbeta_part[(int64_t)p * D + c] = 0.f; }
     }
 }
 
@@ -870,12 +873,6 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
     LinComb lc = make_lincomb(xin);
     LinComb lpre = make_lincomb(pre);
     const int64_t n_part = gode_gemm_bwd_parts(n_rows);
-    if (dgamma_part && groups > 0) {
-        hipError_t e = hipMemsetAsync(dgamma_part, 0, (size_t)n_part * d_in * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
-        e = hipMemsetAsync(dbeta_part, 0, (size_t)n_part * d_in * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
-    }
     const int cg = fast_cg(d_in, d_out, groups);
     const bool al = lincomb_aligned16(xin) && lincomb_aligned16(pre) && !(((uintptr_t)dS) & 15) && !(((uintptr_t)dx) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) &&
@@ -888,10 +885,16 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
 #define GODE_BWD(NJV, CGV)                                                                          \
         { rc = set_lds(gn_gemm_bwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
           hipLaunchKernelGGL((gn_gemm_bwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
-                             lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part); \
+                             lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part, (int)n_part); \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_BWD)
 #undef GODE_BWD
+    }
+    if (dgamma_part && groups > 0) {        // the generic kernel accumulates into its block partials
+        hipError_t e = hipMemsetAsync(dgamma_part, 0, (size_t)n_part * d_in * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(dbeta_part, 0, (size_t)n_part * d_in * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
     }
     const size_t g2 = (size_t)RB * (groups > 0 ? groups : 1) * 2;
     const size_t lds = ((size_t)RB * d_in * 2 + g2 * 2) * sizeof(float);

@@ -10,11 +10,26 @@ GCN/layers.py:69-75) and its vector-Jacobian products, as two / five HIP kernel 
 
 Stage inputs arrive as (coef, tensor) term lists and are combined inside the kernels.
 """
+import ctypes
+
 import torch
 
-from . import ops
+from . import _lib, ops
 from .graph import as_graph
 from .solver import Field
+
+
+def _graph_struct(g, d):
+    gs = _lib.Graph()
+    gs.rowptr, gs.col = g.rowptr.data_ptr(), g.col.data_ptr()
+    gs.val = g.val.data_ptr() if g.val is not None else None
+    gs.items, gs.n_items = g.items.data_ptr(), g.n_items
+    gs.long_rows = g.long_rows.data_ptr() if g.long_rows is not None else None
+    gs.n_long = g.n_long
+    part = g.partial(d)
+    gs.partial = part.data_ptr() if part is not None else None
+    gs.n_rows, gs.nnz = g.n_rows, g.nnz
+    return gs
 
 
 class _Shared:
@@ -27,12 +42,64 @@ class _Shared:
         self.dS = None
         self.n = n
         self.d = d
+        self.device = device
+        self._ky = self._ka = self._kt = None
+        self._parts = None
 
     def bwd(self):
         if self.dZ is None:
             self.dZ = torch.empty_like(self.S)
             self.dS = torch.empty_like(self.S)
         return self.dZ, self.dS
+
+    # ---- buffers of the C-level rk4 driver (csrc/ode_driver.hip) --------------------------------
+    def stage_buffers(self, adjoint):
+        if self._ky is None:
+            self._ky = [torch.empty_like(self.S) for _ in range(4)]
+        if adjoint and self._ka is None:
+            lib = _lib.load()
+            P = lib.gode_gcn_ode_theta_len(self.d)
+            self._ka = [torch.empty_like(self.S) for _ in range(4)]
+            self._kt = [torch.empty(P, dtype=torch.float32, device=self.device) for _ in range(4)]
+            nW = (self.d + 1) * self.d
+            self._parts = (torch.empty(lib.gode_wgrad_parts(self.n) * nW, dtype=torch.float32, device=self.device),
+                           torch.empty(lib.gode_gemm_bwd_parts(self.n) * self.d, dtype=torch.float32, device=self.device),
+                           torch.empty(lib.gode_gemm_bwd_parts(self.n) * self.d, dtype=torch.float32, device=self.device),
+                           torch.empty(max(lib.gode_colsum_scratch_bytes(self.n, self.d), 16), dtype=torch.uint8,
+                                       device=self.device))
+        return self._ky, self._ka, self._kt, self._parts
+
+    def workspace_struct(self, adjoint):
+        ky, ka, kt, parts = self.stage_buffers(adjoint)
+        ws = _lib.Rk4Workspace()
+        ws.S = self.S.data_ptr()
+        for i in range(4):
+            ws.ky[i] = ky[i].data_ptr()
+        if adjoint:
+            dZ, dS = self.bwd()
+            ws.dZ, ws.dS = dZ.data_ptr(), dS.data_ptr()
+            for i in range(4):
+                ws.ka[i] = ka[i].data_ptr()
+                ws.ktheta[i] = kt[i].data_ptr()
+            ws.wpart, ws.gpart, ws.bpart, ws.colsum_scratch = (p.data_ptr() for p in parts)
+        return ws
+
+
+def _func_struct(spec):
+    fs = _lib.GcnOdeFunc()
+    fs.A = _graph_struct(spec.graph, spec.d)
+    fs.AT = _graph_struct(spec.graph.transpose(), spec.d)
+    fs.n, fs.d, fs.groups, fs.eps = spec.graph.n_rows, spec.d, spec.groups, spec.eps
+    fs.W, fs.b = spec.W.data_ptr(), spec.b.data_ptr()
+    fs.gamma, fs.beta = spec.gamma.data_ptr(), spec.beta.data_ptr()
+    return fs
+
+
+def _by_ptr(ptr_value, candidates):
+    for t in candidates:
+        if t.data_ptr() == ptr_value:
+            return t
+    raise RuntimeError("rk4 driver returned an unknown buffer")
 
 
 class GcnOdeSpec:
@@ -60,6 +127,22 @@ class GcnOdeField(Field):
         ops.gn_time_gemm(terms[0], w.n, s.d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
         ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0])
 
+    def rk4_native(self, comps, t0, t1, n_steps):
+        """Whole fixed-grid solve in one C call (csrc/ode_driver.hip); comps[0] is re-bound to the result."""
+        lib = _lib.load()
+        s, w = self.s, self.w
+        ky = w.stage_buffers(False)[0]
+        fs, ws = _func_struct(s), w.workspace_struct(False)
+        res = ctypes.c_void_p()
+        _lib.check(lib.gode_gcn_ode_rk4_forward(ctypes.byref(fs), _lib.ptr(comps[0]), ctypes.byref(res), ctypes.byref(ws),
+                                                float(t0), float(t1), int(n_steps), _lib.stream_ptr()),
+                   "gode_gcn_ode_rk4_forward")
+        out = _by_ptr(res.value, [comps[0]] + ky)
+        if out is not comps[0]:
+            # keep the driver's buffers private to the workspace: hand back a copy in the caller's tensor
+            comps[0].copy_(out)
+        return 4 * n_steps
+
     def eval_combine(self, t, terms, pre, coef, out):
         """Last RK stage: out[0] = (sum pre[0]) + coef * f(t, sum terms[0]) without materialising f."""
         s, w = self.s, self.w
@@ -79,10 +162,33 @@ class GcnOdeAdjointField(Field):
         self.ratio_groups = [[0], [1], [2], [3, 4, 5, 6]]
 
     def new_state(self, y_end):
+        """[y, a, a_t, W, b, gamma, beta]; the small components are views of ONE packed buffer laid out as the
+        C driver expects: [W | b | gamma | beta | a_t]."""
         s = self.s
-        z = lambda p: torch.zeros_like(p)   # noqa: E731
-        return [y_end.clone(), torch.zeros_like(y_end), torch.zeros(1, dtype=torch.float32, device=y_end.device),
-                z(s.W), z(s.b), z(s.gamma), z(s.beta)]
+        d = s.d
+        nW = (d + 1) * d
+        self.theta = torch.zeros(nW + 3 * d + 1, dtype=torch.float32, device=y_end.device)
+        th = self.theta
+        return [y_end.clone(), torch.zeros_like(y_end), th[nW + 3 * d:], th[:nW].view(d + 1, d), th[nW:nW + d],
+                th[nW + d:nW + 2 * d], th[nW + 2 * d:nW + 3 * d]]
+
+    def rk4_native(self, comps, t0, t1, n_steps):
+        lib = _lib.load()
+        s, w = self.s, self.w
+        ky, ka, _, _ = w.stage_buffers(True)
+        fs, ws = _func_struct(s), w.workspace_struct(True)
+        yr, ar = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.gode_gcn_ode_rk4_adjoint(ctypes.byref(fs), _lib.ptr(comps[0]), _lib.ptr(comps[1]), _lib.ptr(self.theta),
+                                                ctypes.byref(yr), ctypes.byref(ar), ctypes.byref(ws),
+                                                float(t0), float(t1), int(n_steps), _lib.stream_ptr()),
+                   "gode_gcn_ode_rk4_adjoint")
+        yo = _by_ptr(yr.value, [comps[0]] + ky)
+        ao = _by_ptr(ar.value, [comps[1]] + ka)
+        if yo is not comps[0]:
+            comps[0].copy_(yo)
+        if ao is not comps[1]:
+            comps[1].copy_(ao)
+        return 4 * n_steps
 
     def param_grads(self, comps):
         m = {"W": comps[3], "b": comps[4], "gamma": comps[5], "beta": comps[6]}

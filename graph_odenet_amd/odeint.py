@@ -15,6 +15,9 @@ from . import ops
 from .solver import (Dopri5Stats, Field, integrate_dopri5_inplace, integrate_rk4, uniform_grid)
 
 
+NATIVE_RK4 = True      # fused fields: issue a whole rk4 solve from one C-ABI call (False: per-stage Python driver)
+
+
 def _materialise(terms):
     if len(terms) == 1 and terms[0][0] == 1.0:
         return terms[0][1]
@@ -89,7 +92,11 @@ def _method(method):
 def _integrate(field, comps, t0, t1, rtol, atol, method, options, stats):
     if method == "rk4":
         n = uniform_grid(t0, t1, (options or {}).get("step_size"))
-        stats.nfe += integrate_rk4(field, comps, t0, t1, n)
+        native = getattr(field, "rk4_native", None)
+        if native is not None and NATIVE_RK4:
+            stats.nfe += native(comps, t0, t1, n)          # whole solve issued from C (csrc/ode_driver.hip)
+        else:
+            stats.nfe += integrate_rk4(field, comps, t0, t1, n)
     else:
         integrate_dopri5_inplace(field, comps, t0, t1, rtol, atol, stats)
 

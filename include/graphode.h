@@ -191,6 +191,46 @@ int gode_edge_matvec_f32_bwd(const int32_t* edge_row, const float* edge_val, con
                              const float* A, const float* X, int64_t ldx, const float* dM, int64_t ldm,
                              int64_t h, int64_t n_edges, float* dA, float* dxe, void* stream);
 
+/* ---- whole rk4 integrations of the GCN ODE function in one call (host-launch-bound sizes) -----
+ * f(t, x) = relu(A * ([t | GroupNorm(x)] * W) + b)   (ODEfunc.forward, GCN/models.py:172-179).
+ * 3/8-rule steps on a uniform grid from t0 to t1 (t1 < t0 for the adjoint pass); every launch goes to
+ * `stream`, nothing is allocated or synchronised, so the call can be captured into a HIP graph.
+ * The solution / stage buffers swap roles from step to step: the final state is returned through
+ * the *_result pointers (each equals one of the buffers passed in).
+ * Adjoint: (y, a, theta) integrate d/dt [y, a, theta] = [f, -a^T df/dy, -a^T df/dtheta]; `theta` is the
+ * packed vector [dW ((d+1)*d) | db (d) | dgamma (d) | dbeta (d) | dt (1)] of gode_gcn_ode_theta_len(d)
+ * floats and is updated in place. */
+typedef struct gode_graph {
+    const int32_t* rowptr; const int32_t* col; const float* val;      /* CSR, val nullable */
+    const int32_t* items;  int64_t n_items;                             /* balanced records (nullable) */
+    const int32_t* long_rows; int64_t n_long; float* partial;           /* split rows + their slab */
+    int64_t n_rows; int64_t nnz;
+} gode_graph_t;
+
+typedef struct gode_gcn_odefunc {
+    gode_graph_t A, AT;                 /* adjacency and its transpose */
+    int64_t n, d;                       /* nodes, hidden width */
+    int32_t groups; float eps;          /* GroupNorm(groups, d), eps */
+    const float* W;                     /* (d+1) x d, row 0 = time row */
+    const float* b; const float* gamma; const float* beta;
+} gode_gcn_odefunc_t;
+
+typedef struct gode_rk4_workspace {
+    float* S; float* dZ; float* dS;     /* n x d each (dZ, dS: adjoint only) */
+    float* ky[4]; float* ka[4];         /* n x d stage buffers (ka: adjoint only) */
+    float* ktheta[4];                   /* gode_gcn_ode_theta_len(d) floats each (adjoint only) */
+    float* wpart;                       /* gode_wgrad_parts(n) * (d+1)*d floats */
+    float* gpart; float* bpart;         /* gode_gemm_bwd_parts(n) * d floats each */
+    float* colsum_scratch;              /* gode_colsum_scratch_bytes(n, d) bytes */
+} gode_rk4_workspace_t;
+
+int64_t gode_gcn_ode_theta_len(int64_t d);
+int gode_gcn_ode_rk4_forward(const gode_gcn_odefunc_t* f, float* y, float** result,
+                             const gode_rk4_workspace_t* ws, float t0, float t1, int32_t n_steps, void* stream);
+int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, float* a, float* theta,
+                             float** y_result, float** a_result,
+                             const gode_rk4_workspace_t* ws, float t0, float t1, int32_t n_steps, void* stream);
+
 /* ---- measurement aid (bench.py): HIP-event brackets around the SpMM main kernel ----------
  * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 fast-path launch
  * records a start/stop event pair on its stream (up to `capacity` launches).
