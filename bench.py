@@ -155,14 +155,20 @@ def main():
     ms = (ctypes.c_float * cap)()
     dd = (ctypes.c_int64 * cap)()
     rr = (ctypes.c_int64 * cap)()
-    cnt = lib.gode_prof_read(prof, ms, dd, rr, cap)
-    sel = [ms[i] for i in range(max(cnt, 0)) if dd[i] == args.hidden and rr[i] in (g.n_items, g.transpose().n_items)]
+    xx = (ctypes.c_int64 * cap)()
+    cnt = lib.gode_prof_read(prof, ms, dd, rr, xx, cap)
+    sel = [i for i in range(max(cnt, 0)) if dd[i] == args.hidden and rr[i] in (g.n_items, g.transpose().n_items)]
     lib.gode_prof_destroy(prof)
     roof = None
     if sel:
-        avg_ms = sum(sel) / len(sel)
+        tot_ms = sum(ms[i] for i in sel)
+        avg_ms = tot_ms / len(sel)
+        # algorithmic bytes per launch: SURVEY 8(d) B_alg of the product itself + the N x d operand arrays the
+        # fused epilogue of THAT launch reads / writes (RK combine terms, adjoint cotangent terms, masked output)
         b_alg = g.algorithmic_bytes(args.hidden)
-        ach = b_alg / (avg_ms * 1e-3) / 1e9
+        nd4 = n * args.hidden * 4
+        tot_bytes = sum(b_alg + xx[i] * nd4 for i in sel)
+        ach = tot_bytes / (tot_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
         if os.path.exists(tf):
@@ -173,7 +179,9 @@ def main():
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "spmm_vec4_kernel<%d>" % (args.hidden // 4), "launches_timed": len(sel),
-                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": b_alg}
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(tot_bytes / len(sel)),
+                "algorithmic_bytes_plain_product": b_alg,
+                "epilogue_operand_arrays_per_launch": round(sum(xx[i] for i in sel) / len(sel), 3)}
 
     if rank == 0:
         res = {

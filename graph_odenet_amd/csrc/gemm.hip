@@ -18,21 +18,12 @@
 // Bounds: fwd/bwd-data read + write one N x d operand each (HBM) against
 // 2*N*d*d flop on the fp32 MFMA pipe (157 TFLOP/s peak) - near the ridge at d=128.
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxBlocks = 512;   // 2 blocks per CU
-
-// diagnostic build aid (GODE_GEMM_DEBUG & 16): per-wave phase cycle sums, read back with gode_debug_read
-__device__ unsigned long long g_stamps[2048 * 8];
-__device__ __forceinline__ unsigned long long stamp() {
-    unsigned long long t;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return t;
-}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -196,45 +187,27 @@ __device__ __forceinline__ void load_tile(const LinComb& lc, int64_t base, bool 
 // One 16-row panel: acc[tt] += sum_k Wlds[k][16tt + r] * xb[k]   (k-slot g of step (j,c) carries k = 16j+4g+c).
 // The A operands of step s+1 are read from LDS before the MFMAs of step s are issued, and a
 // scheduling barrier per step keeps hipcc from hoisting all 4*NJ*NJ LDS reads to the top (spills).
-template <int NJ, bool PIPE = true>
+template <int NJ>
 __device__ __forceinline__ void mfma_panel(const float* wl /* Wlds + 4g*LDW + r */, const float4 (&xv)[NJ], f32x4 (&acc)[NJ]) {
     constexpr int LDW = 16 * NJ + 4;
-    if (PIPE) {
-        // ping-pong operand registers: step s multiplies out of a[s&1] while a[(s+1)&1] is being read
-        // from LDS (indices are compile-time after unrolling, so no register moves are generated)
-        float a[2][NJ];
+    // ping-pong operand registers: step s multiplies out of a[s&1] while a[(s+1)&1] is being read from LDS
+    // (indices are compile-time after unrolling, so no register moves are generated)
+    float a[2][NJ];
 #pragma unroll
-        for (int tt = 0; tt < NJ; ++tt) a[0][tt] = wl[16 * tt];
+    for (int tt = 0; tt < NJ; ++tt) a[0][tt] = wl[16 * tt];
 #pragma unroll
-        for (int s = 0; s < 4 * NJ; ++s) {
-            const int j = s / 4, c = s % 4;
-            const float xb = c == 0 ? xv[j].x : (c == 1 ? xv[j].y : (c == 2 ? xv[j].z : xv[j].w));
-            if (s + 1 < 4 * NJ) {
-                const int jn = (s + 1) / 4, cn = (s + 1) % 4;
+    for (int s = 0; s < 4 * NJ; ++s) {
+        const int j = s / 4, c = s % 4;
+        const float xb = c == 0 ? xv[j].x : (c == 1 ? xv[j].y : (c == 2 ? xv[j].z : xv[j].w));
+        if (s + 1 < 4 * NJ) {
+            const int jn = (s + 1) / 4, cn = (s + 1) % 4;
 #pragma unroll
-                for (int tt = 0; tt < NJ; ++tt) a[(s + 1) & 1][tt] = wl[(16 * jn + cn) * LDW + 16 * tt];
-            }
-#pragma unroll
-            for (int tt = 0; tt < NJ; ++tt)
-                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tt], xb, acc[tt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int tt = 0; tt < NJ; ++tt) a[(s + 1) & 1][tt] = wl[(16 * jn + cn) * LDW + 16 * tt];
         }
-    } else {
-        // 4 waves per SIMD: the other waves cover the LDS latency, so no register double-buffering
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float xb[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float a[NJ];
-#pragma unroll
-                for (int tt = 0; tt < NJ; ++tt) a[tt] = wl[(16 * j + c) * LDW + 16 * tt];
-#pragma unroll
-                for (int tt = 0; tt < NJ; ++tt)
-                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], xb[c], acc[tt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        for (int tt = 0; tt < NJ; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tt], xb, acc[tt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -263,12 +236,12 @@ __device__ __forceinline__ float4 acc_to_mem_layout(const f32x4 a, int src_f_lan
                        __int_as_float(__builtin_amdgcn_ds_bpermute(src_f_lane_x4, __float_as_int(a[3]))));
 }
 
-template <int NJ, int CG, int NW>   // d = 16*NJ, NW waves per block
-__global__ __launch_bounds__(64 * NW, (NW == 12 ? 3 : NW / 2)) void gn_gemm_fwd_kernel(LinComb xin, int n_rows, float eps,
+template <int NJ, int CG>   // d = 16*NJ
+__global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_rows, float eps,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ W, int has_time, float t,
-                                                             float* __restrict__ S, int dbg)
+                                                             float* __restrict__ S)
 {
     constexpr int D = 16 * NJ;
     constexpr int LDW = D + 4;
@@ -277,56 +250,38 @@ __global__ __launch_bounds__(64 * NW, (NW == 12 ? 3 : NW / 2)) void gn_gemm_fwd_
     float* Gs = smem + D * LDW;          // gamma | beta | t * W[0,:]
     float* Bs = Gs + D;
     float* T0 = Bs + D;
-    fill_w_lds<D, 64 * NW, false>(Ws, W, has_time);
-    fill_vec_lds<D, 64 * NW>(Gs, gamma, 1.f);
-    fill_vec_lds<D, 64 * NW>(Bs, beta, 0.f);
-    for (int c = threadIdx.x; c < D; c += 64 * NW) T0[c] = has_time ? t * W[c] : 0.f;
+    fill_w_lds<D, 256, false>(Ws, W, has_time);
+    fill_vec_lds<D, 256>(Gs, gamma, 1.f);
+    fill_vec_lds<D, 256>(Bs, beta, 0.f);
+    for (int c = threadIdx.x; c < D; c += 256) T0[c] = has_time ? t * W[c] : 0.f;
     __syncthreads();
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int r = l & 15, g = l >> 4;          // MFMA layout
     const int mr = l >> 2, mg = l & 3;         // memory layout
     const int to_f = (4 * r + g) * 4, to_m = (mg * 16 + mr) * 4;
     const int n_tiles = (n_rows + 15) / 16;
-    // The two blocks that share a CU run the same program; started together their waves reach the
-    // VALU-heavy prologue (combine, GroupNorm, layout change) and the MFMA phase in lockstep and then
-    // queue on one matrix pipe.  Half a tile period of skew for the second wave of blocks lets one
-    // SIMD partner compute while the other loads / normalises.
-    if (dbg & 8) { if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(80); }
-    unsigned long long ph[5] = {0, 0, 0, 0, 0};
-    const bool st = dbg & 16;
-    const unsigned long long t_begin = st ? stamp() : 0;
-    for (int tile = blockIdx.x * NW + wave; tile < n_tiles; tile += gridDim.x * NW) {
-        unsigned long long t0 = st ? stamp() : 0;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
         const int row = tile * 16 + mr;
         const bool valid = row < n_rows;
         float4 xv[NJ];
-        load_tile<NJ, (NW > 4 ? 1 : 2)>(xin, (int64_t)row * D + 4 * mg, valid && !(dbg & 4), xv);
-        if (st) { const unsigned long long t1 = stamp(); ph[0] += t1 - t0; t0 = t1; }
+        load_tile<NJ, 2>(xin, (int64_t)row * D + 4 * mg, valid, xv);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             xv[j] = gn_forward_v<CG>(xv[j], eps, ld4(Gs + 16 * j + 4 * mg), ld4(Bs + 16 * j + 4 * mg));
             xv[j] = to_mfma_layout(xv[j], to_f);
         }
-        if (st) { const unsigned long long t1 = stamp(); ph[1] += t1 - t0; t0 = t1; }
         f32x4 acc[NJ];
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) {
             const float4 w0 = ld4(T0 + 16 * tt + 4 * g);
             acc[tt] = (f32x4){w0.x, w0.y, w0.z, w0.w};
         }
-        if (!(dbg & 1)) mfma_panel<NJ, (NW <= 4)>(Ws + 4 * g * LDW + r, xv, acc);
-        else { _Pragma("unroll") for (int tt = 0; tt < NJ; ++tt) { acc[tt][0] += xv[tt].x; acc[tt][1] += xv[tt].y; acc[tt][2] += xv[tt].z; acc[tt][3] += xv[tt].w; } }
-        if (st) { const unsigned long long t1 = stamp(); ph[2] += t1 - t0; t0 = t1; }
+        mfma_panel<NJ>(Ws + 4 * g * LDW + r, xv, acc);
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) {
             const float4 o = acc_to_mem_layout(acc[tt], to_m);
-            if (valid && (!(dbg & 2) || o.x == 12345.678f)) *reinterpret_cast<float4*>(S + (int64_t)row * D + 16 * tt + 4 * mg) = o;
+            if (valid) *reinterpret_cast<float4*>(S + (int64_t)row * D + 16 * tt + 4 * mg) = o;
         }
-        if (st) { const unsigned long long t1 = stamp(); ph[3] += t1 - t0; }
-    }
-    if (st && l == 0) {
-        const int wid = blockIdx.x * NW + wave;
-        if (wid < 2048) { for (int q = 0; q < 4; ++q) g_stamps[wid * 8 + q] = ph[q]; g_stamps[wid * 8 + 4] = stamp() - t_begin; }
     }
 }
 
@@ -771,17 +726,6 @@ int64_t fwd_blocks(int64_t n_rows) {
     if (b > kMaxBlocks) b = kMaxBlocks;
     return b;
 }
-int64_t blocks_nw(int64_t n_rows, int nw, int64_t cap) {
-    int64_t b = ((n_rows + 15) / 16 + nw - 1) / nw;
-    if (b < 1) b = 1;
-    if (b > cap) b = cap;
-    return b;
-}
-int gemm_dbg() { static int d = [] { const char* e = getenv("GODE_GEMM_DEBUG"); return e ? atoi(e) : 0; }(); return d; }
-int fwd_waves() {      // tuning switch (read once): GODE_GEMM_WAVES=4|8|12 waves per block
-    static int w = [] { const char* e = getenv("GODE_GEMM_WAVES"); const int v = e ? atoi(e) : 4; return (v == 8 || v == 12) ? v : 4; }();
-    return w;
-}
 int64_t wgrad_blocks(int64_t n_rows) {
     int64_t b = (n_rows + 31) / 32;
     if (b < 1) b = 1;
@@ -828,15 +772,10 @@ extern "C" int gode_gn_time_gemm_f32(const gode_lincomb_t* xin, int64_t n_rows, 
         const int nj = (int)(d_in / 16);
         const size_t lds = ((size_t)d_in * (d_in + 4) + 3 * d_in) * sizeof(float);
         const int64_t blocks = fwd_blocks(n_rows);
-#define GODE_FWD_LAUNCH(NJV, CGV, NWV, NBLK)                                                        \
-        { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV, NWV>, lds); if (rc) return rc;                  \
-          hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV, NWV>), dim3((unsigned)(NBLK)), dim3(64 * NWV), lds, s, \
-                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S, gemm_dbg()); }
 #define GODE_FWD(NJV, CGV)                                                                          \
-        { const int nw = fwd_waves();                                                               \
-          if (nw == 12) GODE_FWD_LAUNCH(NJV, CGV, 12, blocks_nw(n_rows, 12, 256))                   \
-          else if (nw == 8) GODE_FWD_LAUNCH(NJV, CGV, 8, blocks_nw(n_rows, 8, 512))                 \
-          else GODE_FWD_LAUNCH(NJV, CGV, 4, blocks)                                                 \
+        { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
+          hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
+                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S);                 \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_FWD)
 #undef GODE_FWD
@@ -940,8 +879,4 @@ extern "C" int gode_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t
                        (int)groups, eps, gamma, beta, dS, (int)d_out, has_time, dW_part);
     GODE_LAUNCH_CHECK();
     return 0;
-}
-
-extern "C" int gode_debug_read(unsigned long long* host_out, int n) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
 }

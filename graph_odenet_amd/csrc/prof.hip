@@ -10,7 +10,7 @@ struct GodeProf {
     int capacity;
     int count;
     std::vector<hipEvent_t> ev;      // 2*capacity
-    std::vector<int64_t> d, rows;
+    std::vector<int64_t> d, rows, extra;
 };
 
 // process-global on purpose: torch's autograd engine runs backward on its own thread
@@ -20,7 +20,7 @@ extern "C" void* gode_prof_create(int capacity) {
     if (capacity <= 0) return nullptr;
     GodeProf* p = new GodeProf();
     p->capacity = capacity; p->count = 0;
-    p->ev.resize(2 * (size_t)capacity); p->d.resize(capacity); p->rows.resize(capacity);
+    p->ev.resize(2 * (size_t)capacity); p->d.resize(capacity); p->rows.resize(capacity); p->extra.resize(capacity);
     for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { delete p; return nullptr; }
     return p;
 }
@@ -35,7 +35,7 @@ extern "C" void gode_prof_enable(void* prof) { g_prof = (GodeProf*)prof; }
 extern "C" void gode_prof_reset(void* prof) { if (prof) ((GodeProf*)prof)->count = 0; }
 extern "C" int gode_prof_count(void* prof) { return prof ? ((GodeProf*)prof)->count : 0; }
 
-extern "C" int gode_prof_read(void* prof, float* ms, int64_t* d, int64_t* rows, int max_n) {
+extern "C" int gode_prof_read(void* prof, float* ms, int64_t* d, int64_t* rows, int64_t* extra, int max_n) {
     GodeProf* p = (GodeProf*)prof;
     if (!p || !ms) return GODE_E_NULLPTR;
     int n = p->count < max_n ? p->count : max_n;
@@ -46,15 +46,16 @@ extern "C" int gode_prof_read(void* prof, float* ms, int64_t* d, int64_t* rows, 
         if (e != hipSuccess) return (int)e;
         if (d) d[i] = p->d[i];
         if (rows) rows[i] = p->rows[i];
+        if (extra) extra[i] = p->extra[i];
     }
     return n;
 }
 
-int gode_prof_begin(hipStream_t s, int64_t d, int64_t rows) {
+int gode_prof_begin(hipStream_t s, int64_t d, int64_t rows, int64_t extra) {
     GodeProf* p = g_prof;
     if (!p || p->count >= p->capacity) return -1;
     const int i = p->count;
-    p->d[i] = d; p->rows[i] = rows;
+    p->d[i] = d; p->rows[i] = rows; p->extra[i] = extra;
     (void)hipEventRecord(p->ev[2 * i], s);
     return i;
 }

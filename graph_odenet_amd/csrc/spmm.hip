@@ -197,7 +197,7 @@ int launch_vec4(const int* rowptr, const int* col, const float* val, const int4*
     const int64_t threads = (int64_t)n_items * LPR;
     const int64_t blocks = (threads + 255) / 256;
     if (blocks > 0) {
-        const int slot = gode_prof_begin(s, (int64_t)LPR * 4, n_items);
+        const int slot = gode_prof_begin(s, (int64_t)LPR * 4, n_items, (int64_t)ep.pre.n + ep.cot.n + (ep.Y2 ? 1 : 0));
         hipLaunchKernelGGL(spmm_vec4_kernel<LPR>, dim3((unsigned)blocks), dim3(256), 0, s,
                            rowptr, col, val, items, n_items, partial, X, ldx, Y, ldy, ep);
         gode_prof_end(s, slot);

@@ -235,14 +235,15 @@ int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, float* a, fl
  * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 fast-path launch
  * records a start/stop event pair on its stream (up to `capacity` launches).
  * gode_prof_read waits for the recorded events and returns the number of launches read, with
- * per-launch milliseconds, feature width d and record count. */
+ * per-launch milliseconds, feature width d, record count and `extra` = number of additional
+ * n_rows x d operand arrays the epilogue read or wrote (pre terms + cotangent terms + Y2). */
 void* gode_prof_create(int capacity);
 void  gode_prof_destroy(void* prof);
 void  gode_prof_enable(void* prof /* NULL = off */);
 void  gode_prof_reset(void* prof);
 int   gode_prof_count(void* prof);
 int   gode_prof_read(void* prof, float* ms /* host */, int64_t* d /* host, nullable */,
-                     int64_t* rows /* host, nullable */, int max_n);
+                     int64_t* rows /* host, nullable */, int64_t* extra /* host, nullable */, int max_n);
 
 #ifdef __cplusplus
 }
