@@ -44,7 +44,7 @@ class GcnOdeFunc(ctypes.Structure):
 
 class Rk4Workspace(ctypes.Structure):
     """Mirror of gode_rk4_workspace_t."""
-    _fields_ = [("S", ctypes.c_void_p), ("dZ", ctypes.c_void_p), ("dS", ctypes.c_void_p),
+    _fields_ = [("S", ctypes.c_void_p), ("dZ", ctypes.c_void_p), ("dS", ctypes.c_void_p), ("S2", ctypes.c_void_p),
                 ("ky", ctypes.c_void_p * 4), ("ka", ctypes.c_void_p * 4), ("ktheta", ctypes.c_void_p * 4),
                 ("wpart", ctypes.c_void_p), ("gpart", ctypes.c_void_p), ("bpart", ctypes.c_void_p),
                 ("colsum_scratch", ctypes.c_void_p)]

@@ -7,28 +7,31 @@
 // synchronisation, which also makes the call capturable into a HIP graph by the caller.
 // Launch sequence per stage = graph_odenet_amd/gcn_ode.py (GcnOdeField / GcnOdeAdjointField).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
-const float C38[4] = {0.f, 1.f / 3.f, 2.f / 3.f, 1.f};
-const float A38[4][3] = {{0.f, 0.f, 0.f}, {1.f / 3.f, 0.f, 0.f}, {-1.f / 3.f, 1.f, 0.f}, {1.f, -1.f, 1.f}};
-const float B38[4] = {1.f / 8.f, 3.f / 8.f, 3.f / 8.f, 1.f / 8.f};
+// step size, stage times and h*coefficient products are formed in double and rounded once, exactly as the
+// Python driver (solver.py) does, so both drivers feed identical fp32 coefficients to the kernels
+const double C38[4] = {0.0, 1.0 / 3.0, 2.0 / 3.0, 1.0};
+const double A38[4][3] = {{0.0, 0.0, 0.0}, {1.0 / 3.0, 0.0, 0.0}, {-1.0 / 3.0, 1.0, 0.0}, {1.0, -1.0, 1.0}};
+const double B38[4] = {1.0 / 8.0, 3.0 / 8.0, 3.0 / 8.0, 1.0 / 8.0};
 
 // terms of  y + h * sum_{j<s} A38[s][j] * k[j]
-gode_lincomb_t stage_terms(const float* y, float* const* k, int s, float h) {
+gode_lincomb_t stage_terms(const float* y, float* const* k, int s, double h) {
     gode_lincomb_t lc;
     lc.n = 0;
     lc.coef[lc.n] = 1.f; lc.ptr[lc.n] = y; ++lc.n;
     for (int j = 0; j < s; ++j)
-        if (A38[s][j] != 0.f) { lc.coef[lc.n] = h * A38[s][j]; lc.ptr[lc.n] = k[j]; ++lc.n; }
+        if (A38[s][j] != 0.0) { lc.coef[lc.n] = (float)(h * A38[s][j]); lc.ptr[lc.n] = k[j]; ++lc.n; }
     return lc;
 }
 // terms of  y + h * sum_{j<3} B38[j] * k[j]   (the last stage is folded into the producing launch)
-gode_lincomb_t combine_terms(const float* y, float* const* k, float h) {
+gode_lincomb_t combine_terms(const float* y, float* const* k, double h) {
     gode_lincomb_t lc;
     lc.n = 0;
     lc.coef[lc.n] = 1.f; lc.ptr[lc.n] = y; ++lc.n;
-    for (int j = 0; j < 3; ++j) { lc.coef[lc.n] = h * B38[j]; lc.ptr[lc.n] = k[j]; ++lc.n; }
+    for (int j = 0; j < 3; ++j) { lc.coef[lc.n] = (float)(h * B38[j]); lc.ptr[lc.n] = k[j]; ++lc.n; }
     return lc;
 }
 
@@ -65,18 +68,18 @@ extern "C" int gode_gcn_ode_rk4_forward(const gode_gcn_odefunc_t* f, float* y, f
     if (n_steps <= 0 || f->n <= 0 || f->d <= 0) return GODE_E_SHAPE;
     if (!ws->S || !ws->ky[0] || !ws->ky[1] || !ws->ky[2] || !ws->ky[3]) return GODE_E_NULLPTR;
     const int64_t n = f->n, d = f->d;
-    const float h = (t1 - t0) / n_steps;
+    const double h = ((double)t1 - (double)t0) / n_steps;
     float* cur = y;
     float* k[4] = {ws->ky[0], ws->ky[1], ws->ky[2], ws->ky[3]};
     for (int i = 0; i < n_steps; ++i) {
-        const float t = t0 + i * h;
+        const double t = (double)t0 + i * h;
         for (int s = 0; s < 4; ++s) {
             gode_lincomb_t xin = stage_terms(cur, k, s, h);
             GODE_TRY(gode_gn_time_gemm_f32(&xin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1,
-                                           t + C38[s] * h, ws->S, stream));
+                                           (float)(t + C38[s] * h), ws->S, stream));
             gode_spmm_epilogue_t ep = {};
             ep.bias = f->b; ep.relu = 1; ep.alpha = 1.f;
-            if (s == 3) { ep.pre = combine_terms(cur, k, h); ep.alpha = h * B38[3]; }
+            if (s == 3) { ep.pre = combine_terms(cur, k, h); ep.alpha = (float)(h * B38[3]); }
             GODE_TRY(spmm(f->A, ws->S, k[s], d, &ep, stream));
         }
         float* tmp = cur; cur = k[3]; k[3] = tmp;      // k[3] holds the new solution
@@ -85,6 +88,37 @@ extern "C" int gode_gcn_ode_rk4_forward(const gode_gcn_odefunc_t* f, float* y, f
     return 0;
 }
 
+namespace {
+
+// Side stream + events for the two-chain schedule of the adjoint solve (created once per process/device).
+struct Overlap {
+    hipStream_t side = nullptr;
+    hipEvent_t sp = nullptr, gf = nullptr, spt = nullptr, wg = nullptr;
+    bool ok = false;
+};
+Overlap* overlap_ctx() {
+    static Overlap ctx = [] {
+        Overlap c;
+        const char* e = getenv("GODE_OVERLAP");
+        if (e && atoi(e) == 0) return c;
+        if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return c;
+        bool ok = true;
+        for (hipEvent_t* ev : {&c.sp, &c.gf, &c.spt, &c.wg})
+            ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+        c.ok = ok;
+        return c;
+    }();
+    return &ctx;
+}
+#define GODE_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+}  // namespace
+
+// Adjoint solve.  Per stage the launches form two chains:
+//   F (forward recompute):  Gf(s) = [t|GN(y_s)]W  ->  Sp(s) = relu(A . + b) (+ masked cotangent dZ)
+//   B (vector-Jacobian)  :  SpT(s) = A^T dZ  ->  Gb(s) (k_a)  |  Wg(s) (dW partials)  |  colsum(dZ), reductions
+// Gf(s+1) needs only k_y(s), so it runs on a side stream under the memory-bound SpT(s), and Wg(s) runs on the
+// side stream beside Gb(s) (S is double-buffered when ws->S2 is given; events order every buffer reuse).
 extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, float* a, float* theta,
                                         float** y_result, float** a_result,
                                         const gode_rk4_workspace_t* ws, float t0, float t1, int32_t n_steps,
@@ -97,52 +131,91 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
     if (f->groups > 0 && (!ws->gpart || !ws->bpart)) return GODE_E_NULLPTR;
     const int64_t n = f->n, d = f->d;
     const int64_t nW = (d + 1) * d, P = gode_gcn_ode_theta_len(d);
-    const float h = (t1 - t0) / n_steps;             // negative: the adjoint runs from t0 (later) to t1 (earlier)
+    const double h = ((double)t1 - (double)t0) / n_steps;   // negative: the adjoint runs from t0 (later) to t1 (earlier)
     hipStream_t hs = (hipStream_t)stream;
+    Overlap* ov = overlap_ctx();
+    const bool two = ov->ok && ws->S2 != nullptr;
+    void* side = two ? (void*)ov->side : stream;
+    float* Sbuf[2] = {ws->S, two ? ws->S2 : ws->S};
     float* ycur = y; float* acur = a;
     float* ky[4] = {ws->ky[0], ws->ky[1], ws->ky[2], ws->ky[3]};
     float* ka[4] = {ws->ka[0], ws->ka[1], ws->ka[2], ws->ka[3]};
     const int64_t wparts = gode_wgrad_parts(n), gparts = gode_gemm_bwd_parts(n);
-    for (int i = 0; i < n_steps; ++i) {
-        const float t = t0 + i * h;
-        for (int s = 0; s < 4; ++s) {
-            const float ts = t + C38[s] * h;
-            gode_lincomb_t yin = stage_terms(ycur, ky, s, h);
-            gode_lincomb_t ain = stage_terms(acur, ka, s, h);
-            GODE_TRY(gode_gn_time_gemm_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1, ts, ws->S, stream));
-            gode_spmm_epilogue_t ep = {};
-            ep.bias = f->b; ep.relu = 1; ep.alpha = 1.f;
-            ep.cot = ain;
-            for (int j = 0; j < ep.cot.n; ++j) ep.cot.coef[j] = -ep.cot.coef[j];     // cotangent of the VJP is -a
-            ep.Y2 = ws->dZ;
-            gode_lincomb_t apre; apre.n = 0;
-            if (s == 3) { ep.pre = combine_terms(ycur, ky, h); ep.alpha = h * B38[3]; apre = combine_terms(acur, ka, h); }
-            GODE_TRY(spmm(f->A, ws->S, ky[s], d, &ep, stream));
-            GODE_TRY(spmm(f->AT, ws->dZ, ws->dS, d, nullptr, stream));
-            GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->W, d, 1, ws->dS,
-                                               s == 3 ? h * B38[3] : 1.f, s == 3 ? &apre : nullptr, ka[s],
-                                               f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr, stream));
-            GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, ws->dS, d, 1, ws->wpart, stream));
-            float* kt = ws->ktheta[s];
-            GODE_TRY(gode_reduce_parts_f32(kt, ws->wpart, wparts, nW, 1.f, 0, stream));
-            hipLaunchKernelGGL(theta_fixup_kernel, dim3(1), dim3(256), 0, hs, kt, f->W, ts, (int)d, P - 1);
-            GODE_LAUNCH_CHECK();
-            GODE_TRY(gode_colsum_f32(kt + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, stream));
-            if (f->groups > 0) {
-                GODE_TRY(gode_reduce_parts_f32(kt + nW + d, ws->gpart, gparts, d, 1.f, 0, stream));
-                GODE_TRY(gode_reduce_parts_f32(kt + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
-            } else {
-                hipError_t e = hipMemsetAsync(kt + nW + d, 0, (size_t)2 * d * sizeof(float), hs);
-                if (e != hipSuccess) return (int)e;
-            }
+    const int total = 4 * n_steps;
+
+    auto launch_gf = [&](int g, void* st) -> int {         // forward dense part of global stage g
+        const int i = g / 4, s = g % 4;
+        const float ts = (float)((double)t0 + i * h + C38[s] * h);
+        gode_lincomb_t yin = stage_terms(ycur, ky, s, h);
+        return gode_gn_time_gemm_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1, ts, Sbuf[g & 1], st);
+    };
+
+    GODE_TRY(launch_gf(0, stream));
+    bool wg_pending = false;
+    for (int g = 0; g < total; ++g) {
+        const int i = g / 4, s = g % 4;
+        const float ts = (float)((double)t0 + i * h + C38[s] * h);
+        gode_lincomb_t yin = stage_terms(ycur, ky, s, h);     // terms of THIS stage (used by Gb / Wg below)
+        gode_lincomb_t ain = stage_terms(acur, ka, s, h);
+        gode_spmm_epilogue_t ep = {};
+        ep.bias = f->b; ep.relu = 1; ep.alpha = 1.f;
+        ep.cot = ain;
+        for (int j = 0; j < ep.cot.n; ++j) ep.cot.coef[j] = -ep.cot.coef[j];     // cotangent of the VJP is -a
+        ep.Y2 = ws->dZ;
+        gode_lincomb_t apre; apre.n = 0;
+        if (s == 3) { ep.pre = combine_terms(ycur, ky, h); ep.alpha = (float)(h * B38[3]); apre = combine_terms(acur, ka, h); }
+        if (two && g > 0) GODE_HIP(hipStreamWaitEvent(hs, ov->gf, 0));          // S of this stage was produced on the side stream
+        GODE_TRY(spmm(f->A, Sbuf[g & 1], ky[s], d, &ep, stream));               // Sp(g): k_y (or new y) and dZ
+        // pointers as the NEXT stage will see them (the y-chain swaps buffers after stage 3)
+        float* ycur_n = ycur; float* ky_n[4] = {ky[0], ky[1], ky[2], ky[3]};
+        if (s == 3) { ycur_n = ky[3]; ky_n[3] = ycur; }
+        if (two) {
+            GODE_HIP(hipEventRecord(ov->sp, hs));
+            GODE_HIP(hipStreamWaitEvent(ov->side, ov->sp, 0));
         }
-        // theta <- theta + h * sum b_s ktheta_s   (packed small components, one launch)
-        gode_lincomb_t tc;
-        tc.n = 5; tc.coef[0] = 1.f; tc.ptr[0] = theta;
-        for (int s = 0; s < 4; ++s) { tc.coef[1 + s] = h * B38[s]; tc.ptr[1 + s] = ws->ktheta[s]; }
-        GODE_TRY(gode_lincomb_f32(theta, &tc, P, stream));
-        float* tmp = ycur; ycur = ky[3]; ky[3] = tmp;
-        tmp = acur; acur = ka[3]; ka[3] = tmp;
+        if (g + 1 < total) {                                                    // Gf(g+1) beside SpT(g)
+            const int i2 = (g + 1) / 4, s2 = (g + 1) % 4;
+            gode_lincomb_t yin2 = stage_terms(ycur_n, ky_n, s2, h);
+            GODE_TRY(gode_gn_time_gemm_f32(&yin2, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1,
+                                           (float)((double)t0 + i2 * h + C38[s2] * h), Sbuf[(g + 1) & 1], side));
+            if (two) GODE_HIP(hipEventRecord(ov->gf, ov->side));
+        }
+        if (two && wg_pending) GODE_HIP(hipStreamWaitEvent(hs, ov->wg, 0));     // previous Wg still reads dS
+        GODE_TRY(spmm(f->AT, ws->dZ, ws->dS, d, nullptr, stream));              // SpT(g)
+        if (two) {
+            GODE_HIP(hipEventRecord(ov->spt, hs));
+            GODE_HIP(hipStreamWaitEvent(ov->side, ov->spt, 0));
+        }
+        float* kt = ws->ktheta[s];
+        GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, ws->dS, d, 1, ws->wpart, side));   // Wg(g)
+        GODE_TRY(gode_reduce_parts_f32(kt, ws->wpart, wparts, nW, 1.f, 0, side));
+        hipLaunchKernelGGL(theta_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)side, kt, f->W, ts, (int)d, P - 1);
+        GODE_LAUNCH_CHECK();
+        if (two) { GODE_HIP(hipEventRecord(ov->wg, ov->side)); wg_pending = true; }
+        GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->W, d, 1, ws->dS,
+                                           s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &apre : nullptr, ka[s],
+                                           f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr, stream));   // Gb(g)
+        GODE_TRY(gode_colsum_f32(kt + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, stream));
+        if (f->groups > 0) {
+            GODE_TRY(gode_reduce_parts_f32(kt + nW + d, ws->gpart, gparts, d, 1.f, 0, stream));
+            GODE_TRY(gode_reduce_parts_f32(kt + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
+        } else {
+            GODE_HIP(hipMemsetAsync(kt + nW + d, 0, (size_t)2 * d * sizeof(float), hs));
+        }
+        if (s == 3) {
+            // theta <- theta + h * sum b_s ktheta_s   (packed small components, one launch)
+            if (two) { GODE_HIP(hipStreamWaitEvent(hs, ov->wg, 0)); wg_pending = false; }
+            gode_lincomb_t tc;
+            tc.n = 5; tc.coef[0] = 1.f; tc.ptr[0] = theta;
+            for (int q = 0; q < 4; ++q) { tc.coef[1 + q] = (float)(h * B38[q]); tc.ptr[1 + q] = ws->ktheta[q]; }
+            GODE_TRY(gode_lincomb_f32(theta, &tc, P, stream));
+            float* tmp = ycur; ycur = ky[3]; ky[3] = tmp;
+            tmp = acur; acur = ka[3]; ka[3] = tmp;
+        }
+    }
+    if (two) {                      // join: nothing of this call is left running on the side stream
+        GODE_HIP(hipEventRecord(ov->gf, ov->side));
+        GODE_HIP(hipStreamWaitEvent(hs, ov->gf, 0));
     }
     *y_result = ycur;
     *a_result = acur;

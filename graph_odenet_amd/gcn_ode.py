@@ -78,6 +78,9 @@ class _Shared:
         if adjoint:
             dZ, dS = self.bwd()
             ws.dZ, ws.dS = dZ.data_ptr(), dS.data_ptr()
+            if getattr(self, "S2", None) is None:
+                self.S2 = torch.empty_like(self.S)
+            ws.S2 = self.S2.data_ptr()
             for i in range(4):
                 ws.ka[i] = ka[i].data_ptr()
                 ws.ktheta[i] = kt[i].data_ptr()

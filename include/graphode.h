@@ -199,7 +199,9 @@ int gode_edge_matvec_f32_bwd(const int32_t* edge_row, const float* edge_val, con
  * the *_result pointers (each equals one of the buffers passed in).
  * Adjoint: (y, a, theta) integrate d/dt [y, a, theta] = [f, -a^T df/dy, -a^T df/dtheta]; `theta` is the
  * packed vector [dW ((d+1)*d) | db (d) | dgamma (d) | dbeta (d) | dt (1)] of gode_gcn_ode_theta_len(d)
- * floats and is updated in place. */
+ * floats and is updated in place.  With ws->S2 set, the adjoint runs its forward-recompute chain and its
+ * VJP chain on two streams (one private side stream per process, joined back into `stream` before the
+ * call returns; GODE_OVERLAP=0 disables it): one adjoint solve at a time per process. */
 typedef struct gode_graph {
     const int32_t* rowptr; const int32_t* col; const float* val;      /* CSR, val nullable */
     const int32_t* items;  int64_t n_items;                             /* balanced records (nullable) */
@@ -217,6 +219,7 @@ typedef struct gode_gcn_odefunc {
 
 typedef struct gode_rk4_workspace {
     float* S; float* dZ; float* dS;     /* n x d each (dZ, dS: adjoint only) */
+    float* S2;                          /* nullable: second n x d buffer; enables the two-stream adjoint schedule */
     float* ky[4]; float* ka[4];         /* n x d stage buffers (ka: adjoint only) */
     float* ktheta[4];                   /* gode_gcn_ode_theta_len(d) floats each (adjoint only) */
     float* wpart;                       /* gode_wgrad_parts(n) * (d+1)*d floats */

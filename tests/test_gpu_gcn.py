@@ -320,3 +320,44 @@ def test_cpu_tensor_is_refused():
     from graph_odenet_amd.odeint import odeint_adjoint
     with pytest.raises(RuntimeError):
         odeint_adjoint(torch.nn.Linear(2, 2), torch.zeros(3, 2), torch.tensor([0., 1.]))
+
+
+def test_native_rk4_driver_matches_python_driver():
+    """The one-call C driver (csrc/ode_driver.hip, two-stream adjoint schedule) and the per-stage Python
+    driver issue the same kernels: identical logits, gradients equal to rounding of the partial sums."""
+    from graph_odenet_amd import models, odeint as OI
+    torch.manual_seed(0)
+    n, d = 3000, 128
+    r = torch.randint(0, n, (30000,)); c = torch.randint(0, n, (30000,))
+    v = torch.rand(30000)
+    v = v / torch.zeros(n).index_add_(0, r, v)[r]
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n)).to(dev())
+    x = torch.randn(n, d, device=dev())
+    res = {}
+    for native in (True, False):
+        OI.NATIVE_RK4 = native
+        try:
+            torch.manual_seed(1)
+            blk = models.ODEBlock(models.ODEfunc(d), method="rk4", step_size=0.125).to(dev())
+            xi = x.clone().requires_grad_(True)
+            out = blk(xi, adj)
+            out.square().sum().backward()
+            res[native] = (out.detach(), xi.grad, [p.grad.clone() for p in blk.parameters()], blk.nfe)
+        finally:
+            OI.NATIVE_RK4 = True
+    assert res[True][3] == res[False][3] == 64
+    close(res[True][0], res[False][0], 1e-6, "state")
+    close(res[True][1], res[False][1], 1e-6, "gx")
+    for a, b in zip(res[True][2], res[False][2]):
+        close(a, b, 1e-5, "param grad")
+
+
+def test_shape_errors_are_loud():
+    from graph_odenet_amd import graph as G, ops
+    g = G.from_coo(torch.tensor([0, 1], device=dev()), torch.tensor([1, 0], device=dev()), None, 2, 2)
+    with pytest.raises(ValueError):
+        ops.spmm(g, torch.zeros(3, 4, device=dev()))                 # wrong number of rows
+    with pytest.raises(RuntimeError):
+        ops.spmm(g, torch.zeros(2, 4))                                # CPU tensor: no fallback
+    with pytest.raises(TypeError):
+        ops.spmm(g, torch.zeros(2, 4, device=dev(), dtype=torch.float64))
