@@ -590,6 +590,7 @@ __global__ __launch_bounds__(256) void gn_gemm_fwd_generic(LinComb xin, int n_ro
             const int rr = idx / d_out, n = idx % d_out;
             const int row = blk * RB + rr;
             if (row >= n_rows) continue;
+            if (!W) { S[(int64_t)row * d_out + n] = xs[rr * d_in + n]; continue; }      // stand-alone GroupNorm
             float acc = has_time ? t * W[n] : 0.f;
             for (int k = 0; k < d_in; ++k) acc = fmaf(xs[rr * d_in + k], W[(int64_t)(k + has_time) * d_out + n], acc);
             S[(int64_t)row * d_out + n] = acc;
@@ -615,9 +616,12 @@ __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_ro
             const int rr = idx / d_in, i = idx % d_in;
             const int row = blk * RB + rr;
             float acc = 0.f;
-            if (row < n_rows)
-                for (int n = 0; n < d_out; ++n)
-                    acc = fmaf(dS[(int64_t)row * d_out + n], W[(int64_t)(i + has_time) * d_out + n], acc);
+            if (row < n_rows) {
+                if (!W) acc = dS[(int64_t)row * d_out + i];                               // stand-alone GroupNorm: dy given
+                else
+                    for (int n = 0; n < d_out; ++n)
+                        acc = fmaf(dS[(int64_t)row * d_out + n], W[(int64_t)(i + has_time) * d_out + n], acc);
+            }
             dy[idx] = acc;
         }
         __syncthreads();
@@ -877,6 +881,59 @@ extern "C" int gode_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t
     rc = set_lds(wgrad_generic, lds); if (rc) return rc;
     hipLaunchKernelGGL(wgrad_generic, dim3((unsigned)blocks), dim3(256), lds, s, lc, (int)n_rows, (int)d_in,
                        (int)groups, eps, gamma, beta, dS, (int)d_out, has_time, dW_part);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ---- stand-alone GroupNorm on an (n_rows x d) matrix (nn.GroupNorm applied to a 2-D tensor, GCN/models.py:88,133-156)
+// The same generic kernels with the dense product switched off.
+extern "C" int64_t gode_group_norm_parts(int64_t n_rows) {
+    int64_t b = (n_rows + RB - 1) / RB; if (b > 2048) b = 2048; if (b < 1) b = 1;
+    return b;
+}
+
+extern "C" int gode_group_norm_f32_fwd(const float* x, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                                       const float* gamma, const float* beta, float* y, void* stream)
+{
+    if (n_rows < 0 || d <= 0 || groups <= 0 || d % groups) return GODE_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!x || !y) return GODE_E_NULLPTR;
+    if (n_rows > INT32_MAX || d > 2048) return GODE_E_RANGE;
+    gode_lincomb_t lc; lc.n = 1; lc.coef[0] = 1.f; lc.ptr[0] = x;
+    const size_t lds = ((size_t)RB * d + (size_t)RB * groups * 2) * sizeof(float);
+    int rc = set_lds(gn_gemm_fwd_generic, lds); if (rc) return rc;
+    hipLaunchKernelGGL(gn_gemm_fwd_generic, dim3((unsigned)gode_group_norm_parts(n_rows)), dim3(256), lds, (hipStream_t)stream,
+                       make_lincomb(&lc), (int)n_rows, (int)d, (int)groups, eps, gamma, beta, (const float*)nullptr,
+                       (int)d, 0, 0.f, y);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_group_norm_f32_bwd(const float* x, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                                       const float* gamma, const float* dy, float* dx,
+                                       float* dgamma_part, float* dbeta_part, void* stream)
+{
+    if (n_rows < 0 || d <= 0 || groups <= 0 || d % groups) return GODE_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!x || !dy || !dx) return GODE_E_NULLPTR;
+    if ((dgamma_part == nullptr) != (dbeta_part == nullptr)) return GODE_E_NULLPTR;
+    if (n_rows > INT32_MAX || d > 2048) return GODE_E_RANGE;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n_part = gode_group_norm_parts(n_rows);
+    if (dgamma_part) {
+        hipError_t e = hipMemsetAsync(dgamma_part, 0, (size_t)n_part * d * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(dbeta_part, 0, (size_t)n_part * d * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    gode_lincomb_t lc; lc.n = 1; lc.coef[0] = 1.f; lc.ptr[0] = x;
+    LinComb none = make_lincomb(nullptr);
+    const size_t g2 = (size_t)RB * groups * 2;
+    const size_t lds = ((size_t)RB * d * 2 + g2 * 2) * sizeof(float);
+    int rc = set_lds(gn_gemm_bwd_generic, lds); if (rc) return rc;
+    hipLaunchKernelGGL(gn_gemm_bwd_generic, dim3((unsigned)n_part), dim3(256), lds, s, make_lincomb(&lc), (int)n_rows, (int)d,
+                       (int)groups, eps, gamma, (const float*)nullptr, (int)d, 0, dy, 1.f, none, dx, dgamma_part, dbeta_part);
     GODE_LAUNCH_CHECK();
     return 0;
 }

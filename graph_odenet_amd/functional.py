@@ -71,3 +71,43 @@ class _GraphAggregateFn(torch.autograd.Function):
 
 def graph_aggregate(graph, S, bias=None, relu=False):
     return _GraphAggregateFn.apply(graph, S, bias, bool(relu))
+
+
+class _GroupNorm2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        x = x.contiguous()
+        ctx.meta = (groups, eps)
+        ctx.save_for_backward(x, gamma)
+        return ops.group_norm_fwd(x, groups, eps, gamma, beta)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        groups, eps = ctx.meta
+        dx, dgp, dbp = ops.group_norm_bwd(x, groups, eps, gamma, dy.contiguous(), want_affine_grads=gamma is not None)
+        gg = gb = None
+        if gamma is not None:
+            gg = torch.empty_like(gamma)
+            gb = torch.empty_like(gamma)
+            ops.reduce_parts_(gg, dgp)
+            ops.reduce_parts_(gb, dbp)
+        return dx, gg, gb, None, None
+
+
+class GroupNorm(torch.nn.GroupNorm):
+    """nn.GroupNorm whose 2-D (nodes x channels) GPU path runs on libgraphode.
+
+    Same parameters / state_dict keys as nn.GroupNorm.  Besides keeping the normalisation on the same
+    arithmetic as the fused ODE kernels, this avoids torch-ROCm's own GroupNorm backward on 2-D inputs, whose
+    dgamma / dbeta are wrong for more than a few hundred rows (torch 2.10.0+rocm7.0; tools/dev/gn_torch_check.py:
+    CPU vs GPU differ by 100 % at 3327 x 128)."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32:
+            return _GroupNorm2dFn.apply(x, self.weight, self.bias, self.num_groups, self.eps)
+        return super().forward(x)
+
+
+def group_norm(num_groups, num_channels):
+    return GroupNorm(num_groups, num_channels)

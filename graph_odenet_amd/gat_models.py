@@ -20,11 +20,18 @@ class ODEfunc(nn.Module):
     def set_adj(self, src, tgt, Mtgt):
         self.gc1.set_adj(src, tgt, Mtgt)
 
+    _gode_counts_nfe = True
+
     def forward(self, t, x):
         self.nfe += 1
         xn = self.norm1(x)
         ttx = torch.cat([torch.ones_like(xn[:, :1]) * t, xn], 1)
         return F.relu(self.gc1(ttx))
+
+    def gode_fields(self, y0):
+        """Hook for graph_odenet_amd.odeint: fused forward / adjoint kernel sequences (gat_ode.py)."""
+        from .gat_ode import gat_fields
+        return gat_fields(self, y0)
 
 
 class _GatPlan(_PlanModel):

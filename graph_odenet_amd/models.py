@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .functional import gn_time_linear, graph_aggregate
+from .functional import GroupNorm, gn_time_linear, graph_aggregate
 from .gcn_ode import GcnOdeAdjointField, GcnOdeField, GcnOdeSpec, _Shared, odefunc_apply
 from .graph import as_graph
 from .layers import FixedGraphConvolution, GraphConvolution
@@ -31,7 +31,8 @@ from .odeint import odeint_adjoint as odeint
 
 
 def _gn(dim):
-    return nn.GroupNorm(min(32, dim), dim)
+    """nn.GroupNorm(min(32, dim), dim) of the reference; the subclass routes 2-D GPU inputs to libgraphode."""
+    return GroupNorm(min(32, dim), dim)
 
 
 class _PlanModel(nn.Module):
@@ -123,7 +124,7 @@ class ODEfunc(nn.Module):
 class ODEfunc2(nn.Module):
     """Two stacked (FixedGC -> relu -> GroupNorm), time column re-attached before each convolution
     (reference: GCN/models.py:551-575).  norm1 is folded into the prologue of the second dense product;
-    norm2 has no consumer inside f and stays a PyTorch op."""
+    norm2 has no consumer inside f and runs as the stand-alone GroupNorm kernel."""
 
     def __init__(self, dim, dropout):
         super(ODEfunc2, self).__init__()

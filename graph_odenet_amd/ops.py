@@ -44,12 +44,18 @@ def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None, p
     d = X.shape[1]
     if bias is not None and bias.numel() != d:
         raise ValueError("spmm: bias has %d elements, expected %d" % (bias.numel(), d))
+    ldy = d
     if out is None:
         out = torch.empty(graph.n_rows, d, dtype=torch.float32, device=X.device)
     else:
-        _need(out, "out")
         if tuple(out.shape) != (graph.n_rows, d):
             raise ValueError("spmm: out has wrong shape")
+        if out.is_contiguous():
+            _need(out, "out")
+        else:                                  # a column block of a wider row-major matrix (leading dimension ldy)
+            if not out.is_cuda or out.dtype != torch.float32 or out.stride(1) != 1 or out.stride(0) < d:
+                raise ValueError("spmm: out must be contiguous or a unit-stride column block of a row-major matrix")
+            ldy = out.stride(0)
     ep = None
     if bias is not None or relu or cot_terms is not None or pre_terms is not None or alpha != 1.0:
         ep = _lib.SpmmEpilogue()
@@ -72,7 +78,7 @@ def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None, p
     rc = lib.gode_spmm_csr_f32(ptr(graph.rowptr), ptr(graph.col), ptr(graph.val),
                                ptr(graph.items), graph.n_items,
                                ptr(graph.long_rows), graph.n_long, ptr(partial),
-                               ptr(X), d, ptr(out), d, graph.n_rows, d,
+                               ptr(X), d, ptr(out), ldy, graph.n_rows, d,
                                ctypes.byref(ep) if ep is not None else None, stream_ptr())
     check(rc, "gode_spmm_csr_f32")
     return (out, out2) if cot_terms is not None else out
@@ -236,11 +242,13 @@ def edge_softmax_logits(P, o, bw, src, tgt):
     return a, amax
 
 
-def edge_softmax_agg_fwd(Mt, src, tgt, P, o, bf, a, amax, eps):
+def edge_softmax_agg_fwd(Mt, src, tgt, P, o, bf, a, amax, eps, out=None):
     lib = _lib.load()
     _need(P, "P"); _need(bf, "bf"); _need(a, "a"); _need(amax, "amax")
     n = Mt.n_rows
-    out = torch.empty(n, o, dtype=torch.float32, device=P.device)
+    if out is None:
+        out = torch.empty(n, o, dtype=torch.float32, device=P.device)
+    _need(out, "out")
     w = torch.zeros(src.numel(), dtype=torch.float32, device=P.device)
     den = torch.empty(n, dtype=torch.float32, device=P.device)
     check(lib.gode_edge_softmax_agg_f32_fwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ptr(P),
@@ -284,3 +292,29 @@ def edge_matvec_bwd(edge_row, edge_val, src, A, X, dM, want_dA=True, want_dx=Tru
     check(lib.gode_edge_matvec_f32_bwd(ptr(edge_row), ptr(edge_val), ptr(src), ptr(A), ptr(X), h, ptr(dM), h, h, E,
                                        ptr(dA), ptr(dxe), stream_ptr()), "gode_edge_matvec_f32_bwd")
     return dA, dxe
+
+
+# ---- stand-alone GroupNorm on 2-D node features ---------------------------------------------------
+def group_norm_fwd(x, groups, eps, gamma, beta):
+    lib = _lib.load()
+    _need(x, "x"); _need(gamma, "gamma"); _need(beta, "beta")
+    n, d = x.shape
+    y = torch.empty_like(x)
+    check(lib.gode_group_norm_f32_fwd(ptr(x), n, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(y), stream_ptr()),
+          "gode_group_norm_f32_fwd")
+    return y
+
+
+def group_norm_bwd(x, groups, eps, gamma, dy, want_affine_grads=True):
+    lib = _lib.load()
+    _need(x, "x"); _need(gamma, "gamma"); _need(dy, "dy")
+    n, d = x.shape
+    dx = torch.empty_like(x)
+    dg = db = None
+    if want_affine_grads:
+        n_part = lib.gode_group_norm_parts(n)
+        dg = torch.empty(n_part, d, dtype=torch.float32, device=x.device)
+        db = torch.empty(n_part, d, dtype=torch.float32, device=x.device)
+    check(lib.gode_group_norm_f32_bwd(ptr(x), n, d, groups, float(eps), ptr(gamma), ptr(dy), ptr(dx), ptr(dg), ptr(db),
+                                      stream_ptr()), "gode_group_norm_f32_bwd")
+    return dx, dg, db

@@ -134,6 +134,16 @@ int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin /* host */, int64_t n_ro
                               const gode_lincomb_t* pre /* host, nullable */, float* dx,
                               float* dgamma_part, float* dbeta_part, void* stream);
 
+/* Stand-alone GroupNorm(groups, d) on an n_rows x d matrix (the reference applies nn.GroupNorm to 2-D
+ * node-feature tensors: GCN/models.py:88,133-156,565-575) and its backward; block partials of dgamma /
+ * dbeta have gode_group_norm_parts(n_rows) rows. */
+int64_t gode_group_norm_parts(int64_t n_rows);
+int gode_group_norm_f32_fwd(const float* x, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                            const float* gamma /* nullable */, const float* beta /* nullable */, float* y, void* stream);
+int gode_group_norm_f32_bwd(const float* x, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                            const float* gamma /* nullable */, const float* dy, float* dx,
+                            float* dgamma_part /* nullable */, float* dbeta_part /* nullable */, void* stream);
+
 /* dW = [1 | xn]^T * dS  ((d_in+has_time) x d_out) as n_part block partials
  * dW_part[n_part][(d_in+has_time)*d_out]; the caller sums over parts
  * (gode_reduce_parts_f32).  With has_time, row 0 holds the plain column sums of dS

@@ -74,6 +74,8 @@ def test_gat_odefunc_vs_reference_golden(golden):
     close(x.grad, g["gx"], 1e-4, "gx")
     close(f.gc1.f.weight.grad, g["g_f_w"], 1e-4, "g f.weight")
     close(f.gc1.w.weight.grad, g["g_w_w"], 1e-4, "g w.weight")
+    close(f.norm1.weight.grad, g["g_gn_w"], 1e-3, "g norm1.weight")      # reference computed these on the CPU
+    close(f.norm1.bias.grad, g["g_gn_b"], 1e-3, "g norm1.bias")
 
 
 def test_gat_ode_block_rk4_vs_oracle_on_citeseer_edges(golden):
@@ -235,3 +237,41 @@ def test_gat_empty_and_isolated():
     M0 = torch.sparse_coo_tensor(torch.zeros(2, 0, dtype=torch.int64), torch.zeros(0), (n, 0)).to(dev())
     out0 = lg(x.to(dev()), src0, src0, M0)
     assert out0.shape == (n, fo) and (out0 == 0).all()
+
+
+@pytest.mark.parametrize("method,opts", [("rk4", {"step_size": 0.25}), (None, None)])
+def test_gat_fused_field_matches_autograd_path(golden, method, opts):
+    """The fused GAT ODE field (gat_ode.py) against the same module driven through torch.autograd
+    (generic field), on Citeseer's edge list: states equal to rounding, all six parameter gradients equal."""
+    from graph_odenet_amd import gat_models, odeint as OI
+    ge = golden("citeseer_gat_edges.npz")
+    n = int(ge["n"])
+    src, tgt = T(ge["src"]).long().to(dev()), T(ge["tgt"]).long().to(dev())
+    e = src.numel()
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(e, device=dev())]), torch.ones(e, device=dev()), (n, e))
+    d = 128
+    torch.manual_seed(5)
+    f = gat_models.ODEfunc(d).to(dev())
+    f.set_adj(src, tgt, Mtgt)
+    x0 = torch.randn(n, d, device=dev())
+    t = torch.tensor([0., 1.], device=dev())
+    res = {}
+    for fused in (True, False):
+        hook = gat_models.ODEfunc.gode_fields
+        if not fused:
+            gat_models.ODEfunc.gode_fields = lambda self, y0: None
+        try:
+            f.zero_grad(); f.nfe = 0
+            xi = x0.clone().requires_grad_(True)
+            out = OI.odeint_adjoint(f, xi, t, 1e-5, 1e-5, method, opts)[1]
+            out.square().sum().backward()
+            res[fused] = (out.detach(), xi.grad.clone(), {k: p.grad.clone() for k, p in f.named_parameters()}, f.nfe)
+        finally:
+            gat_models.ODEfunc.gode_fields = hook
+    tol = 2e-5 if method == "rk4" else 2e-3
+    close(res[True][0], res[False][0], tol, "state")
+    close(res[True][1], res[False][1], tol * 5, "gx")
+    for k in res[True][2]:
+        close(res[True][2][k], res[False][2][k], tol * 5, "grad " + k)
+    if method == "rk4":
+        assert res[True][3] == res[False][3] == 32

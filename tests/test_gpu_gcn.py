@@ -103,6 +103,9 @@ def test_odefunc2_fwd_vjp_vs_reference_golden(golden):
     close(x.grad, g["gx"], 5e-3, "gx")            # ill-conditioned GroupNorm backward (see test_oracle_golden)
     close(f.gc2.bias.grad, g["g__gc2__bias"], 5e-3, "g gc2.bias")
     close(f.gc1.weight.grad, g["g__gc1__weight"], 5e-3, "g gc1.weight")
+    close(f.norm2.weight.grad, g["g__norm2__weight"], 5e-3, "g norm2.weight")
+    close(f.norm2.bias.grad, g["g__norm2__bias"], 5e-3, "g norm2.bias")
+    close(f.norm1.weight.grad, g["g__norm1__weight"], 5e-3, "g norm1.weight")
 
 
 def test_odek_models_run():
@@ -361,3 +364,31 @@ def test_shape_errors_are_loud():
         ops.spmm(g, torch.zeros(2, 4))                                # CPU tensor: no fallback
     with pytest.raises(TypeError):
         ops.spmm(g, torch.zeros(2, 4, device=dev(), dtype=torch.float64))
+
+
+def test_fullnorm_model_grads_vs_cpu_on_cora(golden):
+    """RGCN3fullnorm (GCN/models.py:140-159) at nhid=128 on real Cora: logits and every gradient, including the
+    GroupNorm affine parameters, against the same composition on the CPU (oracle layer + torch CPU GroupNorm)."""
+    from graph_odenet_amd import models
+    from oracle import layers_ref as R
+    import torch.nn.functional as F
+    adj, feats, labels, idx = cora(golden)
+    torch.manual_seed(11)
+    m = models.RGCN3fullnorm(nfeat=feats.shape[1], nhid=128, nclass=7, dropout=0.0)
+    with torch.no_grad():
+        for nm in (m.norm1, m.norm2):
+            nm.weight.uniform_(0.5, 1.5); nm.bias.uniform_(-0.5, 0.5)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x = F.relu(R.graph_convolution(feats, adj, p["gc1.weight"], p["gc1.bias"]))
+    x = F.group_norm(x, 32, p["norm1.weight"], p["norm1.bias"], 1e-5)
+    r = x
+    x = F.relu(R.graph_convolution(x, adj, p["gc2.weight"], p["gc2.bias"]))
+    x = F.group_norm(x, 32, p["norm2.weight"], p["norm2.bias"], 1e-5) + r
+    ref = torch.log_softmax(R.graph_convolution(x, adj, p["gc3.weight"], p["gc3.bias"]), 1)
+    F.nll_loss(ref[idx], labels[idx]).backward()
+    m = m.to(dev())
+    out = m(feats.to(dev()), adj.to(dev()))
+    close(out, ref, what="fullnorm logits")
+    F.nll_loss(out[idx.to(dev())], labels.to(dev())[idx.to(dev())]).backward()
+    for k, q in m.named_parameters():
+        close(q.grad, p[k].grad, 5e-5, "grad " + k)

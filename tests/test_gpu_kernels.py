@@ -176,3 +176,76 @@ def test_gn_time_gemm_fwd_bwd_wgrad(d, groups, n):
     gW = part.sum(0).view(d + 1, d)
     close(gW[1:], W.grad[1:], tol=max(tol, 2e-5) * max(1, n ** 0.5), what="dW")
     close(gW[0] * t, W.grad[0], tol=2e-5 * max(1, n ** 0.5), what="dW time row")
+
+
+@pytest.mark.parametrize("d,dout,groups", [(16, 34, 16), (64, 130, 32), (128, 258, 32), (24, 7, 0)])
+def test_gn_time_gemm_rectangular(d, dout, groups):
+    """d_out != d_in (the GAT node-level projection is d x (2o+2)): generic kernels, same parity bar."""
+    from graph_odenet_amd import ops
+    import torch.nn.functional as F
+    torch.manual_seed(d + dout)
+    n = 777
+    x = torch.randn(n, d, requires_grad=True)
+    gam = (torch.rand(d) + 0.5).requires_grad_(True)
+    bet = (torch.rand(d) - 0.5).requires_grad_(True)
+    W = (torch.randn(d + 1, dout) / d ** 0.5).requires_grad_(True)
+    t = 0.61
+    xn = F.group_norm(x, groups, gam, bet, 1e-5) if groups else x
+    S = torch.cat([torch.full((n, 1), t), xn], 1) @ W
+    dS = torch.randn(n, dout)
+    S.backward(dS)
+    D = dev()
+    g_, b_ = (gam.detach().to(D), bet.detach().to(D)) if groups else (None, None)
+    terms = [(1.0, x.detach().to(D))]
+    cg = d // groups if groups else 0
+    tol = {0: TOL, 1: 2e-4, 2: 2e-5}.get(cg, TOL)
+    close(ops.gn_time_gemm(terms, n, d, groups, 1e-5, g_, b_, W.detach().to(D), True, t), S, tol, "fwd")
+    dx, dgp, dbp = ops.gn_time_gemm_bwd(terms, n, d, groups, 1e-5, g_, W.detach().to(D), True, dS.to(D))
+    close(dx, x.grad, {0: TOL, 1: 2e-3, 2: 1e-4}.get(cg, 2e-5), "dx")
+    part = ops.wgrad(terms, n, d, groups, 1e-5, g_, b_, dS.to(D), True)
+    gW = part.sum(0).view(d + 1, dout)
+    close(gW[1:], W.grad[1:], max(tol, 2e-5) * n ** 0.5, "dW")
+    close(gW[0] * t, W.grad[0], 2e-5 * n ** 0.5, "dW time row")
+
+
+def test_spmm_strided_output():
+    from graph_odenet_amd import graph as G, ops
+    n, d = 500, 16
+    r, c, v = powerlaw_graph(n, n, 5, 9)
+    A = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n))
+    g = G.from_coo(r.to(dev()), c.to(dev()), v.to(dev()), n, n)
+    X = torch.randn(n, d)
+    wide = torch.full((n, 2 * d + 2), 7.0, device=dev())
+    ops.spmm(g, X.to(dev()), out=wide[:, d:2 * d])
+    close(wide[:, d:2 * d], torch.sparse.mm(A, X), what="column block")
+    assert (wide[:, :d] == 7).all() and (wide[:, 2 * d:] == 7).all()
+    x1 = torch.randn(n, 1)
+    ops.spmm(g, x1.to(dev()), out=wide[:, 2 * d:2 * d + 1])
+    close(wide[:, 2 * d:2 * d + 1], torch.sparse.mm(A, x1), what="single column")
+
+
+@pytest.mark.parametrize("n,c,g", [(3327, 128, 32), (257, 16, 16), (120, 64, 32), (1000, 48, 8), (5, 7, 1)])
+def test_group_norm_2d_vs_cpu_torch(n, c, g):
+    """Stand-alone GroupNorm on (nodes x channels) against torch's CPU implementation.  (torch-ROCm's own GPU
+    backward returns wrong dgamma / dbeta for 2-D inputs with more than a few hundred rows - the reason this
+    op exists; see functional.GroupNorm.)"""
+    from graph_odenet_amd.functional import GroupNorm
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c)
+    go = torch.randn(n, c)
+    ref = torch.nn.GroupNorm(g, c)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-0.5, 0.5)
+    xr = x.clone().requires_grad_(True)
+    ref(xr).backward(go)
+    m = GroupNorm(g, c).to(dev())
+    m.load_state_dict(ref.state_dict())
+    xg = x.clone().to(dev()).requires_grad_(True)
+    out = m(xg)
+    out.backward(go.to(dev()))
+    cg = c // g
+    ftol = {1: 2e-4, 2: 2e-5}.get(cg, TOL)
+    close(out, ref(x), ftol, "gn fwd")
+    close(xg.grad, xr.grad, {1: 2e-3, 2: 1e-4}.get(cg, 2e-5), "gn dx")
+    close(m.weight.grad, ref.weight.grad, (2e-3 if cg == 1 else 2e-5) * max(1, n ** 0.5), "gn dgamma")
+    close(m.bias.grad, ref.bias.grad, 2e-5 * max(1, n ** 0.5), "gn dbeta")
