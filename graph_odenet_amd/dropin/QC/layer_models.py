@@ -1,0 +1,3 @@
+"""Bare-name shim: `import layer_models` (QC/train_egcn.py:86-95 selects its model classes from it)."""
+from graph_odenet_amd.qc_models import (EdgeGCN_K_Set2Set, EdgeGCN_K_Sum, EdgeRES1_K_Set2Set,  # noqa: F401
+                                        MPNN_ENN_K_Set2Set, MPNN_ENN_K_Sum, RESKnorm)

@@ -13,6 +13,7 @@ What is captured (inputs AND expected outputs, fp32):
   qc_layers.npz      MPNN_enn_edge (T=1,3) and EdgeGraphConvolution fwd + grads (QC/mpnn.py, QC/layers.py)
   scatter_kat.npz    the scatter_add docstring known-answer vector           (QC/torch_scatter.py:207-218)
   pubmed_graph_sym.npz  Pubmed topology, D^-1/2 (A+I) D^-1/2                 (GCN-dense-paper/utils.py:70-110)
+  qc_models.npz      QC model zoo outputs + small gradients on a synthetic batch (QC/layer_models.py:27-232)
 
 `torchdiffeq` is absent from the image; an EMPTY stand-in module object is registered so
 that `models.py` imports.  No solver is ever called through it (parity at the solver
@@ -263,6 +264,47 @@ if __name__ == "__main__":
         sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
         sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
         pubmed_topology()
-    else:
+    elif os.environ.get("GOLDEN_ONLY") != "qc_models":
         main()
         pubmed_topology()
+        qc_models_golden()
+
+
+def qc_models_golden():
+    """QC model zoo (QC/layer_models.py) on a small synthetic batch: outputs and a few gradients of the
+    reference classes themselves (hidden 16 to keep the fixture small)."""
+    sys.path.insert(0, os.path.join(ROOT_REPO))
+    from graph_odenet_amd.synth import qm9_like_batch
+    for n in ("layers", "models", "mpnn", "set2set", "layer_models", "torch_scatter", "torch_geometric_utils"):
+        sys.modules.pop(n, None)
+    sys.path.insert(0, os.path.join(REF, "QC"))
+    try:
+        lm = importlib.import_module("layer_models")
+    finally:
+        sys.path.pop(0)
+    x, ef, Esrc, Etgt, batch = qm9_like_batch(4, seed=3)
+    res = dict(x=x, ef=ef, Esrc=Esrc, etgt=Etgt.argmax(0), batch=batch, n=x.shape[0])
+    torch.manual_seed(21)
+    for name in ("MPNN_ENN_K_Sum", "MPNN_ENN_K_Set2Set", "EdgeGCN_K_Sum", "EdgeGCN_K_Set2Set", "EdgeRES1_K_Set2Set"):
+        m = getattr(lm, name)(node_features=13, edge_features=5, target_features=12, hidden_features=16, num_layers=3,
+                              s2s_processing_steps=3, dropout=0.0)
+        m.eval()
+        out = m(x, ef, Esrc, Etgt, batch)
+        gout = torch.randn_like(out)
+        out.backward(gout)
+        res[name + "__out"] = out
+        res[name + "__gout"] = gout
+        for k, p in m.state_dict().items():
+            res[name + "__sd__" + k.replace(".", "__")] = p
+        for k, p in m.named_parameters():
+            if p.grad is not None and p.numel() <= 600:          # small ones only: biases, norms, output layers
+                res[name + "__g__" + k.replace(".", "__")] = p.grad
+    save("qc_models.npz", **res)
+
+
+ROOT_REPO = os.path.dirname(os.path.dirname(OUT))
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "qc_models":
+    sys.dont_write_bytecode = True
+    stub = types.ModuleType("torchdiffeq"); stub.odeint_adjoint = None; stub.odeint = None
+    sys.modules["torchdiffeq"] = stub
+    qc_models_golden()
