@@ -117,8 +117,9 @@ Overlap* overlap_ctx() {
 // Adjoint solve.  Per stage the launches form two chains:
 //   F (forward recompute):  Gf(s) = [t|GN(y_s)]W  ->  Sp(s) = relu(A . + b) (+ masked cotangent dZ)
 //   B (vector-Jacobian)  :  SpT(s) = A^T dZ  ->  Gb(s) (k_a)  |  Wg(s) (dW partials)  |  colsum(dZ), reductions
-// Gf(s+1) needs only k_y(s), so it runs on a side stream under the memory-bound SpT(s), and Wg(s) runs on the
-// side stream beside Gb(s) (S is double-buffered when ws->S2 is given; events order every buffer reuse).
+// Gf(s+1) needs only k_y(s).  The SpMM launches (HBM-bound) run alone; the three MFMA-bound launches that follow
+// SpT(s) run side by side: Gb(s) on the caller's stream, Wg(s) then Gf(s+1) on a side stream - each of them alone
+// keeps the matrix pipe ~50 % busy (S is double-buffered when ws->S2 is given; events order every buffer reuse).
 extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, float* a, float* theta,
                                         float** y_result, float** a_result,
                                         const gode_rk4_workspace_t* ws, float t0, float t1, int32_t n_steps,
@@ -169,29 +170,26 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
         // pointers as the NEXT stage will see them (the y-chain swaps buffers after stage 3)
         float* ycur_n = ycur; float* ky_n[4] = {ky[0], ky[1], ky[2], ky[3]};
         if (s == 3) { ycur_n = ky[3]; ky_n[3] = ycur; }
-        if (two) {
-            GODE_HIP(hipEventRecord(ov->sp, hs));
-            GODE_HIP(hipStreamWaitEvent(ov->side, ov->sp, 0));
-        }
-        if (g + 1 < total) {                                                    // Gf(g+1) beside SpT(g)
-            const int i2 = (g + 1) / 4, s2 = (g + 1) % 4;
-            gode_lincomb_t yin2 = stage_terms(ycur_n, ky_n, s2, h);
-            GODE_TRY(gode_gn_time_gemm_f32(&yin2, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1,
-                                           (float)((double)t0 + i2 * h + C38[s2] * h), Sbuf[(g + 1) & 1], side));
-            if (two) GODE_HIP(hipEventRecord(ov->gf, ov->side));
-        }
         if (two && wg_pending) GODE_HIP(hipStreamWaitEvent(hs, ov->wg, 0));     // previous Wg still reads dS
-        GODE_TRY(spmm(f->AT, ws->dZ, ws->dS, d, nullptr, stream));              // SpT(g)
+        GODE_TRY(spmm(f->AT, ws->dZ, ws->dS, d, nullptr, stream));              // SpT(g): alone on the chip
         if (two) {
             GODE_HIP(hipEventRecord(ov->spt, hs));
             GODE_HIP(hipStreamWaitEvent(ov->side, ov->spt, 0));
         }
+        // side stream, beside Gb(g) on the main stream: Wg(g), then the dense part of the NEXT stage
         float* kt = ws->ktheta[s];
         GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, ws->dS, d, 1, ws->wpart, side));   // Wg(g)
         GODE_TRY(gode_reduce_parts_f32(kt, ws->wpart, wparts, nW, 1.f, 0, side));
         hipLaunchKernelGGL(theta_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)side, kt, f->W, ts, (int)d, P - 1);
         GODE_LAUNCH_CHECK();
         if (two) { GODE_HIP(hipEventRecord(ov->wg, ov->side)); wg_pending = true; }
+        if (g + 1 < total) {                                                    // Gf(g+1)
+            const int i2 = (g + 1) / 4, s2 = (g + 1) % 4;
+            gode_lincomb_t yin2 = stage_terms(ycur_n, ky_n, s2, h);
+            GODE_TRY(gode_gn_time_gemm_f32(&yin2, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1,
+                                           (float)((double)t0 + i2 * h + C38[s2] * h), Sbuf[(g + 1) & 1], side));
+            if (two) GODE_HIP(hipEventRecord(ov->gf, ov->side));
+        }
         GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->W, d, 1, ws->dS,
                                            s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &apre : nullptr, ka[s],
                                            f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr, stream));   // Gb(g)
