@@ -59,6 +59,8 @@ c_i = ctypes.c_int
 SIGNATURES = {
     "gode_abi_version": (c_i, []),
     "gode_error_string": (ctypes.c_char_p, [c_i]),
+    "gode_set_option": (c_i, [ctypes.c_char_p, c_i]),
+    "gode_get_option": (c_i, [ctypes.c_char_p]),
     "gode_spmm_csr_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64,
                                 c_i64, c_i64, ctypes.POINTER(SpmmEpilogue), c_p]),
     "gode_lincomb_f32": (c_i, [c_p, ctypes.POINTER(LinComb), c_i64, c_p]),

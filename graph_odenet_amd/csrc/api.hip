@@ -16,3 +16,29 @@ extern "C" const char* gode_error_string(int code) {
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "graphode: unknown error";
 }
+
+// ---- run-time options (tuning switches shared by the translation units) ---------------------------------
+#include "options.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+int g_gemm_split = -1, g_overlap = -1;
+}
+
+int gode_opt_gemm_split() { if (g_gemm_split < 0) g_gemm_split = env_int("GODE_GEMM_SPLIT", 0) != 0; return g_gemm_split; }
+int gode_opt_overlap() { if (g_overlap < 0) g_overlap = env_int("GODE_OVERLAP", 1) != 0; return g_overlap; }
+
+extern "C" int gode_set_option(const char* name, int value) {
+    if (!name) return GODE_E_NULLPTR;
+    if (!strcmp(name, "gemm_split")) { g_gemm_split = value != 0; return 0; }
+    if (!strcmp(name, "overlap")) { g_overlap = value != 0; return 0; }
+    return GODE_E_UNSUPPORTED;
+}
+extern "C" int gode_get_option(const char* name) {
+    if (!name) return GODE_E_NULLPTR;
+    if (!strcmp(name, "gemm_split")) return gode_opt_gemm_split();
+    if (!strcmp(name, "overlap")) return gode_opt_overlap();
+    return GODE_E_UNSUPPORTED;
+}

@@ -18,6 +18,7 @@
 // Bounds: fwd/bwd-data read + write one N x d operand each (HBM) against
 // 2*N*d*d flop on the fp32 MFMA pipe (157 TFLOP/s peak) - near the ridge at d=128.
 #include "common.h"
+#include "options.h"
 
 namespace {
 
@@ -277,6 +278,137 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_
             acc[tt] = (f32x4){w0.x, w0.y, w0.z, w0.w};
         }
         mfma_panel<NJ>(Ws + 4 * g * LDW + r, xv, acc);
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            const float4 o = acc_to_mem_layout(acc[tt], to_m);
+            if (valid) *reinterpret_cast<float4*>(S + (int64_t)row * D + 16 * tt + 4 * mg) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Split-bf16 variant of the forward product (d = 128).
+// v_mfma_f32_16x16x4_f32 runs on the SIMD's fp32 vector ALUs (64 FLOP/clk/SIMD, measured: an fp32-MFMA wave and
+// a VALU wave on one SIMD take the SUM of their times, tools/dev/mfma_valu.hip), so the exact-fp32 kernel above
+// pays MFMA + VALU serially.  Here every fp32 operand is decomposed EXACTLY into three bf16 pieces
+// (x = x_hi + x_mid + x_lo, 8+8+8 significant bits, each piece the round-to-nearest bf16 of the running residual)
+// and the product is accumulated in fp32 from the six piece products whose weight is >= 2^-24 of the result
+// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are < 2^-24 relative) on
+// v_mfma_f32_16x16x32_bf16 - 16 cycles per instruction at 8x the K depth: 192 MFMAs x 16 cycles per 16-row tile
+// instead of 256 x 32.  Parity is the same 1e-5 bar (tests/test_gpu_kernels.py runs both variants).
+// ---------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_bits(float x) {
+    const __bf16 h = (__bf16)x;                               // v_cvt_pk_bf16_f32, round to nearest even
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf16_val(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ void split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    h = bf16_bits(x);
+    const float r1 = x - bf16_val(h);
+    m = bf16_bits(r1);
+    l = bf16_bits(r1 - bf16_val(m));
+}
+
+template <int CG>   // d = 128
+__global__ __launch_bounds__(512, 2) void gn_gemm_fwd_split_kernel(LinComb xin, int n_rows, float eps,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   const float* __restrict__ W, int has_time, float t,
+                                                                   float* __restrict__ S)
+{
+    constexpr int D = 128, NJ = 8, NK = 4;          // NK k-blocks of 32
+    constexpr int LDK = D + 8;                      // bf16 elements per Wt row (272 B: conflict-free ds_read_b128)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* Wp = reinterpret_cast<unsigned short*>(smem);          // [3][D][LDK]: Wt pieces, Wt[n][k] = W1[k][n]
+    float* Gs = smem + (3 * D * LDK) / 2;
+    float* Bs = Gs + D;
+    float* T0 = Bs + D;
+    for (int idx = threadIdx.x; idx < D * D / 4; idx += 512) {
+        const int k = idx / (D / 4), n = (idx % (D / 4)) * 4;
+        const float4 w = ld4(W + (int64_t)(k + has_time) * D + n);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned short h, m, l;
+            split3(wv[q], h, m, l);
+            Wp[(0 * D + n + q) * LDK + k] = h; Wp[(1 * D + n + q) * LDK + k] = m; Wp[(2 * D + n + q) * LDK + k] = l;
+        }
+    }
+    fill_vec_lds<D, 512>(Gs, gamma, 1.f);
+    fill_vec_lds<D, 512>(Bs, beta, 0.f);
+    for (int c = threadIdx.x; c < D; c += 512) T0[c] = has_time ? t * W[c] : 0.f;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int r = l & 15, g = l >> 4;          // MFMA layout
+    const int mr = l >> 2, mg = l & 3;         // memory layout
+    const int to_m = (mg * 16 + mr) * 4;
+    const int n_tiles = (n_rows + 15) / 16;
+    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+        const int row = tile * 16 + mr;
+        const bool valid = row < n_rows;
+        float4 xv[NJ];
+        load_tile<NJ, 2>(xin, (int64_t)row * D + 4 * mg, valid, xv);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            xv[j] = gn_forward_v<CG>(xv[j], eps, ld4(Gs + 16 * j + 4 * mg), ld4(Bs + 16 * j + 4 * mg));
+        // memory layout -> bf16 MFMA layout: F-lane (r, g) needs x[row r][32kb + 8g + 4h + c]; that float4 sits in
+        // M-lane 4r + 2(g&1) + h, register 2kb + (g>>1)
+        bf16x8 xp[NK][3];
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) {
+            float xf[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int src = (4 * r + 2 * (g & 1) + h) * 4;
+                const float4 a = to_mfma_layout(xv[2 * kb], src), b = to_mfma_layout(xv[2 * kb + 1], src);
+                const float4 v = (g >> 1) ? b : a;
+                xf[4 * h] = v.x; xf[4 * h + 1] = v.y; xf[4 * h + 2] = v.z; xf[4 * h + 3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned short h, m, lo;
+                split3(xf[e], h, m, lo);
+                xp[kb][0][e] = (short)h; xp[kb][1][e] = (short)m; xp[kb][2][e] = (short)lo;
+            }
+        }
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            const float4 w0 = ld4(T0 + 16 * tt + 4 * g);
+            acc[tt] = (f32x4){w0.x, w0.y, w0.z, w0.w};
+        }
+        // ping-pong A pieces: group s = kb*NJ + tt multiplies out of a[s&1] while a[(s+1)&1] is read from LDS;
+        // the per-group scheduling barrier keeps hipcc from hoisting all 96 16-byte LDS reads (spills)
+        bf16x8 a[2][3];
+        {
+            const unsigned short* wr = Wp + r * LDK + 8 * g;
+            a[0][0] = *reinterpret_cast<const bf16x8*>(wr);
+            a[0][1] = *reinterpret_cast<const bf16x8*>(wr + D * LDK);
+            a[0][2] = *reinterpret_cast<const bf16x8*>(wr + 2 * D * LDK);
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < NK * NJ; ++sidx) {
+            const int kb = sidx / NJ, tt = sidx % NJ;
+            if (sidx + 1 < NK * NJ) {
+                const int kb2 = (sidx + 1) / NJ, tt2 = (sidx + 1) % NJ;
+                const unsigned short* wr = Wp + (16 * tt2 + r) * LDK + 32 * kb2 + 8 * g;
+                a[(sidx + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(wr);
+                a[(sidx + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(wr + D * LDK);
+                a[(sidx + 1) & 1][2] = *reinterpret_cast<const bf16x8*>(wr + 2 * D * LDK);
+            }
+            const bf16x8 ah = a[sidx & 1][0], am = a[sidx & 1][1], al = a[sidx & 1][2];
+            f32x4 c = acc[tt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xp[kb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xp[kb][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xp[kb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xp[kb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xp[kb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xp[kb][0], c, 0, 0, 0);
+            acc[tt] = c;
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) {
             const float4 o = acc_to_mem_layout(acc[tt], to_m);
@@ -772,6 +904,16 @@ extern "C" int gode_gn_time_gemm_f32(const gode_lincomb_t* xin, int64_t n_rows, 
     const int cg = fast_cg(d_in, d_out, groups);
     const bool al = lincomb_aligned16(xin) && !(((uintptr_t)S) & 15) && !(((uintptr_t)W) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15));
+    if (cg >= 0 && al && d_in == 128 && gode_opt_gemm_split()) {
+        const size_t lds = (size_t)3 * 128 * (128 + 8) * sizeof(unsigned short) + 3 * 128 * sizeof(float);
+        int64_t blocks = ((n_rows + 15) / 16 + 7) / 8; if (blocks < 1) blocks = 1; if (blocks > 256) blocks = 256;
+#define GODE_FWDS(CGV) { rc = set_lds(gn_gemm_fwd_split_kernel<CGV>, lds); if (rc) return rc;                \
+          hipLaunchKernelGGL((gn_gemm_fwd_split_kernel<CGV>), dim3((unsigned)blocks), dim3(512), lds, s,     \
+                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S);                           \
+          GODE_LAUNCH_CHECK(); return 0; }
+        if (cg == 0) GODE_FWDS(0) else if (cg == 1) GODE_FWDS(1) else if (cg == 2) GODE_FWDS(2) else GODE_FWDS(4)
+#undef GODE_FWDS
+    }
     if (cg >= 0 && al) {
         const int nj = (int)(d_in / 16);
         const size_t lds = ((size_t)d_in * (d_in + 4) + 3 * d_in) * sizeof(float);

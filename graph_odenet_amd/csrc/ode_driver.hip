@@ -7,7 +7,7 @@
 // synchronisation, which also makes the call capturable into a HIP graph by the caller.
 // Launch sequence per stage = graph_odenet_amd/gcn_ode.py (GcnOdeField / GcnOdeAdjointField).
 #include "common.h"
-#include <cstdlib>
+#include "options.h"
 
 namespace {
 
@@ -99,8 +99,6 @@ struct Overlap {
 Overlap* overlap_ctx() {
     static Overlap ctx = [] {
         Overlap c;
-        const char* e = getenv("GODE_OVERLAP");
-        if (e && atoi(e) == 0) return c;
         if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return c;
         bool ok = true;
         for (hipEvent_t* ev : {&c.sp, &c.gf, &c.spt, &c.wg})
@@ -135,7 +133,7 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
     const double h = ((double)t1 - (double)t0) / n_steps;   // negative: the adjoint runs from t0 (later) to t1 (earlier)
     hipStream_t hs = (hipStream_t)stream;
     Overlap* ov = overlap_ctx();
-    const bool two = ov->ok && ws->S2 != nullptr;
+    const bool two = ov->ok && ws->S2 != nullptr && gode_opt_overlap();
     void* side = two ? (void*)ov->side : stream;
     float* Sbuf[2] = {ws->S, two ? ws->S2 : ws->S};
     float* ycur = y; float* acur = a;

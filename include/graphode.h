@@ -54,6 +54,11 @@ typedef struct gode_lincomb {
 } gode_lincomb_t;
 
 int         gode_abi_version(void);
+/* run-time tuning switches (process-wide): "gemm_split" (0/1, default 0: exact-fp32 MFMA; 1: split-bf16 x3
+ * forward dense product at d = 128, fp32-equivalent), "overlap" (0/1, default 1: two-stream adjoint schedule).
+ * Initial values come from GODE_GEMM_SPLIT / GODE_OVERLAP.  Returns 0 or GODE_E_UNSUPPORTED. */
+int         gode_set_option(const char* name, int value);
+int         gode_get_option(const char* name);
 const char* gode_error_string(int code);   /* host string, static storage */
 
 /* ---- sparse aggregation -------------------------------------------------

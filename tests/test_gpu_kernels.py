@@ -249,3 +249,30 @@ def test_group_norm_2d_vs_cpu_torch(n, c, g):
     close(xg.grad, xr.grad, {1: 2e-3, 2: 1e-4}.get(cg, 2e-5), "gn dx")
     close(m.weight.grad, ref.weight.grad, (2e-3 if cg == 1 else 2e-5) * max(1, n ** 0.5), "gn dgamma")
     close(m.bias.grad, ref.bias.grad, 2e-5 * max(1, n ** 0.5), "gn dbeta")
+
+
+def test_split_bf16_forward_product_matches_fp32_path():
+    """Opt-in split-bf16 x3 variant of the d=128 forward dense product (exact 3-piece decomposition, six piece
+    products, fp32 accumulation) against the exact-fp32 MFMA path and against the CPU: same 1e-5 bar."""
+    from graph_odenet_amd import _lib, ops
+    import torch.nn.functional as F
+    lib = _lib.load()
+    torch.manual_seed(3)
+    n, d = 5000, 128
+    y, k1 = torch.randn(n, d) * 3, torch.randn(n, d)
+    gam, bet = torch.rand(d) + 0.5, torch.rand(d) - 0.5
+    W = torch.randn(d + 1, d) / d ** 0.5
+    ref = torch.cat([torch.full((n, 1), 0.4), F.group_norm(y + 0.2 * k1, 32, gam, bet, 1e-5)], 1).double() @ W.double()
+    terms = [(1.0, y.to(dev())), (0.2, k1.to(dev()))]
+    outs = {}
+    try:
+        for mode in (0, 1):
+            assert lib.gode_set_option(b"gemm_split", mode) == 0 and lib.gode_get_option(b"gemm_split") == mode
+            outs[mode] = ops.gn_time_gemm(terms, n, d, 32, 1e-5, gam.to(dev()), bet.to(dev()), W.to(dev()), True, 0.4).cpu()
+    finally:
+        lib.gode_set_option(b"gemm_split", 0)
+    e0 = (outs[0].double() - ref).abs().max().item()
+    e1 = (outs[1].double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert e0 <= 1e-5 * scale and e1 <= 1e-5 * scale, (e0, e1, scale)
+    assert e1 <= 4 * e0 + 1e-6 * scale        # the split product is as close to the fp64 truth as the fp32 MFMA chain
