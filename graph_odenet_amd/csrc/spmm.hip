@@ -107,6 +107,62 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
     else *reinterpret_cast<float4*>(partial + (int64_t)slot * (LPR * 4) + lane * 4) = acc;
 }
 
+// Small-graph variant: a whole wave per record.  The wave's 64/LPR sub-groups of LPR lanes each take every
+// (64/LPR)-th chunk of LPR nonzeros of the SAME record and their partial sums are added with xor-shuffles, so a
+// long row costs len/(64/LPR) dependent gathers instead of len (on Cora at d=16 one 169-neighbour row was the whole
+// 34 us of the launch) and no row needs the split / finish pass.  Used when there are too few records to fill the
+// chip anyway (launch_vec4).
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_vec4_wave_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const int4* __restrict__ items, int n_items, float* __restrict__ partial,
+    const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, Epilogue ep)
+{
+    const int gid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);      // one record per wave
+    const int wl = threadIdx.x & 63;
+    const int lane = wl & (LPR - 1), sub = wl / LPR;
+    if (gid >= n_items) return;                                                            // wave-uniform
+    int row, b, e, slot = -1;
+    if (items) { const int4 it = items[gid]; row = it.x; b = it.y; e = it.z; slot = it.w; }
+    else { row = gid; b = rowptr[gid]; e = rowptr[gid + 1]; }
+    const int len = e - b;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* Xl = X + lane * 4;
+    for (int base = sub * LPR; base - sub * LPR < len; base += 64) {                      // same trip count in every sub-group
+        int c = 0; float v = 0.f;
+        if (base + lane < len) {
+            c = col[b + base + lane];
+            v = val ? val[b + base + lane] : 1.f;
+        }
+        const int cnt = len - base;
+        constexpr int U = LPR < 4 ? LPR : 4;
+        for (int k = 0; k < LPR; k += U) {
+            if (!__any(k < cnt)) break;
+            int cc[U]; float vv[U]; float4 xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cc[u] = __shfl(c, k + u, LPR); vv[u] = __shfl(v, k + u, LPR); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k + u < cnt) xv[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)cc[u] * ldx);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc.x = fmaf(vv[u], xv[u].x, acc.x); acc.y = fmaf(vv[u], xv[u].y, acc.y);
+                acc.z = fmaf(vv[u], xv[u].z, acc.z); acc.w = fmaf(vv[u], xv[u].w, acc.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    if (sub != 0) return;
+    if (slot < 0) epilogue_store4<LPR>(ep, acc, row, lane, (int64_t)LPR * 4, Y, ldy);
+    else *reinterpret_cast<float4*>(partial + (int64_t)slot * (LPR * 4) + lane * 4) = acc;
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void spmm_finish_vec4_kernel(
     const int4* __restrict__ long_rows, int n_long, const float* __restrict__ partial,
@@ -194,6 +250,21 @@ template <int LPR>
 int launch_vec4(const int* rowptr, const int* col, const float* val, const int4* items, int n_items,
                 const int4* long_rows, int n_long, float* partial, const float* X, int64_t ldx,
                 float* Y, int64_t ldy, const Epilogue& ep, hipStream_t s) {
+    if (LPR < 64 && n_items > 0 && n_items <= 65536) {         // too few records to fill the chip: a wave per record
+        const int64_t wb = ((int64_t)n_items * 64 + 255) / 256;
+        const int slot = gode_prof_begin(s, (int64_t)LPR * 4, n_items, (int64_t)ep.pre.n + ep.cot.n + (ep.Y2 ? 1 : 0));
+        hipLaunchKernelGGL(spmm_vec4_wave_kernel<LPR>, dim3((unsigned)wb), dim3(256), 0, s,
+                           rowptr, col, val, items, n_items, partial, X, ldx, Y, ldy, ep);
+        gode_prof_end(s, slot);
+        GODE_LAUNCH_CHECK();
+        if (n_long > 0) {
+            const int64_t b2 = ((int64_t)n_long * LPR + 255) / 256;
+            hipLaunchKernelGGL(spmm_finish_vec4_kernel<LPR>, dim3((unsigned)b2), dim3(256), 0, s,
+                               long_rows, n_long, partial, Y, ldy, ep);
+            GODE_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const int64_t threads = (int64_t)n_items * LPR;
     const int64_t blocks = (threads + 255) / 256;
     if (blocks > 0) {

@@ -23,9 +23,9 @@ def auto_split(nnz):
     """Longest record the SpMM kernel walks with one lane group.  Large graphs: 256 - measured on the R-MAT
     2^20 / 10.8 M-nnz graph at d=128 (tools/kbench.py --split): 64 -> 1.005 ms, 128 -> 0.925, 160 -> 0.849,
     256 -> 0.818, 320 -> 0.820, 512 -> 0.865 (fewer partial slots and finish work vs. a longer tail).
-    Small graphs (citation-graph size): 32, because there a single long record handled by a 4-lane group
-    (d=16) IS the kernel's duration (measured 34 us -> 9 us on Cora)."""
-    return 256 if nnz >= (1 << 20) else 32
+    Small graphs (citation-graph size): 1024, i.e. practically no splitting - below 65 536 records the kernel
+    gives every record a whole wave (spmm_vec4_wave_kernel), which shortens the tail without a finish pass."""
+    return 256 if nnz >= (1 << 20) else 1024
 
 
 class CSRGraph:
