@@ -89,6 +89,8 @@ SIGNATURES = {
                                             c_i64, c_p, c_p, c_p]),
     "gode_edge_matvec_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
     "gode_edge_matvec_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "gode_segment_attention_f32_fwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "gode_segment_attention_f32_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_gcn_ode_theta_len": (c_i64, [c_i64]),
     "gode_gcn_ode_rk4_forward": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, ctypes.POINTER(c_p), ctypes.POINTER(Rk4Workspace),
                                        c_f, c_f, ctypes.c_int32, c_p]),

@@ -294,6 +294,34 @@ def edge_matvec_bwd(edge_row, edge_val, src, A, X, dM, want_dA=True, want_dx=Tru
     return dA, dxe
 
 
+# ---- Set2Set attention readout ---------------------------------------------------------------------
+def segment_attention_fwd(segptr, perm, x, q):
+    """a = per-graph softmax(<x_i, q_b>), r_b = sum_i a_i x_i; returns (a[N], r[B, h])."""
+    lib = _lib.load()
+    _need(x, "x"); _need(q, "q"); _need(segptr, "segptr", torch.int32)
+    if perm is not None:
+        _need(perm, "perm", torch.int32)
+    nb, h = q.shape
+    if x.dim() != 2 or x.shape[1] != h or segptr.numel() != nb + 1:
+        raise ValueError("segment_attention: x must be N x %d and segptr have %d entries" % (h, nb + 1))
+    a = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+    r = torch.empty(nb, h, dtype=torch.float32, device=x.device)
+    check(lib.gode_segment_attention_f32_fwd(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(q), nb, h, ptr(a), ptr(r),
+                                             stream_ptr()), "gode_segment_attention_f32_fwd")
+    return a, r
+
+
+def segment_attention_bwd(segptr, perm, x, q, a, dr):
+    lib = _lib.load()
+    _need(dr, "dr")
+    nb, h = q.shape
+    dx = torch.zeros_like(x, memory_format=torch.contiguous_format)
+    dq = torch.empty_like(q)
+    check(lib.gode_segment_attention_f32_bwd(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(q), ptr(a), ptr(dr), nb, h,
+                                             ptr(dx), ptr(dq), stream_ptr()), "gode_segment_attention_f32_bwd")
+    return dx, dq
+
+
 # ---- stand-alone GroupNorm on 2-D node features ---------------------------------------------------
 def group_norm_fwd(x, groups, eps, gamma, beta):
     lib = _lib.load()

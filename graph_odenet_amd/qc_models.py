@@ -10,7 +10,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .functional import GroupNorm
+from .graph import incidence_from_index
 from .qc_layers import EdgeGraphConvolution, MPNN_enn_edge
 
 
@@ -78,13 +80,87 @@ class EdgeEncoderMLP(nn.Module):
 
 
 # ---- readouts ---------------------------------------------------------------------------------------
-def segment_sum(x, batch, n_graphs):
-    """scatter_add(x, batch, dim=0, dim_size=n_graphs) (QC/torch_scatter.py:170-221)."""
-    return torch.zeros(n_graphs, x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, batch, x)
+_seg_cache = {}
+
+
+class _Segments:
+    """Graph membership of a batch vector, converted once per tensor object: nodes of graph b are
+    perm[segptr[b] : segptr[b+1]] (perm is None when `batch` is already sorted, as the reference's collate emits it)."""
+
+    def __init__(self, batch):
+        b64 = batch.to(torch.int64)
+        self.nb = int(b64.max().item()) + 1 if b64.numel() else 0
+        counts = torch.bincount(b64, minlength=self.nb)
+        segptr = torch.zeros(self.nb + 1, dtype=torch.int64, device=batch.device)
+        segptr[1:] = torch.cumsum(counts, 0)
+        self.segptr = segptr.to(torch.int32)
+        if b64.numel() > 1 and bool((b64[1:] < b64[:-1]).any().item()):
+            self.perm = torch.argsort(b64, stable=True).to(torch.int32)
+        else:
+            self.perm = None
+        self.index = b64
+        self.incidence = None
+
+    def sum_matrix(self):
+        if self.incidence is None:
+            self.incidence = incidence_from_index(self.index, self.nb)
+        return self.incidence
+
+
+def _segments(batch):
+    key = id(batch)
+    hit = _seg_cache.get(key)
+    if hit is not None and hit[0] is batch and hit[2] == batch._version:
+        return hit[1]
+    seg = _Segments(batch)
+    if len(_seg_cache) > 64:
+        _seg_cache.clear()
+    _seg_cache[key] = (batch, seg, batch._version)
+    return seg
+
+
+class _SegmentSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, x):
+        ctx.seg = seg
+        return ops.spmm(seg.sum_matrix(), x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        return None, dout.index_select(0, ctx.seg.index)
+
+
+def segment_sum(x, batch, n_graphs=None):
+    """scatter_add(x, batch, dim=0, dim_size=n_graphs) (QC/torch_scatter.py:170-221) as a pattern-only SpMM over the
+    graph-membership matrix: fixed summation order, no atomics."""
+    seg = _segments(batch)
+    if n_graphs is not None and n_graphs != seg.nb:
+        raise ValueError("segment_sum: batch holds %d graphs, dim_size says %d" % (seg.nb, n_graphs))
+    return _SegmentSumFn.apply(seg, x)
+
+
+class _SegmentAttentionFn(torch.autograd.Function):
+    """r_b = sum_i softmax_b(<x_i, q_b>)_i x_i   (the loop body of QC/set2set.py:63-74)."""
+
+    @staticmethod
+    def forward(ctx, seg, x, q):
+        x, q = x.contiguous(), q.contiguous()
+        a, r = ops.segment_attention_fwd(seg.segptr, seg.perm, x, q)
+        ctx.seg = seg
+        ctx.save_for_backward(x, q, a)
+        return r
+
+    @staticmethod
+    def backward(ctx, dr):
+        x, q, a = ctx.saved_tensors
+        dx, dq = ops.segment_attention_bwd(ctx.seg.segptr, ctx.seg.perm, x, q, a, dr.contiguous())
+        return None, dx, dq
 
 
 class Set2Set(nn.Module):
-    """Set2Set pooling (Vinyals et al. 2015) with the reference's parameters (`lstm`), vectorised over graphs."""
+    """Set2Set pooling (Vinyals et al. 2015) with the reference's parameters (`lstm`).  The per-graph softmax loop of
+    the reference is one kernel per processing step (csrc/segment.hip); the single-layer LSTM step runs as a fused
+    cell on the same `lstm.*` parameters (gate order i, f, g, o as in nn.LSTM)."""
 
     def __init__(self, in_channels, processing_steps, num_layers=1):
         super().__init__()
@@ -92,19 +168,22 @@ class Set2Set(nn.Module):
         self.processing_steps, self.num_layers = processing_steps, num_layers
         self.lstm = nn.LSTM(self.out_channels, self.in_channels, num_layers)
 
+    def _lstm_step(self, q_star, h):
+        if self.num_layers != 1:
+            q, h = self.lstm(q_star.unsqueeze(0), h)
+            return q.view(q_star.shape[0], self.in_channels), h
+        l = self.lstm
+        hx, cx = torch.lstm_cell(q_star, (h[0][0], h[1][0]), l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)
+        return hx, (hx.unsqueeze(0), cx.unsqueeze(0))
+
     def forward(self, x, batch):
-        nb = int(batch.max().item()) + 1
+        seg = _segments(batch)
+        nb = seg.nb
         h = (x.new_zeros(self.num_layers, nb, self.in_channels), x.new_zeros(self.num_layers, nb, self.in_channels))
         q_star = x.new_zeros(nb, self.out_channels)
         for _ in range(self.processing_steps):
-            q, h = self.lstm(q_star.unsqueeze(0), h)
-            q = q.view(nb, self.in_channels)
-            e = (x * q[batch]).sum(-1)
-            # per-graph softmax: shift by the graph's maximum, normalise by the graph's sum
-            emax = torch.full((nb,), -float("inf"), dtype=x.dtype, device=x.device).scatter_reduce(0, batch, e, "amax")
-            w = torch.exp(e - emax[batch])
-            a = w / torch.zeros(nb, dtype=x.dtype, device=x.device).index_add_(0, batch, w)[batch]
-            r = segment_sum(a.unsqueeze(1) * x, batch, nb)
+            q, h = self._lstm_step(q_star, h)
+            r = _SegmentAttentionFn.apply(seg, x, q)
             q_star = torch.cat([q, r], -1)
         return q_star
 
@@ -137,9 +216,8 @@ class MPNN_ENN_K_Sum(_QCBase):
         self._finish(type, target_features)
 
     def forward(self, node_features, edge_features, Esrc, Etgt, batch):
-        nb = int(batch.max().item()) + 1
         x = self.mpnn(self.input(node_features), Esrc, Etgt, self.ee(edge_features))
-        return self.output_function(segment_sum(self.output(x), batch, nb))
+        return self.output_function(segment_sum(self.output(x), batch))
 
 
 class MPNN_ENN_K_Set2Set(_QCBase):
@@ -182,9 +260,8 @@ class EdgeGCN_K_Sum(_EdgeGCNStack):
         self._finish(type, target_features)
 
     def forward(self, node_features, edge_features, Esrc, Etgt, batch):
-        nb = int(batch.max().item()) + 1
         x = self._stack(self.mlpin(node_features), Esrc, Etgt, self.ee(edge_features))
-        return self.output_function(segment_sum(self.mlpout(x), batch, nb))
+        return self.output_function(segment_sum(self.mlpout(x), batch))
 
 
 class EdgeGCN_K_Set2Set(_EdgeGCNStack):

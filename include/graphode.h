@@ -206,6 +206,18 @@ int gode_edge_matvec_f32_bwd(const int32_t* edge_row, const float* edge_val, con
                              const float* A, const float* X, int64_t ldx, const float* dM, int64_t ldm,
                              int64_t h, int64_t n_edges, float* dA, float* dxe, void* stream);
 
+/* ---- Set2Set attention readout over the graphs of a batch (QC/set2set.py:59-75) --------------
+ * The nodes of graph b are perm[segptr[b] .. segptr[b+1]) (perm nullable: node ids are the positions).
+ *   e_i = <x_i, q_b>,  a = softmax(e) within the graph,  r_b = sum_i a_i x_i.
+ * fwd writes a[N] (attention weight per node id) and r[n_seg x h]; a graph without nodes gives r_b = 0.
+ * bwd takes dr[n_seg x h] and writes dx[N x h] (rows of nodes in segments; contiguous, ld = h) and dq[n_seg x h].
+ * h <= 1024.  The reference evaluates this with a Python loop over the graphs. */
+int gode_segment_attention_f32_fwd(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
+                                   const float* q, int64_t n_seg, int64_t h, float* a, float* r, void* stream);
+int gode_segment_attention_f32_bwd(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
+                                   const float* q, const float* a, const float* dr, int64_t n_seg, int64_t h,
+                                   float* dx, float* dq, void* stream);
+
 /* ---- whole rk4 integrations of the GCN ODE function in one call (host-launch-bound sizes) -----
  * f(t, x) = relu(A * ([t | GroupNorm(x)] * W) + b)   (ODEfunc.forward, GCN/models.py:172-179).
  * 3/8-rule steps on a uniform grid from t0 to t1 (t1 < t0 for the adjoint pass); every launch goes to

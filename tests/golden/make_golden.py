@@ -13,6 +13,7 @@ What is captured (inputs AND expected outputs, fp32):
   qc_layers.npz      MPNN_enn_edge (T=1,3) and EdgeGraphConvolution fwd + grads (QC/mpnn.py, QC/layers.py)
   scatter_kat.npz    the scatter_add docstring known-answer vector           (QC/torch_scatter.py:207-218)
   pubmed_graph_sym.npz  Pubmed topology, D^-1/2 (A+I) D^-1/2                 (GCN-dense-paper/utils.py:70-110)
+  set2set.npz        the reference's Set2Set readout alone: q_star + gradients (QC/set2set.py:6-75)
   qc_models.npz      QC model zoo outputs + small gradients on a synthetic batch (QC/layer_models.py:27-232)
 
 `torchdiffeq` is absent from the image; an EMPTY stand-in module object is registered so
@@ -264,10 +265,11 @@ if __name__ == "__main__":
         sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
         sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
         pubmed_topology()
-    elif os.environ.get("GOLDEN_ONLY") != "qc_models":
+    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set"):
         main()
         pubmed_topology()
         qc_models_golden()
+        set2set_golden()
 
 
 def qc_models_golden():
@@ -302,7 +304,36 @@ def qc_models_golden():
     save("qc_models.npz", **res)
 
 
+def set2set_golden():
+    """The reference's Set2Set module (QC/set2set.py:6-75) alone: h=24, 4 processing steps, 6 graphs of
+    uneven size; inputs, lstm parameters, q_star and the gradients of x and of the lstm parameters."""
+    for n in ("set2set", "torch_scatter", "torch_geometric_utils"):
+        sys.modules.pop(n, None)
+    sys.path.insert(0, os.path.join(REF, "QC"))
+    try:
+        s2s = importlib.import_module("set2set")
+    finally:
+        sys.path.pop(0)
+    torch.manual_seed(33)
+    sizes = [5, 1, 17, 9, 2, 30]
+    batch = torch.cat([torch.full((n,), b, dtype=torch.int64) for b, n in enumerate(sizes)])
+    x = torch.randn(batch.numel(), 24, requires_grad=True)
+    m = s2s.Set2Set(24, 4, 1)
+    out = m(x, batch)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    res = dict(x=x.detach(), batch=batch, out=out.detach(), gout=gout, gx=x.grad)
+    for k, p in m.state_dict().items():
+        res["sd__" + k.replace(".", "__")] = p
+    for k, p in m.named_parameters():
+        res["g__" + k.replace(".", "__")] = p.grad
+    save("set2set.npz", **res)
+
+
 ROOT_REPO = os.path.dirname(os.path.dirname(OUT))
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "set2set":
+    sys.dont_write_bytecode = True
+    set2set_golden()
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "qc_models":
     sys.dont_write_bytecode = True
     stub = types.ModuleType("torchdiffeq"); stub.odeint_adjoint = None; stub.odeint = None

@@ -161,3 +161,17 @@ def test_scatter_add_kat(golden):
     g = golden("scatter_kat.npz")
     out = torch.zeros(2, 6).scatter_add_(1, T(g["index"]), T(g["src"]))
     assert torch.equal(out, T(g["out"]))
+
+
+def test_set2set_oracle_vs_reference_golden(golden):
+    """oracle.set2set / set2set_attention against the reference's own Set2Set module (QC/set2set.py)."""
+    g = golden("set2set.npz")
+    x = T(g["x"]).clone().requires_grad_(True)
+    batch = T(g["batch"]).long()
+    p = [T(g["sd__lstm__" + k]).clone().requires_grad_(True) for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    out = R.set2set(x, batch, 6, *p, processing_steps=4)
+    close(out, g["out"], 1e-5)
+    out.backward(T(g["gout"]))
+    close(x.grad, g["gx"], 2e-5)
+    for q, k in zip(p, ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")):
+        close(q.grad, g["g__lstm__" + k], 2e-5)

@@ -1,70 +1,136 @@
 #!/usr/bin/env python3
-"""QC (config C4) step timing: MPNN_ENN_K_Sum-shaped model (QC/layer_models.py:27-50: edge encoder ->
-input Linear -> MPNN_enn_edge T=3 -> per-graph sum -> output MLP, MSE on 12 targets) on a synthetic
-QM9-like batch of 20 graphs, h=73.  Product on the GPU vs the same model with the oracle's message step
-on the host cores.  Development aid."""
+"""QC / QM9 data-parallel step timing (config C4 of SURVEY.md §8(d), configs[3] of BASELINE.json).
+
+Model: the reference's `MPNN_ENN_K_Set2Set` shape (QC/layer_models.py: edge encoder 5 -> 2667 -> 73*73, input
+Linear 13 -> 73, MPNN_enn_edge T=3, Set2Set(12), output Linear -> 12 targets; 14.4 M parameters, 57 MB of
+gradients), batch of 20 synthetic QM9-like molecules per GPU (RDKit / QM9 files are absent), MSE loss,
+Adam(lr 1e-3) as in QC/train_egcn.py:122.
+
+  python tools/qc_bench.py                                       one GPU (+ the oracle's message step on the host)
+  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/qc_bench.py --gpus N
+      one rank per GPU, every rank its own batches (seed = rank), one flat RCCL all-reduce of the
+      gradients per step (parallel.GradBucket); weak scaling, value = N*20*K / max-over-ranks time.
+
+Prints one JSON line on rank 0.  Development / secondary measurement; the contract line is bench.py's.
+"""
+import argparse
+import json
 import os
 import sys
 import time
 
 import torch
-import torch.nn as nn
+import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from graph_odenet_amd.qc_layers import MPNN_enn_edge  # noqa: E402
-from graph_odenet_amd.synth import qm9_like_batch  # noqa: E402
-from oracle import layers_ref as R  # noqa: E402
 
 
-class Net(nn.Module):
-    def __init__(self, h=73, T=3, product=True):
-        super().__init__()
-        self.h, self.T, self.product = h, T, product
-        self.ee = nn.Sequential(nn.Linear(5, 128), nn.ReLU(), nn.Linear(128, h * h))   # stands in for EdgeEncoderMLP
-        self.inp = nn.Linear(13, h)
-        self.mpnn = MPNN_enn_edge(5, h)
-        self.mpnn.set_T(T)
-        self.out = nn.Sequential(nn.Linear(h, 128), nn.ReLU(), nn.Linear(128, 12))
-
-    def forward(self, x, ef, Esrc, Etgt, batch, nb):
-        A = self.ee(ef).view(-1, self.h, self.h)
-        hx = self.inp(x)
-        if self.product:
-            hx = self.mpnn(hx, Esrc, Etgt, A)
-        else:
-            hx = R.mpnn_enn_edge(hx, Esrc, Etgt, A, self.mpnn.update_net, self.T)
-        pooled = torch.zeros(nb, self.h, device=x.device).index_add_(0, batch, hx)
-        return self.out(pooled)
-
-
-def run(dev, product, n_it):
+def build(dev, model_name, seed, n_batches, batch_size):
+    from graph_odenet_amd import qc_models
+    from graph_odenet_amd.synth import qm9_like_batch
     torch.manual_seed(0)
-    x, ef, Esrc, Etgt, batch = qm9_like_batch(20, seed=0, device=dev)
-    net = Net(product=product).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-    tgt = torch.randn(20, 12, device=dev)
+    net = getattr(qc_models, model_name)(node_features=13, edge_features=5, target_features=12,
+                                         hidden_features=73, num_layers=3).to(dev)
+    batches = []
+    for b in range(n_batches):
+        x, ef, Esrc, Etgt, batch = qm9_like_batch(batch_size, seed=seed * 1000 + b, device=dev)
+        tgt = torch.randn(batch_size, 12, generator=torch.Generator().manual_seed(seed * 1000 + b)).to(dev)
+        batches.append((x, ef, Esrc, Etgt, batch, tgt))
+    return net, batches
 
-    def step():
+
+def cpu_oracle_step(model_name, batch_size, reps):
+    """Same model on the host cores with the oracle's message step instead of the HIP one."""
+    from oracle import layers_ref as R
+    net, batches = build(torch.device("cpu"), model_name, 0, 1, batch_size)
+
+    def mpnn_cpu(x, Esrc, Etgt, A):
+        return R.mpnn_enn_edge(x, Esrc, Etgt, A, net.mpnn.update_net, net.mpnn.T)
+    net.mpnn.forward = mpnn_cpu
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x, ef, Esrc, Etgt, batch, tgt = batches[0]
+    ts = []
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
         opt.zero_grad()
-        loss = ((net(x, ef, Esrc, Etgt, batch, 20) - tgt) ** 2).mean()
+        F.mse_loss(net(x, ef, Esrc, Etgt, batch), tgt).backward()
+        opt.step()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts[1:])[len(ts[1:]) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=20)
+    ap.add_argument("--model", default="MPNN_ENN_K_Set2Set")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run, one rank per GPU")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from graph_odenet_amd.parallel import GradBucket, broadcast_parameters
+
+    net, batches = build(dev, args.model, rank, 8, args.batch_size)
+    broadcast_parameters(net, 0)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    bucket = GradBucket(net)
+
+    def step(i):
+        x, ef, Esrc, Etgt, batch, tgt = batches[i % len(batches)]
+        opt.zero_grad(set_to_none=False)
+        loss = F.mse_loss(net(x, ef, Esrc, Etgt, batch), tgt)
         loss.backward()
+        bucket.allreduce_mean()
         opt.step()
         return loss
-    for _ in range(3):
-        step()
-    if dev.type == "cuda":
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(n_it):
-        loss = step()
-    if dev.type == "cuda":
-        torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n_it, float(loss), x.shape[0], Esrc.numel()
+    for i in range(args.steps):
+        loss = step(i)
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = el.item()
+    if rank == 0:
+        res = {"metric": "QC edge-MPNN training throughput (graphs/s), batch %d per GPU" % args.batch_size,
+               "value": round(world * args.batch_size * args.steps / el, 1), "unit": "graphs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * el / args.steps, 3), "scaling": "weak", "dtype": "f32",
+               "data": "synthetic", "loss": round(float(loss), 5),
+               "config": {"workload": "%s h=73 T=3, %d QM9-like molecules per rank, 8 distinct batches cycled"
+                                      % (args.model, args.batch_size),
+                          "params": sum(p.numel() for p in net.parameters()),
+                          "gradient_bytes_allreduced_per_step": 4 * bucket.flat.numel() if world > 1 else 0}}
+        if world == 1 and not args.no_cpu_baseline:
+            t = cpu_oracle_step(args.model, args.batch_size, 3)
+            res["cpu_baseline"] = {"value": round(args.batch_size / t, 1), "unit": "graphs/s",
+                                   "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": "median of 3 steps after 1 warm-up, %.1f ms/step" % (1e3 * t)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    dt, loss, n, e = run(torch.device("cuda:0"), True, 50)
-    print("QC batch 20 (N=%d, E=%d, h=73, T=3): GPU product %.2f ms/step (%.0f graphs/s), loss %.4f" % (n, e, dt * 1e3, 20 / dt, loss))
-    dt, loss, n, e = run(torch.device("cpu"), False, 5)
-    print("QC batch 20: CPU oracle %.2f ms/step (%.0f graphs/s, %d threads), loss %.4f" % (dt * 1e3, 20 / dt, torch.get_num_threads(), loss))
+    main()
