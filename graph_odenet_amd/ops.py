@@ -304,7 +304,11 @@ def segment_attention_fwd(segptr, perm, x, q):
     nb, h = q.shape
     if x.dim() != 2 or x.shape[1] != h or segptr.numel() != nb + 1:
         raise ValueError("segment_attention: x must be N x %d and segptr have %d entries" % (h, nb + 1))
-    a = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+    if int(segptr.numel()) and x.shape[0] == 0:
+        return x.new_zeros(0), x.new_zeros(nb, h)
+    # every node id must occur exactly once in the segments (callers build them from a batch vector, which
+    # guarantees it), so a[] and, in the backward, dx[] are fully written by the kernels
+    a = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
     r = torch.empty(nb, h, dtype=torch.float32, device=x.device)
     check(lib.gode_segment_attention_f32_fwd(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(q), nb, h, ptr(a), ptr(r),
                                              stream_ptr()), "gode_segment_attention_f32_fwd")
@@ -315,7 +319,7 @@ def segment_attention_bwd(segptr, perm, x, q, a, dr):
     lib = _lib.load()
     _need(dr, "dr")
     nb, h = q.shape
-    dx = torch.zeros_like(x, memory_format=torch.contiguous_format)
+    dx = torch.empty_like(x, memory_format=torch.contiguous_format)
     dq = torch.empty_like(q)
     check(lib.gode_segment_attention_f32_bwd(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(q), ptr(a), ptr(dr), nb, h,
                                              ptr(dx), ptr(dq), stream_ptr()), "gode_segment_attention_f32_bwd")
