@@ -47,7 +47,7 @@ class Rk4Workspace(ctypes.Structure):
     _fields_ = [("S", ctypes.c_void_p), ("dZ", ctypes.c_void_p), ("dS", ctypes.c_void_p), ("S2", ctypes.c_void_p),
                 ("ky", ctypes.c_void_p * 4), ("ka", ctypes.c_void_p * 4), ("ktheta", ctypes.c_void_p * 4),
                 ("wpart", ctypes.c_void_p), ("gpart", ctypes.c_void_p), ("bpart", ctypes.c_void_p),
-                ("colsum_scratch", ctypes.c_void_p)]
+                ("colsum_scratch", ctypes.c_void_p), ("X", ctypes.c_void_p * 2)]
 
 
 c_i64 = ctypes.c_int64
@@ -69,6 +69,8 @@ SIGNATURES = {
     "gode_rk_scaled_sumsq_f32": (c_i, [c_p, ctypes.POINTER(LinComb), c_p, c_f, c_f, c_i64, c_p, c_p]),
     "gode_gn_time_gemm_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
                                     c_p, c_i64, c_i, c_f, c_p, c_p]),
+    "gode_gn_time_gemm_xout_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
+                                         c_p, c_i64, c_i, c_f, c_p, c_p, c_p]),
     "gode_gemm_bwd_parts": (c_i64, [c_i64]),
     "gode_gn_time_gemm_bwd_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p,
                                         c_p, c_i64, c_i, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p]),

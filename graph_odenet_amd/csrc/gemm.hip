@@ -212,6 +212,55 @@ __device__ __forceinline__ void mfma_panel(const float* wl /* Wlds + 4g*LDW + r 
     }
 }
 
+// Steps [S0, S1) of mfma_panel (same operand order, hence the same sums): lets the caller put global-memory
+// work between two parts of a panel.
+template <int NJ, int S0, int S1>
+__device__ __forceinline__ void mfma_panel_part(const float* wl, const float4 (&xv)[NJ], f32x4 (&acc)[NJ]) {
+    constexpr int LDW = 16 * NJ + 4;
+    float a[2][NJ];
+#pragma unroll
+    for (int tt = 0; tt < NJ; ++tt) a[S0 & 1][tt] = wl[(16 * (S0 / 4) + (S0 % 4)) * LDW + 16 * tt];
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+        const int j = s / 4, c = s % 4;
+        const float xb = c == 0 ? xv[j].x : (c == 1 ? xv[j].y : (c == 2 ? xv[j].z : xv[j].w));
+        if (s + 1 < S1) {
+            const int jn = (s + 1) / 4, cn = (s + 1) % 4;
+#pragma unroll
+            for (int tt = 0; tt < NJ; ++tt) a[(s + 1) & 1][tt] = wl[(16 * jn + cn) * LDW + 16 * tt];
+        }
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt)
+            acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][tt], xb, acc[tt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Raw loads of terms [T0, T0+2) of one tile (issued, not yet used) and their accumulation, in the term order of
+// load_tile_n so that prefetched and direct loads give the same bits.
+template <int NJ>
+__device__ __forceinline__ void issue_terms2(const LinComb& lc, int t0, int64_t base, bool valid, float4 (&v)[2][NJ]) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+        if (valid && t0 + tt < lc.n) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[tt][j] = ld4(lc.ptr[t0 + tt] + base + 16 * j);
+        }
+}
+template <int NJ>
+__device__ __forceinline__ void fold_terms2(const LinComb& lc, int t0, bool valid, const float4 (&v)[2][NJ], float4 (&xv)[NJ]) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+        if (valid && t0 + tt < lc.n) {
+            const float c = lc.coef[t0 + tt];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                xv[j].x = fmaf(c, v[tt][j].x, xv[j].x); xv[j].y = fmaf(c, v[tt][j].y, xv[j].y);
+                xv[j].z = fmaf(c, v[tt][j].z, xv[j].z); xv[j].w = fmaf(c, v[tt][j].w, xv[j].w);
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------
 // forward:  S[row, :] = t*W[0,:] + GN(x[row,:]) * W[1:, :]
 // ---------------------------------------------------------------------------------
@@ -242,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ W, int has_time, float t,
-                                                             float* __restrict__ S)
+                                                             float* __restrict__ S, float* __restrict__ xout)
 {
     constexpr int D = 16 * NJ;
     constexpr int LDW = D + 4;
@@ -261,15 +310,28 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_
     const int mr = l >> 2, mg = l & 3;         // memory layout
     const int to_f = (4 * r + g) * 4, to_m = (mg * 16 + mr) * 4;
     const int n_tiles = (n_rows + 15) / 16;
-    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+    const int stride = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;
+    // The combined input rows of the NEXT tile are fetched while the matrix pipe works on the current one: terms 0-1
+    // are issued before the first half of the panel, terms 2-3 before the second half (more than 4 terms - adaptive
+    // solvers only - are completed after the panel).  With two waves per SIMD (LDS-bound occupancy) the loads of a
+    // 3- or 4-term stage input are otherwise exposed.
+    float4 nx[NJ];
+    load_tile<NJ, 2>(xin, (int64_t)(tile * 16 + mr) * D + 4 * mg, tile * 16 + mr < n_rows, nx);
+    for (; tile < n_tiles; tile += stride) {
         const int row = tile * 16 + mr;
         const bool valid = row < n_rows;
+        const int nrow = row + stride * 16;
+        const bool nvalid = (tile + stride < n_tiles) && nrow < n_rows;
+        const int64_t nbase = (int64_t)nrow * D + 4 * mg;
         float4 xv[NJ];
-        load_tile<NJ, 2>(xin, (int64_t)row * D + 4 * mg, valid, xv);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            xv[j] = gn_forward_v<CG>(xv[j], eps, ld4(Gs + 16 * j + 4 * mg), ld4(Bs + 16 * j + 4 * mg));
+            if (xout != nullptr && valid) *reinterpret_cast<float4*>(xout + (int64_t)row * D + 16 * j + 4 * mg) = nx[j];
+            xv[j] = gn_forward_v<CG>(nx[j], eps, ld4(Gs + 16 * j + 4 * mg), ld4(Bs + 16 * j + 4 * mg));
             xv[j] = to_mfma_layout(xv[j], to_f);
+            nx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         f32x4 acc[NJ];
 #pragma unroll
@@ -277,7 +339,15 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_
             const float4 w0 = ld4(T0 + 16 * tt + 4 * g);
             acc[tt] = (f32x4){w0.x, w0.y, w0.z, w0.w};
         }
-        mfma_panel<NJ>(Ws + 4 * g * LDW + r, xv, acc);
+        float4 v[2][NJ];
+        issue_terms2<NJ>(xin, 0, nbase, nvalid, v);
+        mfma_panel_part<NJ, 0, 2 * NJ>(Ws + 4 * g * LDW + r, xv, acc);
+        fold_terms2<NJ>(xin, 0, nvalid, v, nx);
+        issue_terms2<NJ>(xin, 2, nbase, nvalid, v);
+        mfma_panel_part<NJ, 2 * NJ, 4 * NJ>(Ws + 4 * g * LDW + r, xv, acc);
+        fold_terms2<NJ>(xin, 2, nvalid, v, nx);
+        if (xin.n > 4) { issue_terms2<NJ>(xin, 4, nbase, nvalid, v); fold_terms2<NJ>(xin, 4, nvalid, v, nx); }
+        if (xin.n > 6) { issue_terms2<NJ>(xin, 6, nbase, nvalid, v); fold_terms2<NJ>(xin, 6, nvalid, v, nx); }
 #pragma unroll
         for (int tt = 0; tt < NJ; ++tt) {
             const float4 o = acc_to_mem_layout(acc[tt], to_m);
@@ -895,16 +965,25 @@ extern "C" int gode_gn_time_gemm_f32(const gode_lincomb_t* xin, int64_t n_rows, 
                                      float eps, const float* gamma, const float* beta, const float* W,
                                      int64_t d_out, int has_time, float t, float* S, void* stream)
 {
+    return gode_gn_time_gemm_xout_f32(xin, n_rows, d_in, groups, eps, gamma, beta, W, d_out, has_time, t, S, nullptr,
+                                      stream);
+}
+
+extern "C" int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d_in, int32_t groups,
+                                          float eps, const float* gamma, const float* beta, const float* W,
+                                          int64_t d_out, int has_time, float t, float* S, float* x_out, void* stream)
+{
     int rc = check_common(xin, n_rows, d_in, groups, d_out); if (rc) return rc;
     if (n_rows == 0) return 0;
     if (!W || !S) return GODE_E_NULLPTR;
+    if (x_out && (((uintptr_t)x_out) & 15)) return GODE_E_ALIGN;
     has_time = has_time ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     LinComb lc = make_lincomb(xin);
     const int cg = fast_cg(d_in, d_out, groups);
     const bool al = lincomb_aligned16(xin) && !(((uintptr_t)S) & 15) && !(((uintptr_t)W) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15));
-    if (cg >= 0 && al && d_in == 128 && gode_opt_gemm_split()) {
+    if (cg >= 0 && al && d_in == 128 && gode_opt_gemm_split() && !x_out) {
         const size_t lds = (size_t)3 * 128 * (128 + 8) * sizeof(unsigned short) + 3 * 128 * sizeof(float);
         int64_t blocks = ((n_rows + 15) / 16 + 7) / 8; if (blocks < 1) blocks = 1; if (blocks > 256) blocks = 256;
 #define GODE_FWDS(CGV) { rc = set_lds(gn_gemm_fwd_split_kernel<CGV>, lds); if (rc) return rc;                \
@@ -921,11 +1000,12 @@ extern "C" int gode_gn_time_gemm_f32(const gode_lincomb_t* xin, int64_t n_rows, 
 #define GODE_FWD(NJV, CGV)                                                                          \
         { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
           hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
-                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S);                 \
+                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S, x_out);          \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_FWD)
 #undef GODE_FWD
     }
+    if (x_out) { rc = gode_lincomb_f32(x_out, xin, n_rows * d_in, stream); if (rc) return rc; }
     const size_t lds = ((size_t)RB * d_in + (size_t)RB * (groups > 0 ? groups : 1) * 2) * sizeof(float);
     rc = set_lds(gn_gemm_fwd_generic, lds); if (rc) return rc;
     int64_t blocks = (n_rows + RB - 1) / RB; if (blocks > 2048) blocks = 2048;

@@ -85,6 +85,9 @@ class _Shared:
                 ws.ka[i] = ka[i].data_ptr()
                 ws.ktheta[i] = kt[i].data_ptr()
             ws.wpart, ws.gpart, ws.bpart, ws.colsum_scratch = (p.data_ptr() for p in parts)
+            if getattr(self, "X2", None) is None:
+                self.X2 = [torch.empty_like(self.S), torch.empty_like(self.S)]
+            ws.X[0], ws.X[1] = self.X2[0].data_ptr(), self.X2[1].data_ptr()
         return ws
 
 

@@ -138,8 +138,8 @@ def rk_scaled_sumsq(terms, y, rtol, atol, out=None):
     return out
 
 
-def gn_time_gemm(x_terms, n_rows, d_in, groups, eps, gamma, beta, W, has_time, t, out=None):
-    """S = [t | GroupNorm(sum x_terms)] @ W   (W is (d_in+has_time) x d_out)."""
+def gn_time_gemm(x_terms, n_rows, d_in, groups, eps, gamma, beta, W, has_time, t, out=None, x_out=None):
+    """S = [t | GroupNorm(sum x_terms)] @ W   (W is (d_in+has_time) x d_out); x_out (optional) receives sum x_terms."""
     lib = _lib.load()
     _need(W, "W"); _need(gamma, "gamma"); _need(beta, "beta")
     if _need_terms(x_terms, "x") != n_rows * d_in:
@@ -151,9 +151,13 @@ def gn_time_gemm(x_terms, n_rows, d_in, groups, eps, gamma, beta, W, has_time, t
         out = torch.empty(n_rows, d_out, dtype=torch.float32, device=W.device)
     _need(out, "out")
     lc = lincomb(x_terms)
-    check(lib.gode_gn_time_gemm_f32(ctypes.byref(lc), n_rows, d_in, groups, float(eps), ptr(gamma), ptr(beta),
-                                    ptr(W), d_out, 1 if has_time else 0, float(t), ptr(out), stream_ptr()),
-          "gode_gn_time_gemm_f32")
+    if x_out is not None:
+        _need(x_out, "x_out")
+        if x_out.numel() != n_rows * d_in:
+            raise ValueError("gn_time_gemm: x_out has wrong size")
+    check(lib.gode_gn_time_gemm_xout_f32(ctypes.byref(lc), n_rows, d_in, groups, float(eps), ptr(gamma), ptr(beta),
+                                         ptr(W), d_out, 1 if has_time else 0, float(t), ptr(out), ptr(x_out),
+                                         stream_ptr()), "gode_gn_time_gemm_xout_f32")
     return out
 
 

@@ -123,6 +123,12 @@ int gode_gn_time_gemm_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, 
                           int32_t groups, float eps, const float* gamma, const float* beta,
                           const float* W, int64_t d_out, int has_time, float t,
                           float* S, void* stream);
+/* Same, and additionally x_out[i,:] = x(i,:) (the combined, un-normalised stage input; nullable, 16-byte aligned,
+ * n_rows x d_in contiguous) so that later kernels of the same stage read one array instead of the term list. */
+int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d_in,
+                               int32_t groups, float eps, const float* gamma, const float* beta,
+                               const float* W, int64_t d_out, int has_time, float t,
+                               float* S, float* x_out, void* stream);
 
 /* VJP of the above w.r.t. x:  dxn = dS * W[has_time:,:]^T ; dx = GroupNorm'(x)^T dxn
  * out[i,:] = (sum_j pre.coef[j]*pre.ptr[j][i,:]) + out_scale * dx[i,:]
@@ -252,6 +258,9 @@ typedef struct gode_rk4_workspace {
     float* wpart;                       /* gode_wgrad_parts(n) * (d+1)*d floats */
     float* gpart; float* bpart;         /* gode_gemm_bwd_parts(n) * d floats each */
     float* colsum_scratch;              /* gode_colsum_scratch_bytes(n, d) bytes */
+    float* X[2];                        /* nullable pair of n x d buffers (adjoint): the combined input of a stage with
+                                           3 or 4 terms is written once by its forward launch and read as one array by
+                                           the VJP and weight-gradient launches */
 } gode_rk4_workspace_t;
 
 int64_t gode_gcn_ode_theta_len(int64_t d);

@@ -74,6 +74,16 @@ def main():
         for nt, terms in ((1, [(1.0, X)]), (2, [(1.0, X), (0.1, K1)]), (4, [(1.0, X), (0.1, K1), (-0.1, K2), (0.1, K3)])):
             rec("gn_time_gemm fwd (%d terms)" % nt,
                 timeit(lambda: ops.gn_time_gemm(terms, n, d, 32, 1e-5, gam, bet, W, True, 0.3, out=OUT)), (nt + 1) * nd, fl / 1e3)
+        t4 = [(1.0, X), (0.1, K1), (-0.1, K2), (0.1, K3)]
+        XO = torch.empty_like(X)
+        rec("gn_time_gemm fwd (4 terms, +x_out)",
+            timeit(lambda: ops.gn_time_gemm(t4, n, d, 32, 1e-5, gam, bet, W, True, 0.3, out=OUT, x_out=XO)), 6 * nd, fl / 1e3)
+        rec("gn_time_gemm fwd (3 terms)",
+            timeit(lambda: ops.gn_time_gemm(t4[:3], n, d, 32, 1e-5, gam, bet, W, True, 0.3, out=OUT)), 4 * nd, fl / 1e3)
+        for nt, terms in ((1, [(1.0, X)]), (4, [(1.0, X), (0.1, K1), (-0.1, K2), (0.1, K3)])):
+            rec("gn_time_gemm bwd (%d terms)" % nt,
+                timeit(lambda: ops.gn_time_gemm_bwd(terms, n, d, 32, 1e-5, gam, W, True, Y, out=OUT)), (nt + 2) * nd, fl / 1e3)
+            rec("wgrad (%d terms)" % nt, timeit(lambda: ops.wgrad(terms, n, d, 32, 1e-5, gam, bet, Y, True)), (nt + 1) * nd, fl / 1e3)
         t2 = [(1.0, X), (0.1, K1)]
         rec("gn_time_gemm bwd (2 terms)", timeit(lambda: ops.gn_time_gemm_bwd(t2, n, d, 32, 1e-5, gam, W, True, Y, out=OUT)), 4 * nd, fl / 1e3)
         rec("wgrad (2 terms)", timeit(lambda: ops.wgrad(t2, n, d, 32, 1e-5, gam, bet, Y, True)), 3 * nd, fl / 1e3)
