@@ -17,6 +17,9 @@
 //     group per accumulator register quad.
 // Bounds: fwd/bwd-data read + write one N x d operand each (HBM) against
 // 2*N*d*d flop on the fp32 MFMA pipe (157 TFLOP/s peak) - near the ridge at d=128.
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 #include "options.h"
 
@@ -905,15 +908,26 @@ __global__ __launch_bounds__(256) void wgrad_generic(LinComb xin, int n_rows, in
     }
 }
 
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return (int)e;
-    }
+// Dynamic LDS above 64 KB needs the function attribute once per (device, kernel); remembering it keeps the call out
+// of the launch path (and out of HIP-graph captures, where only stream operations should occur).
+int set_lds_once(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(dev, fn);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    done[key] = bytes;
     return 0;
 }
+template <typename K>
+int set_lds(K kernel, size_t bytes) { return set_lds_once(reinterpret_cast<const void*>(kernel), bytes); }
 
 int fast_cg(int64_t d_in, int64_t d_out, int32_t groups) {
     // returns CG (0,1,2,4) when the MFMA fast path applies, else -1

@@ -28,6 +28,13 @@ class ODEfunc(nn.Module):
         ttx = torch.cat([torch.ones_like(xn[:, :1]) * t, xn], 1)
         return F.relu(self.gc1(ttx))
 
+    def gode_plan_token(self, y0):
+        from .gat_layers import edge_graph
+        layer = self.gc1
+        if not torch.is_tensor(layer.src) or layer.src.dim() != 1:
+            return None
+        return ("gat", id(edge_graph(layer.src, layer.tgt, layer.Mtgt)))
+
     def gode_fields(self, y0):
         """Hook for graph_odenet_amd.odeint: fused forward / adjoint kernel sequences (gat_ode.py)."""
         from .gat_ode import gat_fields

@@ -27,12 +27,19 @@ class GatOdeSpec:
             raise ValueError("GatOdeSpec: the ODE layer maps d+1 -> d features")
         self.groups, self.eps_gn = int(norm.num_groups), float(norm.eps)
         self.eps = float(layer.eps)
-        Wf, ww = layer.f.weight.detach(), layer.w.weight.detach()
-        i = self.i
-        self.Wcat = torch.cat([Wf[:, :i].t(), Wf[:, i:].t(), ww[:, :i].t(), ww[:, i:].t()], 1).contiguous()
+        self.Wcat = torch.empty(self.i, 2 * self.d + 2, dtype=torch.float32, device=layer.f.weight.device)
+        self.refresh()
         self.bf, self.bw = layer.f.bias.detach(), layer.w.bias.detach()
         self.gamma, self.beta = norm.weight.detach(), norm.bias.detach()
         self.n = eg.n
+
+
+    def refresh(self):
+        """Re-pack the two Linear weights into Wcat in place (at the start of every solve: the parameters move
+        between solves, the buffer - and a HIP graph captured over it - does not)."""
+        Wf, ww = self.layer.f.weight.detach(), self.layer.w.weight.detach()
+        i = self.i
+        torch.cat([Wf[:, :i].t(), Wf[:, i:].t(), ww[:, :i].t(), ww[:, i:].t()], 1, out=self.Wcat)
 
 
 class _Work:
@@ -49,6 +56,10 @@ class GatOdeField(Field):
 
     def __init__(self, spec, work):
         self.s, self.w = spec, work
+        self.token = ("gat", id(spec.eg))
+
+    def prepare(self):
+        self.s.refresh()
 
     def _forward(self, t, y_terms, out):
         s, w = self.s, self.w
@@ -95,7 +106,7 @@ class GatOdeAdjointField(GatOdeField):
         w.g.mul_(out[0] > 0)
         dz, da = ops.edge_softmax_agg_bwd(eg.Mt, eg.src, eg.tgt, w.P, o, s.bf, wgt, den, out[0], w.g)
         if eg.E > 0:                                    # path through the global max (GAT/layers.py:47)
-            da[torch.argmax(a)] -= da.sum()
+            da.index_add_(0, torch.argmax(a).view(1), -da.sum().view(1))      # no host sync (graph-capturable)
         dP = w.dP
         ops.spmm(eg.Ms_inc, dz, out=dP[:, :o])
         ops.spmm(eg.Mt_inc, dz, out=dP[:, o:2 * o])

@@ -127,6 +127,7 @@ class GcnOdeField(Field):
 
     def __init__(self, spec, shared):
         self.s, self.w = spec, shared
+        self.token = ("gcn", id(spec.graph))     # identity of the problem besides shapes and parameters (odeint plans)
 
     def eval(self, t, terms, out):
         s, w = self.s, self.w

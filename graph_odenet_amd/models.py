@@ -104,6 +104,12 @@ class ODEfunc(nn.Module):
         return odefunc_apply(self.gc1.adj, float(t), x, self.gc1.weight, self.gc1.bias, self.norm1.weight,
                              self.norm1.bias, self.norm1.num_groups, self.norm1.eps)
 
+    def gode_plan_token(self, y0):
+        """Identity of the graph behind this ODE function (odeint keys its captured solves on it)."""
+        if self.gc1.bias is None or y0.dim() != 2 or self.gc1.adj is None:
+            return None
+        return ("gcn", id(as_graph(self.gc1.adj)))
+
     def gode_fields(self, y0):
         """Hook for graph_odenet_amd.odeint: fused forward / adjoint fields (None -> autograd path)."""
         if self.gc1.bias is None or y0.dim() != 2:

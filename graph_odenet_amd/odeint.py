@@ -16,6 +16,9 @@ from .solver import (Dopri5Stats, Field, integrate_dopri5_inplace, integrate_rk4
 
 
 NATIVE_RK4 = True      # fused fields: issue a whole rk4 solve from one C-ABI call (False: per-stage Python driver)
+# Fixed-grid solves of fused fields on launch-bound sizes (state of at most this many elements) are captured into a
+# HIP graph the second time the same solve is requested and replayed afterwards; 0 turns the capture off.
+GRAPH_CAPTURE_MAX_ELEMS = 1 << 21
 
 
 def _materialise(terms):
@@ -91,14 +94,90 @@ def _method(method):
 
 def _integrate(field, comps, t0, t1, rtol, atol, method, options, stats):
     if method == "rk4":
-        n = uniform_grid(t0, t1, (options or {}).get("step_size"))
-        native = getattr(field, "rk4_native", None)
-        if native is not None and NATIVE_RK4:
-            stats.nfe += native(comps, t0, t1, n)          # whole solve issued from C (csrc/ode_driver.hip)
-        else:
-            stats.nfe += integrate_rk4(field, comps, t0, t1, n)
+        stats.nfe += _run_rk4(field, comps, t0, t1, uniform_grid(t0, t1, (options or {}).get("step_size")))
     else:
+        prep = getattr(field, "prepare", None)
+        if prep is not None:
+            prep()
         integrate_dopri5_inplace(field, comps, t0, t1, rtol, atol, stats)
+
+
+class _GraphedSolve:
+    """One captured fixed-grid solve: static input components, the HIP graph, and the components holding the result."""
+
+    def __init__(self, field, comps, t0, t1, n_steps):
+        from . import _lib
+        lib = _lib.load()
+        self.field = field
+        self.inputs = list(comps)
+        self.nfe = 4 * n_steps
+        work = list(comps)
+        overlap = lib.gode_get_option(b"overlap")
+        lib.gode_set_option(b"overlap", 0)           # launch-bound sizes gain nothing from the second stream
+        try:
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                _run_rk4(field, work, t0, t1, n_steps)
+        finally:
+            lib.gode_set_option(b"overlap", overlap)
+        self.outputs = work
+
+    def run(self, values):
+        """values[c]: tensor copied into input component c, or None for zero.  Returns clones of the result."""
+        for dst, src in zip(self.inputs, values):
+            if src is None:
+                dst.zero_()
+            else:
+                dst.copy_(src)
+        self.graph.replay()
+        return [o.clone() for o in self.outputs]
+
+
+class _Plan:
+    """Per-(func, problem) record: fields kept alive across training steps and their captured solves."""
+
+    def __init__(self, fwd, mk_adj, plist):
+        self.fwd, self.mk_adj, self.plist = fwd, mk_adj, plist
+        self.adj = None
+        self.seen_f = self.seen_b = 0
+        self.gf = self.gb = None
+
+
+def _plan_for(func, y0, tl, method, options, params):
+    """(plan, fields) of this solve; plan is None when the solve is not eligible for capture.  A func opts in by
+    offering gode_plan_token(y0): a cheap hashable identity of everything the fields depend on besides the state
+    shape and the parameter storage (i.e. the graph)."""
+    tok = getattr(func, "gode_plan_token", None)
+    token = None
+    if (tok is not None and GRAPH_CAPTURE_MAX_ELEMS > 0 and method == "rk4" and len(tl) == 2
+            and y0.numel() <= GRAPH_CAPTURE_MAX_ELEMS and not torch.cuda.is_current_stream_capturing()):
+        token = tok(y0)
+    if token is None:
+        return None, _fields(func, y0)
+    n = uniform_grid(tl[0], tl[1], (options or {}).get("step_size"))
+    key = (tuple(y0.shape), y0.device.index, tl[0], tl[1], n, token, tuple(p.data_ptr() for p in params), NATIVE_RK4)
+    plans = func.__dict__.setdefault("_gode_plans", {})
+    plan = plans.get(key)
+    if plan is None:
+        fields = _fields(func, y0)
+        if not getattr(fields[0], "fused", False):
+            return None, fields
+        if len(plans) >= 4:
+            plans.clear()                       # a func that keeps changing graphs / shapes: start over
+        plan = plans[key] = _Plan(*fields)
+        plan.n_steps = n
+    return plan, (plan.fwd, plan.mk_adj, plan.plist)
+
+
+def _run_rk4(field, comps, t0, t1, n):
+    prep = getattr(field, "prepare", None)
+    if prep is not None:
+        prep()
+    native = getattr(field, "rk4_native", None)
+    if native is not None and NATIVE_RK4:
+        return native(comps, t0, t1, n)          # whole solve issued from C (csrc/ode_driver.hip)
+    return integrate_rk4(field, comps, t0, t1, n)
 
 
 def _fields(func, y0):
@@ -137,18 +216,29 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
 class _OdeintAdjoint(torch.autograd.Function):
     @staticmethod
     def forward(ctx, func, tl, rtol, atol, method, options, y0, *params):
-        fwd, mk_adj, plist = _fields(func, y0)
+        plan, (fwd, mk_adj, plist) = _plan_for(func, y0, tl, method, options, params)
         stats = Dopri5Stats()
-        ys = [y0.detach().contiguous().clone()]
-        outs = [ys[0].clone()]
-        for i in range(1, len(tl)):
-            _integrate(fwd, ys, tl[i - 1], tl[i], rtol, atol, method, options, stats)
-            outs.append(ys[0].clone())
+        y_start = y0.detach().contiguous()
+        if plan is not None and plan.gf is None and plan.seen_f >= 1:
+            plan.gf = _GraphedSolve(fwd, [y_start.clone()], tl[0], tl[1], plan.n_steps)
+        if plan is not None and plan.gf is not None:
+            (y_end,) = plan.gf.run([y_start])
+            stats.nfe += plan.gf.nfe
+            outs = [y_start.clone(), y_end]
+        else:
+            ys = [y_start.clone()]
+            outs = [ys[0].clone()]
+            for i in range(1, len(tl)):
+                _integrate(fwd, ys, tl[i - 1], tl[i], rtol, atol, method, options, stats)
+                outs.append(ys[0].clone())
+            if plan is not None:
+                plan.seen_f += 1
         _bump_nfe(func, stats.nfe if getattr(fwd, "fused", False) else 0)
         ans = torch.stack(outs)
         ctx.func, ctx.tl, ctx.rtol, ctx.atol, ctx.method, ctx.options = func, tl, rtol, atol, method, options
         ctx.mk_adj = mk_adj
         ctx.fwd = fwd
+        ctx.plan = plan
         ctx.n_params = len(params)
         ctx.save_for_backward(ans)
         return ans
@@ -157,9 +247,22 @@ class _OdeintAdjoint(torch.autograd.Function):
     def backward(ctx, grad_out):
         (ans,) = ctx.saved_tensors
         func, tl = ctx.func, ctx.tl
+        grad_out = grad_out.contiguous()
+        plan = ctx.plan
+        if plan is not None and plan.seen_b >= 1:
+            with torch.no_grad():
+                if plan.gb is None:
+                    plan.adj = plan.mk_adj()
+                    plan.gb = _GraphedSolve(plan.adj, plan.adj.new_state(ans[1]), tl[1], tl[0], plan.n_steps)
+                vals = [ans[1], grad_out[1]] + [None] * (len(plan.gb.inputs) - 2)
+                comps = plan.gb.run(vals)
+                comps[1].add_(grad_out[0])
+            _bump_nfe(func, plan.gb.nfe)
+            return (None, None, None, None, None, None, comps[1], *plan.adj.param_grads(comps))
+        if plan is not None:
+            plan.seen_b += 1
         adj = ctx.mk_adj()
         fwd = ctx.fwd
-        grad_out = grad_out.contiguous()
         ctx_tmp = torch.empty_like(ans[0])
         stats = Dopri5Stats()
         with torch.no_grad():

@@ -376,3 +376,39 @@ def test_set2set_module_vs_reference_golden(golden):
     close(x.grad, g["gx"], 2e-5, "gx")
     for k, p in m.named_parameters():
         close(p.grad, g["g__" + k.replace(".", "__")], 2e-5, "grad " + k)
+
+
+def test_gat_hip_graph_captured_solves_match_eager(golden):
+    """Same as the GCN capture test for the fused GAT field (Python-driven stages, weights re-packed inside the graph)."""
+    from graph_odenet_amd import gat_models, odeint as OI
+    ge = golden("citeseer_gat_edges.npz")
+    n, src, tgt, Mtgt = gat_inputs(ge)
+    d = 16
+    xs = [torch.randn(n, d, generator=torch.Generator().manual_seed(i)).to(dev()) for i in range(4)]
+    res = {}
+    old = OI.GRAPH_CAPTURE_MAX_ELEMS
+    for capture in (True, False):
+        OI.GRAPH_CAPTURE_MAX_ELEMS = old if capture else 0
+        try:
+            torch.manual_seed(1)
+            blk = gat_models.ODEBlock(gat_models.ODEfunc(d), method="rk4", step_size=0.25).to(dev())
+            opt = torch.optim.SGD(blk.parameters(), lr=0.05)
+            log = []
+            for x in xs:
+                opt.zero_grad()
+                xi = x.clone().requires_grad_(True)
+                out = blk(xi, src, tgt, Mtgt)
+                out.square().mean().backward()
+                log.append((out.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()]))
+                opt.step()
+            res[capture] = (log, blk.nfe)
+            if capture:
+                plans = list(blk.odefunc.__dict__["_gode_plans"].values())
+                assert len(plans) == 1 and plans[0].gf is not None and plans[0].gb is not None
+        finally:
+            OI.GRAPH_CAPTURE_MAX_ELEMS = old
+    assert res[True][1] == res[False][1]
+    for (o1, g1, p1), (o2, g2, p2) in zip(res[True][0], res[False][0]):
+        close(o1, o2, 1e-6, "state"); close(g1, g2, 1e-6, "gx")
+        for a, b in zip(p1, p2):
+            close(a, b, 1e-6, "param grad")

@@ -392,3 +392,47 @@ def test_fullnorm_model_grads_vs_cpu_on_cora(golden):
     F.nll_loss(out[idx.to(dev())], labels.to(dev())[idx.to(dev())]).backward()
     for k, q in m.named_parameters():
         close(q.grad, p[k].grad, 5e-5, "grad " + k)
+
+
+@pytest.mark.parametrize("native,d", [(True, 16), (True, 128), (False, 16)])
+def test_hip_graph_captured_solves_match_eager(native, d):
+    """Launch-bound fixed-grid solves are captured into a HIP graph on their second occurrence and replayed afterwards
+    (odeint.py: _GraphedSolve).  Four training steps with changing weights and inputs: the replayed solves return the
+    bits of the eager ones (same kernels, same order), forward and adjoint, for the C driver and the Python driver."""
+    from graph_odenet_amd import models, odeint as OI
+    torch.manual_seed(0)
+    n = 1500
+    r = torch.randint(0, n, (9000,)); c = torch.randint(0, n, (9000,))
+    v = torch.rand(9000)
+    v = v / torch.zeros(n).index_add_(0, r, v)[r]
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n)).to(dev())
+    xs = [torch.randn(n, d, device=dev()) for _ in range(4)]
+    res = {}
+    old = OI.GRAPH_CAPTURE_MAX_ELEMS
+    for capture in (True, False):
+        OI.NATIVE_RK4 = native
+        OI.GRAPH_CAPTURE_MAX_ELEMS = old if capture else 0
+        try:
+            torch.manual_seed(1)
+            blk = models.ODEBlock(models.ODEfunc(d), method="rk4", step_size=0.25).to(dev())
+            opt = torch.optim.SGD(blk.parameters(), lr=0.05)
+            log = []
+            for x in xs:
+                opt.zero_grad()
+                xi = x.clone().requires_grad_(True)
+                out = blk(xi, adj)
+                out.square().mean().backward()
+                log.append((out.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()]))
+                opt.step()
+            res[capture] = (log, blk.nfe)
+            if capture:
+                plans = list(blk.odefunc.__dict__["_gode_plans"].values())
+                assert len(plans) == 1 and plans[0].gf is not None and plans[0].gb is not None
+        finally:
+            OI.NATIVE_RK4 = True
+            OI.GRAPH_CAPTURE_MAX_ELEMS = old
+    assert res[True][1] == res[False][1] == 4 * 2 * 16
+    for (o1, g1, p1), (o2, g2, p2) in zip(res[True][0], res[False][0]):
+        assert torch.equal(o1, o2) and torch.equal(g1, g2)
+        for a, b in zip(p1, p2):
+            assert torch.equal(a, b)
