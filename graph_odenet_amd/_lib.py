@@ -42,6 +42,12 @@ class GcnOdeFunc(ctypes.Structure):
                 ("W", ctypes.c_void_p), ("b", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p)]
 
 
+class GatProj(ctypes.Structure):
+    """Mirror of gode_gat_proj_t."""
+    _fields_ = [("ps", ctypes.c_void_p), ("ld_s", ctypes.c_int64), ("pt", ctypes.c_void_p), ("ld_t", ctypes.c_int64),
+                ("as_", ctypes.c_void_p), ("at", ctypes.c_void_p), ("ld_a", ctypes.c_int64)]
+
+
 class Rk4Workspace(ctypes.Structure):
     """Mirror of gode_rk4_workspace_t."""
     _fields_ = [("S", ctypes.c_void_p), ("dZ", ctypes.c_void_p), ("dS", ctypes.c_void_p), ("S2", ctypes.c_void_p),
@@ -89,6 +95,15 @@ SIGNATURES = {
                                             c_p, c_p, c_p, c_p]),
     "gode_edge_softmax_agg_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p,
                                             c_i64, c_p, c_p, c_p]),
+    "gode_gat_logits_f32": (c_i, [ctypes.POINTER(GatProj), c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "gode_gat_agg_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(GatProj), c_i64, c_p, c_p, c_p, c_f, c_i64,
+                                   c_p, c_p, c_p, c_p]),
+    "gode_gat_agg_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(GatProj), c_i64, c_p, c_p, c_p, c_p, c_p,
+                                   ctypes.POINTER(LinComb), c_f, c_i64, c_p, c_p, c_p]),
+    "gode_gat_maxpath_f32": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
+    "gode_gat_scatter_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64,
+                                   c_p]),
+    "gode_time_row_fixup_f32": (c_i, [c_p, c_p, c_i64, c_f, c_p, c_i, c_p]),
     "gode_edge_matvec_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
     "gode_edge_matvec_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_segment_attention_f32_fwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p]),

@@ -17,6 +17,15 @@
 
 namespace {
 
+// Node-level projections as the edge kernels see them (device copy of gode_gat_proj_t).
+struct Proj {
+    const float* ps; int64_t lds;     // message part gathered by source : ps[v*lds + c], c < o
+    const float* pt; int64_t ldt;     // message part gathered by target
+    const float* as; const float* at; int64_t lda;   // logit parts per node
+};
+Proj proj_of(const float* P, int64_t ldp, int64_t o) { return Proj{P, ldp, P + o, ldp, P + 2 * o, P + 2 * o + 1, ldp}; }
+Proj proj_of(const gode_gat_proj_t* p) { return Proj{p->ps, p->ld_s, p->pt, p->ld_t, p->as, p->at, p->ld_a}; }
+
 __device__ __forceinline__ float block_max(float v) {
     __shared__ float sm[4];
     v = wave_max(v);
@@ -26,14 +35,13 @@ __device__ __forceinline__ float block_max(float v) {
 }
 
 // a[e] = P[src,2o] + P[tgt,2o+1] + bw ; block maxima -> pmax[block]
-__global__ __launch_bounds__(256) void gat_logits_kernel(const float* __restrict__ P, int64_t ldp, int o,
-                                                         const float* __restrict__ bw,
+__global__ __launch_bounds__(256) void gat_logits_kernel(Proj pv, const float* __restrict__ bw,
                                                          const int* __restrict__ src, const int* __restrict__ tgt,
                                                          int n_edges, float* __restrict__ a, float* __restrict__ pmax) {
     float m = -INFINITY;
     const float b = bw ? bw[0] : 0.f;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n_edges; e += gridDim.x * 256) {
-        const float v = P[(int64_t)src[e] * ldp + 2 * o] + P[(int64_t)tgt[e] * ldp + 2 * o + 1] + b;
+        const float v = pv.as[(int64_t)src[e] * pv.lda] + pv.at[(int64_t)tgt[e] * pv.lda] + b;
         a[e] = v;
         m = fmaxf(m, v);
     }
@@ -54,7 +62,7 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void gat_agg_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                           const float* __restrict__ val,
                                                           const int* __restrict__ src, const int* __restrict__ tgt,
-                                                          const float* __restrict__ P, int64_t ldp, int o,
+                                                          Proj pv, int o,
                                                           const float* __restrict__ bf, const float* __restrict__ a,
                                                           const float* __restrict__ amax, float eps, int n_rows, int G,
                                                           float* __restrict__ out, float* __restrict__ w_out,
@@ -74,8 +82,8 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_kernel(const int* __restrict_
         const float we = (val ? val[k] : 1.f) * w;
         if (lane == 0) w_out[e] = w;
         s += we;
-        const float* ps = P + (int64_t)src[e] * ldp;
-        const float* pt = P + (int64_t)tgt[e] * ldp + o;
+        const float* ps = pv.ps + (int64_t)src[e] * pv.lds;
+        const float* pt = pv.pt + (int64_t)tgt[e] * pv.ldt;
 #pragma unroll
         for (int q = 0; q < MAXC; ++q) {
             const int c = lane + q * G;
@@ -103,7 +111,7 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void gat_agg_bwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                           const float* __restrict__ val,
                                                           const int* __restrict__ src, const int* __restrict__ tgt,
-                                                          const float* __restrict__ P, int64_t ldp, int o,
+                                                          Proj pv, int o,
                                                           const float* __restrict__ bf, const float* __restrict__ w,
                                                           const float* __restrict__ den, const float* __restrict__ out,
                                                           const float* __restrict__ dout, int n_rows, int G,
@@ -132,8 +140,8 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_kernel(const int* __restrict_
         const int e = eid[k];
         const float we = w[e];
         const float vv = val ? val[k] : 1.f;
-        const float* ps = P + (int64_t)src[e] * ldp;
-        const float* pt = P + (int64_t)tgt[e] * ldp + o;
+        const float* ps = pv.ps + (int64_t)src[e] * pv.lds;
+        const float* pt = pv.pt + (int64_t)tgt[e] * pv.ldt;
         float part = 0.f;
 #pragma unroll
         for (int q = 0; q < MAXC; ++q) {
@@ -148,6 +156,223 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_kernel(const int* __restrict_
         for (int off = G >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
         if (lane == 0) da[e] = vv * (part + dsum) * we;
     }
+}
+
+
+// ---- small-graph variants: a whole wave per target row ------------------------------------------
+// 64/G sub-groups of G lanes stride through the row's edges (a 99-edge hub of Citeseer takes 25 trips instead of
+// 99) and are combined with xor-shuffles; used below 65 536 rows, where one lane group per row leaves the chip idle
+// behind the longest row.
+template <int MAXC>
+__global__ __launch_bounds__(256) void gat_agg_fwd_wave_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
+                                                               const float* __restrict__ val,
+                                                               const int* __restrict__ src, const int* __restrict__ tgt,
+                                                               Proj pv, int o,
+                                                               const float* __restrict__ bf, const float* __restrict__ a,
+                                                               const float* __restrict__ amax, float eps, int n_rows, int G,
+                                                               float* __restrict__ out, float* __restrict__ w_out,
+                                                               float* __restrict__ s_out) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_rows) return;
+    const int l = threadIdx.x & 63, lane = l & (G - 1), sg = l / G, ns = 64 / G;
+    const float m = amax[0];
+    float acc[MAXC], bias[MAXC];
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) { acc[q] = 0.f; const int c = lane + q * G; bias[q] = (bf && c < o) ? bf[c] : 0.f; }
+    float s = 0.f;
+    const int end = rowptr[v + 1];
+    for (int k = rowptr[v] + sg; k < end; k += ns) {
+        const int e = eid[k];
+        const float w = expf(a[e] - m);
+        const float we = (val ? val[k] : 1.f) * w;
+        if (lane == 0) w_out[e] = w;
+        s += we;
+        const float* ps = pv.ps + (int64_t)src[e] * pv.lds;
+        const float* pt = pv.pt + (int64_t)tgt[e] * pv.ldt;
+#pragma unroll
+        for (int q = 0; q < MAXC; ++q) {
+            const int c = lane + q * G;
+            if (c < o) acc[q] = fmaf(we, fmaxf(ps[c] + pt[c] + bias[q], 0.f), acc[q]);
+        }
+    }
+    for (int off = G; off < 64; off <<= 1) {
+        s += __shfl_xor(s, off, 64);
+#pragma unroll
+        for (int q = 0; q < MAXC; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+    }
+    const float den = s + eps;
+    if (l == 0) s_out[v] = den;
+    if (sg == 0) {
+#pragma unroll
+        for (int q = 0; q < MAXC; ++q) {
+            const int c = lane + q * G;
+            if (c < o) out[(int64_t)v * o + c] = acc[q] / den;
+        }
+    }
+}
+
+// Backward, wave per row.  The cotangent is either dout[v, c] or, when cot.n > 0, cot_scale * (sum_j cot_j[v, c])
+// masked by out[v, c] > 0 (the relu that follows the layer inside the ODE function): the solver's stage cotangent
+// is combined and masked here instead of in three elementwise launches.
+template <int MAXC>
+__global__ __launch_bounds__(256) void gat_agg_bwd_wave_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
+                                                               const float* __restrict__ val,
+                                                               const int* __restrict__ src, const int* __restrict__ tgt,
+                                                               Proj pv, int o,
+                                                               const float* __restrict__ bf, const float* __restrict__ w,
+                                                               const float* __restrict__ den, const float* __restrict__ out,
+                                                               const float* __restrict__ dout, LinComb cot, float cot_scale,
+                                                               int n_rows, int G,
+                                                               float* __restrict__ dz, float* __restrict__ da) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_rows) return;
+    const int l = threadIdx.x & 63, lane = l & (G - 1), sg = l / G, ns = 64 / G;
+    const float dn = den[v];
+    float dA[MAXC], bias[MAXC];
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+        const int c = lane + q * G;
+        dA[q] = 0.f; bias[q] = 0.f;
+        if (c < o) {
+            const float ov = out[(int64_t)v * o + c];
+            float g;
+            if (cot.n > 0) g = ov > 0.f ? cot_scale * lc_load1(cot, (int64_t)v * o + c) : 0.f;
+            else g = dout[(int64_t)v * o + c];
+            dA[q] = g / dn;
+            dot += g * ov;
+            bias[q] = bf ? bf[c] : 0.f;
+        }
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    const float dsum = -dot / dn;
+    const int end = rowptr[v + 1];
+    for (int k = rowptr[v] + sg; k < end; k += ns) {
+        const int e = eid[k];
+        const float we = w[e];
+        const float vv = val ? val[k] : 1.f;
+        const float* ps = pv.ps + (int64_t)src[e] * pv.lds;
+        const float* pt = pv.pt + (int64_t)tgt[e] * pv.ldt;
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXC; ++q) {
+            const int c = lane + q * G;
+            if (c < o) {
+                const float z = ps[c] + pt[c] + bias[q];
+                part += dA[q] * fmaxf(z, 0.f);
+                dz[(int64_t)e * o + c] = z > 0.f ? vv * we * dA[q] : 0.f;
+            }
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 0) da[e] = vv * (part + dsum) * we;
+    }
+}
+
+// One block: logits of all edges and their maximum in a single launch (E <= 32 768).
+__global__ __launch_bounds__(1024) void gat_logits_small_kernel(Proj pv, const float* __restrict__ bw,
+                                                                const int* __restrict__ src, const int* __restrict__ tgt,
+                                                                int n_edges, float* __restrict__ a, float* __restrict__ amax) {
+    __shared__ float sm[16];
+    float m = -INFINITY;
+    const float b = bw ? bw[0] : 0.f;
+    for (int e = threadIdx.x; e < n_edges; e += 1024) {
+        const float v = pv.as[(int64_t)src[e] * pv.lda] + pv.at[(int64_t)tgt[e] * pv.lda] + b;
+        a[e] = v;
+        m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = sm[0];
+        for (int j = 1; j < 16; ++j) r = fmaxf(r, sm[j]);
+        amax[0] = r;
+    }
+}
+
+// The path of the gradient through the global maximum (GAT/layers.py:47: a - max(a)): da[e*] -= sum_e da[e] with e* the
+// first edge attaining the maximum.  One block; fixed summation order.
+__global__ __launch_bounds__(1024) void gat_maxpath_kernel(const float* __restrict__ a, const float* __restrict__ amax,
+                                                           float* __restrict__ da, int n_edges) {
+    __shared__ float ssum[16];
+    __shared__ int sidx[16];
+    const float m = amax[0];
+    float s = 0.f;
+    int first = INT32_MAX;
+    for (int e = threadIdx.x; e < n_edges; e += 1024) {
+        s += da[e];
+        if (a[e] == m && e < first) first = e;
+    }
+    s = wave_sum(s);
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, 64));
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; sidx[threadIdx.x >> 6] = first; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f; int f = INT32_MAX;
+        for (int j = 0; j < 16; ++j) { t += ssum[j]; f = min(f, sidx[j]); }
+        if (f < n_edges) da[f] -= t;
+    }
+}
+
+// Edge cotangents back to the node-level projections: a wave per node sums dz / da over the edges leaving it
+// (source incidence) and over the edges entering it (target incidence) - the four incidence products of the VJP
+// in one launch.
+template <int MAXC>
+__global__ __launch_bounds__(256) void gat_scatter_kernel(const int* __restrict__ rp_s, const int* __restrict__ e_s,
+                                                          const int* __restrict__ rp_t, const int* __restrict__ e_t,
+                                                          const float* __restrict__ dz, const float* __restrict__ da,
+                                                          int o, int n_rows, int G,
+                                                          float* __restrict__ dps, int64_t lds, float* __restrict__ dpt,
+                                                          int64_t ldt, float* __restrict__ das, float* __restrict__ dat,
+                                                          int64_t lda) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_rows) return;
+    const int l = threadIdx.x & 63, lane = l & (G - 1), sg = l / G, ns = 64 / G;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int* rp = side == 0 ? rp_s : rp_t;
+        const int* ee = side == 0 ? e_s : e_t;
+        float acc[MAXC], sa = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXC; ++q) acc[q] = 0.f;
+        const int end = rp[v + 1];
+        for (int k = rp[v] + sg; k < end; k += ns) {
+            const int e = ee[k];
+            sa += da[e];
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) {
+                const int c = lane + q * G;
+                if (c < o) acc[q] += dz[(int64_t)e * o + c];
+            }
+        }
+        for (int off = G; off < 64; off <<= 1) {
+            sa += __shfl_xor(sa, off, 64);
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+        }
+        float* dp = side == 0 ? dps + (int64_t)v * lds : dpt + (int64_t)v * ldt;
+        if (sg == 0) {
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) {
+                const int c = lane + q * G;
+                if (c < o) dp[c] = acc[q];
+            }
+        }
+        if (l == 0) (side == 0 ? das : dat)[(int64_t)v * lda] = sa;
+    }
+}
+
+// a_t' and the time row of a weight gradient: at (+)= <g_row0, W_row0>, g_row0 *= t  (one tiny block).
+__global__ __launch_bounds__(256) void time_row_fixup_kernel(float* __restrict__ g_row0, const float* __restrict__ w_row0,
+                                                             int len, float t, float* __restrict__ at, int accumulate) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < len; c += 256) s += g_row0[c] * w_row0[c];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float r = (sm[0] + sm[1]) + (sm[2] + sm[3]); at[0] = accumulate ? at[0] + r : r; }
+    for (int c = threadIdx.x; c < len; c += 256) g_row0[c] *= t;
 }
 
 // ---------------- QC edge-conditioned messages ------------------------------------------------
@@ -222,6 +447,75 @@ extern "C" int64_t gode_edge_softmax_scratch_bytes(int64_t n_edges) {
     return b * (int64_t)sizeof(float);
 }
 
+namespace {
+
+constexpr int64_t kWaveRows = 65536;      // below this a whole wave works on one target row
+constexpr int64_t kOneBlockEdges = 32768; // below this logits + maximum are one launch
+
+int check_proj(const Proj& p, int64_t o) {
+    if (!p.ps || !p.pt || !p.as || !p.at) return GODE_E_NULLPTR;
+    if (p.lds < o || p.ldt < o || p.lda < 1) return GODE_E_SHAPE;
+    return 0;
+}
+
+int launch_logits(const Proj& pv, const float* bw, const int32_t* src, const int32_t* tgt, int64_t n_edges,
+                  float* a, float* amax, float* scratch, hipStream_t s) {
+    if (n_edges <= kOneBlockEdges) {
+        hipLaunchKernelGGL(gat_logits_small_kernel, dim3(1), dim3(1024), 0, s, pv, bw, src, tgt, (int)n_edges, a, amax);
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
+    int64_t b = (n_edges + 255) / 256; if (b > 1024) b = 1024; if (b < 1) b = 1;
+    hipLaunchKernelGGL(gat_logits_kernel, dim3((unsigned)b), dim3(256), 0, s, pv, bw, src, tgt, (int)n_edges, a, scratch);
+    GODE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, s, (const float*)scratch, (int)b, amax);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_agg_fwd(const int32_t* rowptr, const int32_t* eid, const float* val, const int32_t* src, const int32_t* tgt,
+                   const Proj& pv, int64_t o, const float* bf, const float* a, const float* amax, float eps,
+                   int64_t n_rows, float* out, float* w_out, float* den_out, hipStream_t s) {
+    const int G = pow2_group((int)o);
+    const int maxc = (int)((o + G - 1) / G);
+    const bool wave = n_rows <= kWaveRows;
+    const int64_t blocks = wave ? (n_rows + 3) / 4 : (n_rows * G + 255) / 256;
+#define GODE_AGG(M)                                                                                              \
+    do {                                                                                                         \
+        if (wave) hipLaunchKernelGGL(gat_agg_fwd_wave_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
+                                     src, tgt, pv, (int)o, bf, a, amax, eps, (int)n_rows, G, out, w_out, den_out); \
+        else hipLaunchKernelGGL(gat_agg_fwd_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
+                                src, tgt, pv, (int)o, bf, a, amax, eps, (int)n_rows, G, out, w_out, den_out);     \
+    } while (0)
+    if (maxc <= 1) GODE_AGG(1); else if (maxc <= 2) GODE_AGG(2); else if (maxc <= 4) GODE_AGG(4); else GODE_AGG(8);
+#undef GODE_AGG
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_agg_bwd(const int32_t* rowptr, const int32_t* eid, const float* val, const int32_t* src, const int32_t* tgt,
+                   const Proj& pv, int64_t o, const float* bf, const float* w, const float* den, const float* out,
+                   const float* dout, const LinComb& cot, float cot_scale, int64_t n_rows, float* dz, float* da,
+                   hipStream_t s) {
+    const int G = pow2_group((int)o);
+    const int maxc = (int)((o + G - 1) / G);
+    const bool wave = n_rows <= kWaveRows || cot.n > 0;      // the cotangent-combining form exists as wave kernel only
+    const int64_t blocks = wave ? (n_rows + 3) / 4 : (n_rows * G + 255) / 256;
+#define GODE_AGG(M)                                                                                              \
+    do {                                                                                                         \
+        if (wave) hipLaunchKernelGGL(gat_agg_bwd_wave_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
+                                     src, tgt, pv, (int)o, bf, w, den, out, dout, cot, cot_scale, (int)n_rows, G, dz, da); \
+        else hipLaunchKernelGGL(gat_agg_bwd_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
+                                src, tgt, pv, (int)o, bf, w, den, out, dout, (int)n_rows, G, dz, da);             \
+    } while (0)
+    if (maxc <= 1) GODE_AGG(1); else if (maxc <= 2) GODE_AGG(2); else if (maxc <= 4) GODE_AGG(4); else GODE_AGG(8);
+#undef GODE_AGG
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
 extern "C" int gode_edge_softmax_logits_f32(const float* P, int64_t ldp, int64_t o, const float* bw,
                                             const int32_t* src, const int32_t* tgt, int64_t n_edges,
                                             float* a, float* amax, float* scratch, void* stream) {
@@ -229,14 +523,7 @@ extern "C" int gode_edge_softmax_logits_f32(const float* P, int64_t ldp, int64_t
     if (!amax || !scratch) return GODE_E_NULLPTR;
     if (n_edges > 0 && (!P || !src || !tgt || !a)) return GODE_E_NULLPTR;
     if (n_edges > INT32_MAX || o > (1 << 20)) return GODE_E_RANGE;
-    hipStream_t s = (hipStream_t)stream;
-    int64_t b = (n_edges + 255) / 256; if (b > 1024) b = 1024; if (b < 1) b = 1;
-    hipLaunchKernelGGL(gat_logits_kernel, dim3((unsigned)b), dim3(256), 0, s, P, ldp, (int)o, bw, src, tgt,
-                       (int)n_edges, a, scratch);
-    GODE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(final_max_kernel, dim3(1), dim3(256), 0, s, (const float*)scratch, (int)b, amax);
-    GODE_LAUNCH_CHECK();
-    return 0;
+    return launch_logits(proj_of(P, ldp, o), bw, src, tgt, n_edges, a, amax, scratch, (hipStream_t)stream);
 }
 
 extern "C" int gode_edge_softmax_agg_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
@@ -248,16 +535,8 @@ extern "C" int gode_edge_softmax_agg_f32_fwd(const int32_t* rowptr, const int32_
     if (n_rows == 0) return 0;
     if (!rowptr || !eid || !src || !tgt || !P || !a || !amax || !out || !w_out || !den_out) return GODE_E_NULLPTR;
     if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
-    hipStream_t s = (hipStream_t)stream;
-    const int G = pow2_group((int)o);
-    const int64_t blocks = (n_rows * G + 255) / 256;
-    const int maxc = (int)((o + G - 1) / G);
-#define GODE_AGG(M) hipLaunchKernelGGL(gat_agg_fwd_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
-                                       src, tgt, P, ldp, (int)o, bf, a, amax, eps, (int)n_rows, G, out, w_out, den_out)
-    if (maxc <= 1) GODE_AGG(1); else if (maxc <= 2) GODE_AGG(2); else if (maxc <= 4) GODE_AGG(4); else GODE_AGG(8);
-#undef GODE_AGG
-    GODE_LAUNCH_CHECK();
-    return 0;
+    return launch_agg_fwd(rowptr, eid, val, src, tgt, proj_of(P, ldp, o), o, bf, a, amax, eps, n_rows, out, w_out,
+                          den_out, (hipStream_t)stream);
 }
 
 extern "C" int gode_edge_softmax_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, const float* val,
@@ -269,14 +548,90 @@ extern "C" int gode_edge_softmax_agg_f32_bwd(const int32_t* rowptr, const int32_
     if (n_rows == 0) return 0;
     if (!rowptr || !eid || !src || !tgt || !P || !w || !den || !out || !dout || !dz || !da) return GODE_E_NULLPTR;
     if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
-    hipStream_t s = (hipStream_t)stream;
+    return launch_agg_bwd(rowptr, eid, val, src, tgt, proj_of(P, ldp, o), o, bf, w, den, out, dout, make_lincomb(nullptr),
+                          1.f, n_rows, dz, da, (hipStream_t)stream);
+}
+
+// ---- the same three steps over separately stored projections, plus the fused pieces of the ODE-function VJP --------
+extern "C" int gode_gat_logits_f32(const gode_gat_proj_t* proj, const float* bw, const int32_t* src, const int32_t* tgt,
+                                   int64_t n_edges, float* a, float* amax, float* scratch, void* stream) {
+    if (!proj || !amax || !scratch) return GODE_E_NULLPTR;
+    if (n_edges < 0) return GODE_E_SHAPE;
+    if (n_edges > INT32_MAX) return GODE_E_RANGE;
+    const Proj pv = proj_of(proj);
+    if (n_edges > 0) { int rc = check_proj(pv, 1); if (rc) return rc; if (!src || !tgt || !a) return GODE_E_NULLPTR; }
+    return launch_logits(pv, bw, src, tgt, n_edges, a, amax, scratch, (hipStream_t)stream);
+}
+
+extern "C" int gode_gat_agg_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
+                                    const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj, int64_t o,
+                                    const float* bf, const float* a, const float* amax, float eps, int64_t n_rows,
+                                    float* out, float* w_out, float* den_out, void* stream) {
+    if (n_rows < 0 || o <= 0) return GODE_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!proj || !rowptr || !eid || !src || !tgt || !a || !amax || !out || !w_out || !den_out) return GODE_E_NULLPTR;
+    if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
+    const Proj pv = proj_of(proj);
+    int rc = check_proj(pv, o); if (rc) return rc;
+    return launch_agg_fwd(rowptr, eid, val, src, tgt, pv, o, bf, a, amax, eps, n_rows, out, w_out, den_out,
+                          (hipStream_t)stream);
+}
+
+extern "C" int gode_gat_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, const float* val,
+                                    const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj, int64_t o,
+                                    const float* bf, const float* w, const float* den, const float* out,
+                                    const float* dout, const gode_lincomb_t* cot, float cot_scale, int64_t n_rows,
+                                    float* dz, float* da, void* stream) {
+    if (n_rows < 0 || o <= 0) return GODE_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!proj || !rowptr || !eid || !src || !tgt || !w || !den || !out || !dz || !da) return GODE_E_NULLPTR;
+    if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
+    const bool use_cot = cot && cot->n > 0;
+    if (use_cot) { int rc = check_lincomb(cot, true); if (rc) return rc; }
+    else if (!dout) return GODE_E_NULLPTR;
+    const Proj pv = proj_of(proj);
+    int rc = check_proj(pv, o); if (rc) return rc;
+    return launch_agg_bwd(rowptr, eid, val, src, tgt, pv, o, bf, w, den, out, dout, make_lincomb(use_cot ? cot : nullptr),
+                          cot_scale, n_rows, dz, da, (hipStream_t)stream);
+}
+
+extern "C" int gode_gat_maxpath_f32(const float* a, const float* amax, float* da, int64_t n_edges, void* stream) {
+    if (n_edges < 0) return GODE_E_SHAPE;
+    if (n_edges == 0) return 0;
+    if (!a || !amax || !da) return GODE_E_NULLPTR;
+    if (n_edges > INT32_MAX) return GODE_E_RANGE;
+    hipLaunchKernelGGL(gat_maxpath_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, amax, da, (int)n_edges);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* eid_src, const int32_t* rowptr_tgt,
+                                    const int32_t* eid_tgt, const float* dz, const float* da, int64_t o, int64_t n_rows,
+                                    float* dps, int64_t ld_s, float* dpt, int64_t ld_t, float* das, float* dat,
+                                    int64_t ld_a, void* stream) {
+    if (n_rows < 0 || o <= 0 || ld_s < o || ld_t < o || ld_a < 1) return GODE_E_SHAPE;
+    if (n_rows == 0) return 0;
+    if (!rowptr_src || !eid_src || !rowptr_tgt || !eid_tgt || !dz || !da || !dps || !dpt || !das || !dat) return GODE_E_NULLPTR;
+    if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
     const int G = pow2_group((int)o);
-    const int64_t blocks = (n_rows * G + 255) / 256;
     const int maxc = (int)((o + G - 1) / G);
-#define GODE_AGG(M) hipLaunchKernelGGL(gat_agg_bwd_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
-                                       src, tgt, P, ldp, (int)o, bf, w, den, out, dout, (int)n_rows, G, dz, da)
-    if (maxc <= 1) GODE_AGG(1); else if (maxc <= 2) GODE_AGG(2); else if (maxc <= 4) GODE_AGG(4); else GODE_AGG(8);
-#undef GODE_AGG
+    const int64_t blocks = (n_rows + 3) / 4;
+    hipStream_t s = (hipStream_t)stream;
+#define GODE_SC(M) hipLaunchKernelGGL(gat_scatter_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr_src, eid_src, \
+                                      rowptr_tgt, eid_tgt, dz, da, (int)o, (int)n_rows, G, dps, ld_s, dpt, ld_t, das, dat, ld_a)
+    if (maxc <= 1) GODE_SC(1); else if (maxc <= 2) GODE_SC(2); else if (maxc <= 4) GODE_SC(4); else GODE_SC(8);
+#undef GODE_SC
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_time_row_fixup_f32(float* g_row0, const float* w_row0, int64_t len, float t, float* at,
+                                       int accumulate, void* stream) {
+    if (len <= 0) return GODE_E_SHAPE;
+    if (!g_row0 || !w_row0 || !at) return GODE_E_NULLPTR;
+    if (len > INT32_MAX) return GODE_E_RANGE;
+    hipLaunchKernelGGL(time_row_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g_row0, w_row0, (int)len, t, at,
+                       accumulate ? 1 : 0);
     GODE_LAUNCH_CHECK();
     return 0;
 }

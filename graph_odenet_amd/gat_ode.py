@@ -1,19 +1,27 @@
 """Fused GAT ODE function  f(t, x) = relu(EdgeAttention([t | GroupNorm(x)]))  (reference: GAT/models.py:172-179 ->
 GAT/layers.py:95-122) and its vector-Jacobian product as plain kernel sequences over the C ABI - no autograd
-graph, no per-edge E x 2i tensor:
+graph, no per-edge E x 2i tensor.
 
-  forward : gode_gn_time_gemm_f32 (GroupNorm + time column + node-level projections P = [t|xn] Wcat, 2o+2 columns)
-            gode_edge_softmax_logits_f32 (a_e, global max), gode_edge_softmax_agg_f32_fwd (per-target normalised sum)
-  adjoint : + gode_edge_softmax_agg_f32_bwd, the global-max path, 4 incidence SpMMs scattering dz / da into dP,
-            gode_gn_time_gemm_bwd_f32 (dx, dgamma, dbeta), gode_wgrad_f32 (dWcat), column sums for the biases.
+The two Linear layers of the reference act on h_e = [x[src_e] | x[tgt_e]] (f: o x 2i, w: 1 x 2i, i = d+1 with the
+time column first).  They are applied at NODE level and split by role, so that the two d x d blocks run on the square
+MFMA kernels and only the two logit columns take the generic path:
 
-The weights of the two Linear layers (f: o x 2i, w: 1 x 2i with i = d+1) are packed once per solve into
-Wcat (i x (2o+2)) = [Wf_src^T | Wf_tgt^T | ww_src^T | ww_tgt^T]; the adjoint integrates the gradient in that
-layout and converts it back to the parameters' layout once, at the end of the solve.
+  Ps = [t|xn] Wsrc   (Wsrc = Wf[:, :i]^T, i x o)      As = [t|xn] ww[:, :i]^T     z_e = Ps[src_e] + Pt[tgt_e] + bf
+  Pt = [t|xn] Wtgt   (Wtgt = Wf[:, i:]^T, i x o)      At = [t|xn] ww[:, i:]^T     a_e = As[src_e] + At[tgt_e] + bw
+
+  forward : 3 x gode_gn_time_gemm_f32 (GroupNorm + time column fused; a multi-term stage input is combined once and
+            written out by the first launch), gode_gat_logits_f32, gode_gat_agg_f32_fwd
+  adjoint : + gode_gat_agg_f32_bwd (stage cotangent combined and relu-masked inside), gode_gat_maxpath_f32,
+            gode_gat_scatter_f32 (all four incidence sums in one launch), 3 x gode_gn_time_gemm_bwd_f32 (accumulating
+            into k_a), 3 x gode_wgrad_f32 + reductions, gode_time_row_fixup_f32, column sums for the biases.
+
+The adjoint integrates [y, a, a_t, theta] with theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta] packed in ONE
+buffer (one RK combine launch for all parameters); the gradient is converted back to the parameters' layout once,
+at the end of the solve.
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 from .gat_layers import edge_graph
 from .solver import Field
 
@@ -27,27 +35,58 @@ class GatOdeSpec:
             raise ValueError("GatOdeSpec: the ODE layer maps d+1 -> d features")
         self.groups, self.eps_gn = int(norm.num_groups), float(norm.eps)
         self.eps = float(layer.eps)
-        self.Wcat = torch.empty(self.i, 2 * self.d + 2, dtype=torch.float32, device=layer.f.weight.device)
+        dev = layer.f.weight.device
+        self.Wsrc = torch.empty(self.i, self.d, dtype=torch.float32, device=dev)
+        self.Wtgt = torch.empty(self.i, self.d, dtype=torch.float32, device=dev)
+        self.Wlog = torch.empty(self.i, 2, dtype=torch.float32, device=dev)
         self.refresh()
         self.bf, self.bw = layer.f.bias.detach(), layer.w.bias.detach()
         self.gamma, self.beta = norm.weight.detach(), norm.bias.detach()
         self.n = eg.n
-
+        i, o, d = self.i, self.d, self.d
+        # offsets inside the packed parameter-gradient buffer
+        self.off = {}
+        p = 0
+        for name, ln in (("Wsrc", i * o), ("Wtgt", i * o), ("Wlog", i * 2), ("bf", o), ("bw", 1), ("gamma", d), ("beta", d)):
+            self.off[name] = (p, p + ln)
+            p += ln
+        self.n_theta = p
 
     def refresh(self):
-        """Re-pack the two Linear weights into Wcat in place (at the start of every solve: the parameters move
-        between solves, the buffer - and a HIP graph captured over it - does not)."""
+        """Re-pack the two Linear weights by role, in place (at the start of every solve: the parameters move between
+        solves, the buffers - and a HIP graph captured over them - do not)."""
         Wf, ww = self.layer.f.weight.detach(), self.layer.w.weight.detach()
         i = self.i
-        torch.cat([Wf[:, :i].t(), Wf[:, i:].t(), ww[:, :i].t(), ww[:, i:].t()], 1, out=self.Wcat)
+        self.Wsrc.copy_(Wf[:, :i].t())
+        self.Wtgt.copy_(Wf[:, i:].t())
+        self.Wlog[:, 0].copy_(ww[0, :i])
+        self.Wlog[:, 1].copy_(ww[0, i:])
+
+    def views(self, theta):
+        o, i = self.d, self.i
+        v = {k: theta[a:b] for k, (a, b) in self.off.items()}
+        v["Wsrc"], v["Wtgt"], v["Wlog"] = v["Wsrc"].view(i, o), v["Wtgt"].view(i, o), v["Wlog"].view(i, 2)
+        return v
 
 
 class _Work:
+    """Buffers of one (graph, d): allocated once, so that neither the eager path nor a captured graph allocates."""
+
     def __init__(self, spec, device):
-        n, o = spec.n, spec.d
-        self.P = torch.empty(n, 2 * o + 2, dtype=torch.float32, device=device)
-        self.dP = torch.empty(n, 2 * o + 2, dtype=torch.float32, device=device)
-        self.g = torch.empty(n, o, dtype=torch.float32, device=device)
+        n, o, E = spec.n, spec.d, spec.eg.E
+        lib = _lib.load()
+        f = dict(dtype=torch.float32, device=device)
+        self.X = torch.empty(n, o, **f)
+        self.Ps, self.Pt, self.A2 = torch.empty(n, o, **f), torch.empty(n, o, **f), torch.empty(n, 2, **f)
+        self.dPs, self.dPt, self.dA2 = torch.empty(n, o, **f), torch.empty(n, o, **f), torch.empty(n, 2, **f)
+        self.a, self.amax = torch.empty(max(E, 1), **f)[:E], torch.empty(1, **f)
+        self.wgt, self.den = torch.zeros(max(E, 1), **f)[:E], torch.empty(n, **f)
+        self.dz, self.da = torch.zeros(max(E, 1), o, **f)[:E], torch.zeros(max(E, 1), **f)[:E]
+        self.proj = ops.gat_proj(self.Ps, self.Pt, self.A2)
+        self.np_b = lib.gode_gemm_bwd_parts(n)
+        self.gp, self.bp = torch.empty(3 * self.np_b, o, **f), torch.empty(3 * self.np_b, o, **f)
+        npw = lib.gode_wgrad_parts(n)
+        self.wp = [torch.empty(npw, spec.i * o, **f), torch.empty(npw, spec.i * o, **f), torch.empty(npw, spec.i * 2, **f)]
 
 
 class GatOdeField(Field):
@@ -61,70 +100,79 @@ class GatOdeField(Field):
     def prepare(self):
         self.s.refresh()
 
-    def _forward(self, t, y_terms, out):
+    def _project(self, t, y_terms):
+        """Ps, Pt, A2 of the stage input; returns the term list later launches of the stage should read."""
         s, w = self.s, self.w
-        ops.gn_time_gemm(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wcat, True, t, out=w.P)
-        a, amax = ops.edge_softmax_logits(w.P, s.d, s.bw, s.eg.src, s.eg.tgt)
-        _, wgt, den = ops.edge_softmax_agg_fwd(s.eg.Mt, s.eg.src, s.eg.tgt, w.P, s.d, s.bf, a, amax, s.eps, out=out)
-        return a, amax, wgt, den      # the outer relu of ODEfunc is the identity on a weighted mean of relu's
+        x_out = w.X if len(y_terms) > 1 else None
+        ops.gn_time_gemm(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, True, t, out=w.Ps, x_out=x_out)
+        terms = [(1.0, w.X)] if x_out is not None else y_terms
+        ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wtgt, True, t, out=w.Pt)
+        ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog, True, t, out=w.A2)
+        return terms
+
+    def _forward(self, t, y_terms, out):
+        s, w, eg = self.s, self.w, self.s.eg
+        terms = self._project(t, y_terms)
+        ops.gat_logits(w.proj, s.bw, eg.src, eg.tgt, w.a, w.amax)
+        ops.gat_agg_fwd(eg.Mt, eg.src, eg.tgt, w.proj, s.d, s.bf, w.a, w.amax, s.eps, out, w.wgt, w.den)
+        return terms                 # the outer relu of ODEfunc is the identity on a weighted mean of relu's
 
     def eval(self, t, terms, out):
         self._forward(t, terms[0], out[0])
 
 
 class GatOdeAdjointField(GatOdeField):
-    """Components: [y, a, a_t, Wcat, bf, bw, gamma, beta]."""
+    """Components: [y, a, a_t, theta] with theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta]."""
 
     def __init__(self, spec, work, order):
         super().__init__(spec, work)
         self.order = order
-        self.n_components = 8
-        self.ratio_groups = [[0], [1], [2], [3, 4, 5, 6, 7]]
+        self.n_components = 4
+        self.ratio_groups = [[0], [1], [2], [3]]
 
     def new_state(self, y_end):
         s = self.s
-        z = torch.zeros_like
-        return [y_end.clone(), z(y_end), torch.zeros(1, dtype=torch.float32, device=y_end.device),
-                z(s.Wcat), z(s.bf), z(s.bw), z(s.gamma), z(s.beta)]
+        return [y_end.clone(), torch.zeros_like(y_end), torch.zeros(1, dtype=torch.float32, device=y_end.device),
+                torch.zeros(s.n_theta, dtype=torch.float32, device=y_end.device)]
 
     def param_grads(self, comps):
         s = self.s
-        i, o = s.i, s.d
-        gW = comps[3]
-        gWf = torch.cat([gW[:, :o].t(), gW[:, o:2 * o].t()], 1).contiguous()                     # o x 2i
-        gww = torch.cat([gW[:, 2 * o], gW[:, 2 * o + 1]]).view(1, 2 * i).contiguous()              # 1 x 2i
-        m = {"gamma": comps[6], "beta": comps[7], "Wf": gWf, "bf": comps[4], "ww": gww, "bw": comps[5]}
+        i = s.i
+        v = s.views(comps[3])
+        gWf = torch.cat([v["Wsrc"].t(), v["Wtgt"].t()], 1).contiguous()                          # o x 2i
+        gww = torch.cat([v["Wlog"][:, 0], v["Wlog"][:, 1]]).view(1, 2 * i).contiguous()           # 1 x 2i
+        m = {"gamma": v["gamma"].clone(), "beta": v["beta"].clone(), "Wf": gWf, "bf": v["bf"].clone(),
+             "ww": gww, "bw": v["bw"].clone()}
         return [m[k] for k in self.order]
 
     def eval(self, t, terms, out):
         s, w = self.s, self.w
         eg, n, o = s.eg, s.n, s.d
-        y_terms = terms[0]
-        a, amax, wgt, den = self._forward(t, y_terms, out[0])
-        # cotangent -a, masked by the outer relu (o > 0)
-        ops.lincomb_(w.g, [(-c, x) for (c, x) in terms[1]])
-        w.g.mul_(out[0] > 0)
-        dz, da = ops.edge_softmax_agg_bwd(eg.Mt, eg.src, eg.tgt, w.P, o, s.bf, wgt, den, out[0], w.g)
-        if eg.E > 0:                                    # path through the global max (GAT/layers.py:47)
-            da.index_add_(0, torch.argmax(a).view(1), -da.sum().view(1))      # no host sync (graph-capturable)
-        dP = w.dP
-        ops.spmm(eg.Ms_inc, dz, out=dP[:, :o])
-        ops.spmm(eg.Mt_inc, dz, out=dP[:, o:2 * o])
-        da2 = da.view(-1, 1)
-        ops.spmm(eg.Ms_inc, da2, out=dP[:, 2 * o:2 * o + 1])
-        ops.spmm(eg.Mt_inc, da2, out=dP[:, 2 * o + 1:2 * o + 2])
-        ops.colsum_(out[4], dz)
-        ops.colsum_(out[5], da2)
-        _, dgp, dbp = ops.gn_time_gemm_bwd(y_terms, n, o, s.groups, s.eps_gn, s.gamma, s.Wcat, True, dP, out=out[1])
-        part = ops.wgrad(y_terms, n, o, s.groups, s.eps_gn, s.gamma, s.beta, dP, True)
-        ops.reduce_parts_(out[3].view(-1), part)
-        out[2].copy_((out[3][0] * s.Wcat[0]).sum().reshape(1))
-        out[3][0].mul_(t)
-        if dgp is not None:
-            ops.reduce_parts_(out[6], dgp)
-            ops.reduce_parts_(out[7], dbp)
+        xt = self._forward(t, terms[0], out[0])
+        g = s.views(out[3])
+        # cotangent -a of the VJP, masked by the outer relu, is formed inside the kernel
+        ops.gat_agg_bwd(eg.Mt, eg.src, eg.tgt, w.proj, o, s.bf, w.wgt, w.den, out[0], w.dz, w.da,
+                        cot_terms=terms[1], cot_scale=-1.0)
+        if eg.E > 0:
+            ops.gat_maxpath_(w.a, w.amax, w.da)            # path through the global max (GAT/layers.py:47)
+        ops.gat_scatter(eg.Ms_inc, eg.Mt_inc, w.dz, w.da, w.dPs, w.dPt, w.dA2)
+        ops.colsum_(g["bf"], w.dz)
+        ops.colsum_(g["bw"], w.da.view(-1, 1))
+        nb = w.np_b
+        affine = s.groups > 0
+        for j, (Wj, dPj) in enumerate(((s.Wsrc, w.dPs), (s.Wtgt, w.dPt), (s.Wlog, w.dA2))):
+            ops.gn_time_gemm_bwd(xt, n, o, s.groups, s.eps_gn, s.gamma, Wj, True, dPj, out=out[1],
+                                 pre_terms=[(1.0, out[1])] if j else None,
+                                 parts=(w.gp[j * nb:(j + 1) * nb], w.bp[j * nb:(j + 1) * nb]) if affine else None)
+        if affine:
+            ops.reduce_parts_(g["gamma"], w.gp)
+            ops.reduce_parts_(g["beta"], w.bp)
         else:
-            out[6].zero_(); out[7].zero_()
+            g["gamma"].zero_(); g["beta"].zero_()
+        for j, (name, Wj, dPj) in enumerate((("Wsrc", s.Wsrc, w.dPs), ("Wtgt", s.Wtgt, w.dPt), ("Wlog", s.Wlog, w.dA2))):
+            ops.wgrad(xt, n, o, s.groups, s.eps_gn, s.gamma, s.beta, dPj, True, part=w.wp[j])
+            ops.reduce_parts_(g[name].view(-1), w.wp[j])
+            ops.time_row_fixup_(g[name][0], Wj[0], t, out[2], accumulate=j > 0)     # a_t' = -a^T df/dt ; row 0 *= t
 
 
 def gat_fields(odefunc, y0):
@@ -142,6 +190,9 @@ def gat_fields(odefunc, y0):
     if eg.n != y0.shape[0]:
         return None
     spec = GatOdeSpec(eg, layer, norm)
-    work = _Work(spec, y0.device)
+    work = getattr(eg, "_ode_work", {}).get((spec.d, y0.device))
+    if work is None:
+        work = _Work(spec, y0.device)
+        eg.__dict__.setdefault("_ode_work", {})[(spec.d, y0.device)] = work
     order = [names[id(p)] for p in plist]
     return GatOdeField(spec, work), (lambda: GatOdeAdjointField(spec, work, order)), tuple(plist)

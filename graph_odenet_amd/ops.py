@@ -96,12 +96,15 @@ def lincomb_(out, terms):
 
 
 _red_scratch = {}
+_retired = []      # outgrown scratch buffers stay allocated: captured HIP graphs may still hold their addresses
 
 
 def _scratch(device, nbytes):
     buf = _red_scratch.get(device)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _retired.append(buf)
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _red_scratch[device] = buf
     return buf
 
@@ -162,7 +165,7 @@ def gn_time_gemm(x_terms, n_rows, d_in, groups, eps, gamma, beta, W, has_time, t
 
 
 def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS, out_scale=1.0, out=None,
-                     want_affine_grads=True, pre_terms=None):
+                     want_affine_grads=True, pre_terms=None, parts=None):
     """Returns (dx, dgamma_part, dbeta_part); parts are [n_part, d_in] block partials (or None).
     With pre_terms the first output is (sum pre_terms) + out_scale * dx."""
     lib = _lib.load()
@@ -176,8 +179,14 @@ def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS,
     dg = db = None
     if want_affine_grads and groups > 0:
         n_part = lib.gode_gemm_bwd_parts(n_rows)
-        dg = torch.empty(n_part, d_in, dtype=torch.float32, device=W.device)
-        db = torch.empty(n_part, d_in, dtype=torch.float32, device=W.device)
+        if parts is not None:
+            dg, db = parts
+            _need(dg, "dgamma parts"); _need(db, "dbeta parts")
+            if dg.numel() != n_part * d_in or db.numel() != n_part * d_in:
+                raise ValueError("gn_time_gemm_bwd: partial buffers have wrong size")
+        else:
+            dg = torch.empty(n_part, d_in, dtype=torch.float32, device=W.device)
+            db = torch.empty(n_part, d_in, dtype=torch.float32, device=W.device)
     lc = lincomb(x_terms)
     pre = None
     if pre_terms is not None:
@@ -191,7 +200,7 @@ def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS,
     return out, dg, db
 
 
-def wgrad(x_terms, n_rows, d_in, groups, eps, gamma, beta, dS, has_time):
+def wgrad(x_terms, n_rows, d_in, groups, eps, gamma, beta, dS, has_time, part=None):
     """Block partials [n_part, (d_in+has_time)*d_out] of dW = [1 | GN(x)]^T dS (row 0 = colsum(dS))."""
     lib = _lib.load()
     _need(dS, "dS"); _need(gamma, "gamma"); _need(beta, "beta")
@@ -200,7 +209,11 @@ def wgrad(x_terms, n_rows, d_in, groups, eps, gamma, beta, dS, has_time):
     d_out = dS.shape[1]
     n_part = lib.gode_wgrad_parts(n_rows)
     K = d_in + (1 if has_time else 0)
-    part = torch.empty(n_part, K * d_out, dtype=torch.float32, device=dS.device)
+    if part is None:
+        part = torch.empty(n_part, K * d_out, dtype=torch.float32, device=dS.device)
+    elif part.numel() != n_part * K * d_out:
+        raise ValueError("wgrad: part buffer has wrong size")
+    _need(part, "part")
     lc = lincomb(x_terms)
     check(lib.gode_wgrad_f32(ctypes.byref(lc), n_rows, d_in, groups, float(eps), ptr(gamma), ptr(beta), ptr(dS),
                              d_out, 1 if has_time else 0, ptr(part), stream_ptr()), "gode_wgrad_f32")
@@ -271,6 +284,75 @@ def edge_softmax_agg_bwd(Mt, src, tgt, P, o, bf, w, den, out, dout):
                                             P.shape[1], o, ptr(bf), ptr(w), ptr(den), ptr(out), ptr(dout), Mt.n_rows,
                                             ptr(dz), ptr(da), stream_ptr()), "gode_edge_softmax_agg_f32_bwd")
     return dz, da
+
+
+# ---- GAT over separately stored projections + fused VJP pieces (gat_ode.py) ------------------------
+def gat_proj(Ps, Pt, A2):
+    """gode_gat_proj_t over Ps, Pt (n x o each) and A2 (n x 2: logit parts by source / by target)."""
+    _need(Ps, "Ps"); _need(Pt, "Pt"); _need(A2, "A2")
+    if Ps.shape != Pt.shape or A2.shape != (Ps.shape[0], 2):
+        raise ValueError("gat_proj: shapes %s %s %s" % (tuple(Ps.shape), tuple(Pt.shape), tuple(A2.shape)))
+    p = _lib.GatProj()
+    p.ps, p.ld_s, p.pt, p.ld_t = Ps.data_ptr(), Ps.shape[1], Pt.data_ptr(), Pt.shape[1]
+    p.as_, p.at, p.ld_a = A2.data_ptr(), A2.data_ptr() + 4, 2
+    return p
+
+
+def gat_logits(proj, bw, src, tgt, a, amax):
+    lib = _lib.load()
+    _need(bw, "bw"); _need(a, "a"); _need(amax, "amax")
+    E = src.numel()
+    sc = _scratch(a.device, lib.gode_edge_softmax_scratch_bytes(E))
+    check(lib.gode_gat_logits_f32(ctypes.byref(proj), ptr(bw), ptr(src), ptr(tgt), E, ptr(a), ptr(amax), ptr(sc),
+                                  stream_ptr()), "gode_gat_logits_f32")
+
+
+def gat_agg_fwd(Mt, src, tgt, proj, o, bf, a, amax, eps, out, w, den):
+    lib = _lib.load()
+    _need(out, "out"); _need(w, "w"); _need(den, "den"); _need(bf, "bf")
+    check(lib.gode_gat_agg_f32_fwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ctypes.byref(proj), o,
+                                   ptr(bf), ptr(a), ptr(amax), float(eps), Mt.n_rows, ptr(out), ptr(w), ptr(den),
+                                   stream_ptr()), "gode_gat_agg_f32_fwd")
+
+
+def gat_agg_bwd(Mt, src, tgt, proj, o, bf, w, den, out, dz, da, dout=None, cot_terms=None, cot_scale=1.0):
+    """dz[E, o], da[E] from the cotangent `dout`, or from cot_scale * (sum cot_terms) masked by out > 0."""
+    lib = _lib.load()
+    _need(out, "out"); _need(dz, "dz"); _need(da, "da"); _need(dout, "dout")
+    lc = None
+    if cot_terms is not None:
+        if _need_terms(cot_terms, "cot") != out.numel():
+            raise ValueError("gat_agg_bwd: cotangent terms have wrong size")
+        lc = lincomb(cot_terms)
+    elif dout is None:
+        raise ValueError("gat_agg_bwd: dout or cot_terms required")
+    check(lib.gode_gat_agg_f32_bwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ctypes.byref(proj), o,
+                                   ptr(bf), ptr(w), ptr(den), ptr(out), ptr(dout),
+                                   ctypes.byref(lc) if lc is not None else None, float(cot_scale), Mt.n_rows,
+                                   ptr(dz), ptr(da), stream_ptr()), "gode_gat_agg_f32_bwd")
+
+
+def gat_maxpath_(a, amax, da):
+    lib = _lib.load()
+    check(lib.gode_gat_maxpath_f32(ptr(a), ptr(amax), ptr(da), a.numel(), stream_ptr()), "gode_gat_maxpath_f32")
+
+
+def gat_scatter(Ms_inc, Mt_inc, dz, da, dPs, dPt, dA2):
+    """Edge cotangents summed per source node into dPs / dA2[:,0] and per target node into dPt / dA2[:,1]."""
+    lib = _lib.load()
+    _need(dz, "dz"); _need(da, "da"); _need(dPs, "dPs"); _need(dPt, "dPt"); _need(dA2, "dA2")
+    n, o = dPs.shape
+    check(lib.gode_gat_scatter_f32(ptr(Ms_inc.rowptr), ptr(Ms_inc.col), ptr(Mt_inc.rowptr), ptr(Mt_inc.col), ptr(dz),
+                                   ptr(da), o, n, ptr(dPs), o, ptr(dPt), o, ctypes.c_void_p(dA2.data_ptr()),
+                                   ctypes.c_void_p(dA2.data_ptr() + 4), 2, stream_ptr()), "gode_gat_scatter_f32")
+
+
+def time_row_fixup_(g_row0, w_row0, t, at, accumulate):
+    """at (+)= <g_row0, w_row0>; g_row0 *= t."""
+    lib = _lib.load()
+    _need(g_row0, "g_row0"); _need(w_row0, "w_row0"); _need(at, "at")
+    check(lib.gode_time_row_fixup_f32(ptr(g_row0), ptr(w_row0), g_row0.numel(), float(t), ptr(at),
+                                      1 if accumulate else 0, stream_ptr()), "gode_time_row_fixup_f32")
 
 
 # ---- QC edge-conditioned messages ---------------------------------------------------------------

@@ -200,6 +200,42 @@ int gode_edge_softmax_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, con
                                   const float* w, const float* den, const float* out, const float* dout,
                                   int64_t n_rows, float* dz, float* da, void* stream);
 
+/* The same three steps over separately stored node-level projections, and the fused pieces of the VJP of the
+ * GAT ODE function (GAT/models.py:172-179 -> GAT/layers.py:95-122).  Splitting P lets the caller produce the two
+ * d x d message blocks with the square MFMA kernel (gode_gn_time_gemm_f32, once per block) and the two logit
+ * columns with a 2-column product:
+ *   z_e = ps[src_e, 0:o] + pt[tgt_e, 0:o] + bf ;  a_e = as[src_e] + at[tgt_e] + bw. */
+typedef struct gode_gat_proj {
+    const float* ps; int64_t ld_s;      /* message part gathered by source, n x o, row stride ld_s */
+    const float* pt; int64_t ld_t;      /* message part gathered by target */
+    const float* as; const float* at;   /* logit parts, element v at as[v*ld_a] / at[v*ld_a] */
+    int64_t ld_a;
+} gode_gat_proj_t;
+int gode_gat_logits_f32(const gode_gat_proj_t* proj, const float* bw, const int32_t* src, const int32_t* tgt,
+                        int64_t n_edges, float* a, float* amax, float* scratch, void* stream);
+int gode_gat_agg_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
+                         const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj, int64_t o,
+                         const float* bf, const float* a, const float* amax, float eps, int64_t n_rows,
+                         float* out, float* w_out, float* den_out, void* stream);
+/* cotangent: dout (n_rows x o), or - when cot (host, nullable) has terms - cot_scale * (sum_j cot_j) masked by out > 0,
+ * i.e. the stage cotangent of the adjoint solve pushed through the relu that follows the layer. */
+int gode_gat_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, const float* val,
+                         const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj, int64_t o,
+                         const float* bf, const float* w, const float* den, const float* out,
+                         const float* dout, const gode_lincomb_t* cot, float cot_scale, int64_t n_rows,
+                         float* dz, float* da, void* stream);
+/* gradient path through the global maximum of the logits (GAT/layers.py:47): da[e*] -= sum(da), e* = first argmax */
+int gode_gat_maxpath_f32(const float* a, const float* amax, float* da, int64_t n_edges, void* stream);
+/* dps[v,:] = sum_{e: src_e = v} dz[e,:], dpt[v,:] = sum_{e: tgt_e = v} dz[e,:], das / dat likewise from da; the
+ * incidence lists are CSR (rowptr over nodes, eid = edge ids in increasing order). */
+int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* eid_src, const int32_t* rowptr_tgt,
+                         const int32_t* eid_tgt, const float* dz, const float* da, int64_t o, int64_t n_rows,
+                         float* dps, int64_t ld_s, float* dpt, int64_t ld_t, float* das, float* dat, int64_t ld_a,
+                         void* stream);
+/* time row of a weight gradient inside the adjoint: at (+)= <g_row0, w_row0>;  g_row0 *= t  (len floats) */
+int gode_time_row_fixup_f32(float* g_row0, const float* w_row0, int64_t len, float t, float* at, int accumulate,
+                            void* stream);
+
 /* ---- QC edge-conditioned messages (QC/mpnn.py:27-29, QC/layers.py:143-145) ----------------
  * out[v,:] = sum_k val[k] * A[e_k] (h x h, row-major) * X[src[e_k], :]   over row v of Etgt (CSR).
  * Backward (one block per edge): dm = edge_val[e] * dM[edge_row[e], :] (edge_row < 0: edge unused),

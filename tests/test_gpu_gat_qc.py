@@ -412,3 +412,38 @@ def test_gat_hip_graph_captured_solves_match_eager(golden):
         close(o1, o2, 1e-6, "state"); close(g1, g2, 1e-6, "gx")
         for a, b in zip(p1, p2):
             close(a, b, 1e-6, "param grad")
+
+
+@pytest.mark.parametrize("o", [7, 16, 128])
+def test_gat_vjp_pieces_vs_torch(o):
+    """gode_gat_scatter_f32 / gode_gat_maxpath_f32 / gode_time_row_fixup_f32 against index_add / argmax / dot on the
+    CPU; random multigraph with a hub node (in-degree 300), isolated nodes and a tie for the maximum logit."""
+    from graph_odenet_amd import ops
+    from graph_odenet_amd.graph import incidence_from_index
+    gen = torch.Generator().manual_seed(o)
+    n, E = 200, 1500
+    src = torch.randint(0, n - 10, (E,), generator=gen)
+    tgt = torch.randint(0, n - 10, (E,), generator=gen)
+    tgt[:300] = 3
+    dz, da = torch.randn(E, o, generator=gen), torch.randn(E, generator=gen)
+    a = torch.randn(E, generator=gen)
+    a[700] = a[900] = a.max() + 1.0                      # two edges attain the maximum: the first one takes the path
+    da_ref = da.clone()
+    da_ref[700] -= da.sum()
+    dad = da.to(dev())
+    ops.gat_maxpath_(a.to(dev()), a.max().reshape(1).to(dev()), dad)
+    close(dad, da_ref, 2e-5, "max path")
+    Ms, Mt = incidence_from_index(src.to(dev()).to(torch.int32), n), incidence_from_index(tgt.to(dev()).to(torch.int32), n)
+    dPs, dPt, dA2 = (torch.full((n, o), 7.0, device=dev()), torch.full((n, o), 7.0, device=dev()),
+                     torch.full((n, 2), 7.0, device=dev()))
+    ops.gat_scatter(Ms, Mt, dz.to(dev()), dad, dPs, dPt, dA2)
+    close(dPs, torch.zeros(n, o).index_add_(0, src, dz), 2e-5, "dPs")
+    close(dPt, torch.zeros(n, o).index_add_(0, tgt, dz), 2e-5, "dPt")
+    close(dA2[:, 0], torch.zeros(n).index_add_(0, src, da_ref), 2e-5, "das")
+    close(dA2[:, 1], torch.zeros(n).index_add_(0, tgt, da_ref), 2e-5, "dat")
+    g0, w0 = torch.randn(o, generator=gen), torch.randn(o, generator=gen)
+    at = torch.tensor([0.25]).to(dev())
+    g0d = g0.to(dev())
+    ops.time_row_fixup_(g0d, w0.to(dev()), 0.3, at, accumulate=True)
+    close(at, torch.tensor([0.25 + float(g0 @ w0)]), 1e-5, "a_t")
+    close(g0d, g0 * 0.3, 1e-6, "time row")
