@@ -322,6 +322,94 @@ class GCNK(_Deep):
         return F.log_softmax(self.gcs[-1](x, adj), dim=1)
 
 
+class _ResDeep(_Deep):
+    """Residual stacks of the depth sweep (reference: GCN/models.py:280-522).  One rule covers the family: the
+    state is saved every `residue_layers` middle layers and added back after the last layer of the block (also
+    after a trailing, incomplete block); `with_norm` replaces the middle dropout by a GroupNorm;
+    `residue_layers` = 0 means no skip connections at all (GCNKnorm)."""
+    with_norm = False
+    min_layers_msg = "Can't make a Residual GCN with less than {} layers using {} layers for each residual block"
+
+    def _setup(self, nfeat, nhid, nclass, dropout, nlayers, residue_layers):
+        need = 2 + residue_layers
+        if nlayers < need:
+            raise ValueError(self.min_layers_msg.format(need, residue_layers))
+        self.n_layers = nlayers
+        self._build(nfeat, nhid, nclass, dropout, [GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)])
+        if self.with_norm:
+            self.norms = nn.ModuleList([_gn(nhid) for _ in range(nlayers - 2)])
+        self.residue_layers = residue_layers
+
+    def forward(self, x, adj):
+        x = F.dropout(F.relu(self.gcs[0](x, adj)), self.dropout, training=self.training)
+        span = self.residue_layers
+        left, saved = 0, None                     # layers left in the current residual block
+        for k, gc in enumerate(self.gcs[1:-1]):
+            if span and left == 0:
+                saved, left = x, span
+            x = F.relu(gc(x, adj))
+            x = self.norms[k](x) if self.with_norm else F.dropout(x, self.dropout, training=self.training)
+            if span:
+                left -= 1
+                if left == 0:
+                    x = x + saved
+        if span and left > 0:
+            x = x + saved
+        return F.log_softmax(self.gcs[-1](x, adj), dim=1)
+
+
+class GCNKnorm(_ResDeep):
+    with_norm = True
+
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=2):
+        super(GCNKnorm, self).__init__()
+        if nlayers < 2:
+            raise ValueError("Can't make a GCN with less than 2 layers")
+        self._setup(nfeat, nhid, nclass, dropout, nlayers, 0)
+
+
+class RESK(_ResDeep):
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=3, residue_layers=1):
+        super(RESK, self).__init__()
+        self._setup(nfeat, nhid, nclass, dropout, nlayers, residue_layers)
+
+
+class RESKnorm(_ResDeep):
+    with_norm = True
+
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=3, residue_layers=1):
+        super(RESKnorm, self).__init__()
+        self._setup(nfeat, nhid, nclass, dropout, nlayers, residue_layers)
+
+
+class RESK1(_ResDeep):
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=3):
+        super(RESK1, self).__init__()
+        self._setup(nfeat, nhid, nclass, dropout, nlayers, 1)
+
+
+class RESK2(_ResDeep):
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=4):
+        super(RESK2, self).__init__()
+        self._setup(nfeat, nhid, nclass, dropout, nlayers, 2)
+
+
+class RESK1norm(_ResDeep):
+    with_norm = True
+
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=3):
+        super(RESK1norm, self).__init__()
+        self._setup(nfeat, nhid, nclass, dropout, nlayers, 1)
+
+
+class RESK2norm(_ResDeep):
+    with_norm = True
+
+    def __init__(self, nfeat, nhid, nclass, dropout, nlayers=4):
+        super(RESK2norm, self).__init__()
+        self._setup(nfeat, nhid, nclass, dropout, nlayers, 2)
+
+
 class _OdeDeep(_Deep):
     def forward(self, x, adj):
         x = F.dropout(F.relu(self.gcs[0](x, adj)), self.dropout, training=self.training)

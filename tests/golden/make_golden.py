@@ -13,6 +13,7 @@ What is captured (inputs AND expected outputs, fp32):
   qc_layers.npz      MPNN_enn_edge (T=1,3) and EdgeGraphConvolution fwd + grads (QC/mpnn.py, QC/layers.py)
   scatter_kat.npz    the scatter_add docstring known-answer vector           (QC/torch_scatter.py:207-218)
   pubmed_graph_sym.npz  Pubmed topology, D^-1/2 (A+I) D^-1/2                 (GCN-dense-paper/utils.py:70-110)
+  gcn_depth_models.npz  depth-sweep model family (GCNK*, RESK*) eval outputs + one gradient (GCN/models.py:255-522)
   set2set.npz        the reference's Set2Set readout alone: q_star + gradients (QC/set2set.py:6-75)
   qc_models.npz      QC model zoo outputs + small gradients on a synthetic batch (QC/layer_models.py:27-232)
 
@@ -265,11 +266,12 @@ if __name__ == "__main__":
         sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
         sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
         pubmed_topology()
-    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set"):
+    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth"):
         main()
         pubmed_topology()
         qc_models_golden()
         set2set_golden()
+        depth_models_golden()
 
 
 def qc_models_golden():
@@ -304,6 +306,36 @@ def qc_models_golden():
     save("qc_models.npz", **res)
 
 
+def depth_models_golden():
+    """Depth-sweep model family of GCN/train_layers.py (GCN/models.py:255-522): eval-mode log-probabilities and the
+    gradient of the first layer's bias for every class at two depths, on a 60-node random graph, hidden 8."""
+    stub = types.ModuleType("torchdiffeq"); stub.odeint_adjoint = None; stub.odeint = None
+    sys.modules["torchdiffeq"] = stub
+    (models,) = ref_import("GCN", "models")
+    n, nfeat, nhid, ncls = 60, 12, 8, 4
+    r, c, v = rand_graph(n, 300, seed=11)
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n))
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(n, nfeat, generator=gen)
+    gout = torch.randn(n, ncls, generator=gen)
+    res = dict(rows=r, cols=c, vals=v, n=n, x=x, gout=gout)
+    torch.manual_seed(13)
+    for name, depths in (("GCNK", (2, 4)), ("GCNKnorm", (2, 5)), ("RESK1", (3, 5)), ("RESK2", (4, 7)),
+                         ("RESK1norm", (3, 6)), ("RESK2norm", (4, 7)), ("RESK", (5, 6)), ("RESKnorm", (5, 6))):
+        for nl in depths:
+            kw = dict(residue_layers=3) if name in ("RESK", "RESKnorm") else {}
+            mdl = getattr(models, name)(nfeat=nfeat, nhid=nhid, nclass=ncls, dropout=0.5, nlayers=nl, **kw)
+            mdl.eval()
+            out = mdl(x, adj)
+            out.backward(gout)
+            key = "%s_%d" % (name, nl)
+            res[key + "__out"] = out
+            res[key + "__gbias0"] = mdl.gcs[0].bias.grad
+            for k, p in mdl.state_dict().items():
+                res[key + "__sd__" + k.replace(".", "__")] = p
+    save("gcn_depth_models.npz", **res)
+
+
 def set2set_golden():
     """The reference's Set2Set module (QC/set2set.py:6-75) alone: h=24, 4 processing steps, 6 graphs of
     uneven size; inputs, lstm parameters, q_star and the gradients of x and of the lstm parameters."""
@@ -331,6 +363,9 @@ def set2set_golden():
 
 
 ROOT_REPO = os.path.dirname(os.path.dirname(OUT))
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "depth":
+    sys.dont_write_bytecode = True
+    depth_models_golden()
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "set2set":
     sys.dont_write_bytecode = True
     set2set_golden()

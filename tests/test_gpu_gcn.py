@@ -436,3 +436,35 @@ def test_hip_graph_captured_solves_match_eager(native, d):
         assert torch.equal(o1, o2) and torch.equal(g1, g2)
         for a, b in zip(p1, p2):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,nl", [("GCNK", 2), ("GCNK", 4), ("GCNKnorm", 2), ("GCNKnorm", 5), ("RESK1", 3), ("RESK1", 5),
+                                     ("RESK2", 4), ("RESK2", 7), ("RESK1norm", 3), ("RESK1norm", 6), ("RESK2norm", 4),
+                                     ("RESK2norm", 7), ("RESK", 5), ("RESK", 6), ("RESKnorm", 5), ("RESKnorm", 6)])
+def test_depth_sweep_models_vs_reference_golden(golden, name, nl):
+    """The model family GCN/train_layers.py sweeps (GCN/models.py:255-522): same state_dict keys, eval outputs and a
+    gradient equal to what the reference classes produced."""
+    from graph_odenet_amd import models
+    g = golden("gcn_depth_models.npz")
+    n = int(g["n"])
+    adj = coo(g, n).to(dev())
+    key = "%s_%d" % (name, nl)
+    kw = dict(residue_layers=3) if name in ("RESK", "RESKnorm") else {}
+    m = getattr(models, name)(nfeat=12, nhid=8, nclass=4, dropout=0.5, nlayers=nl, **kw)
+    pre = key + "__sd__"
+    sd = {k[len(pre):].replace("__", "."): T(v) for k, v in g.items() if k.startswith(pre)}
+    assert set(sd) == set(m.state_dict().keys())
+    m.load_state_dict(sd)
+    m = m.to(dev()).eval()
+    out = m(T(g["x"]).to(dev()), adj)
+    close(out, g[key + "__out"], TOL, key + " out")
+    out.backward(T(g["gout"]).to(dev()))
+    close(m.gcs[0].bias.grad, g[key + "__gbias0"], 2e-5, key + " grad")
+
+
+def test_depth_sweep_models_refuse_too_few_layers():
+    from graph_odenet_amd import models
+    for name, nl in (("GCNK", 1), ("GCNKnorm", 1), ("RESK1", 2), ("RESK2", 3), ("RESK1norm", 2), ("RESK2norm", 3), ("ODEK1", 2),
+                     ("ODEK2", 3)):
+        with pytest.raises(ValueError):
+            getattr(models, name)(nfeat=4, nhid=4, nclass=2, dropout=0.5, nlayers=nl)

@@ -1,0 +1,40 @@
+"""The two training harnesses (reference: GCN/train_res.py, GCN/train_layers.py) run end to end on the GPU with tiny
+settings: flags accepted, stdout lines in the reference's format, pickles in the layout GCN/plot_layers.py reads."""
+import pickle
+import re
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_res_output_format(capsys):
+    from graph_odenet_amd import train_res
+    train_res.main(["--model", "ode3", "--dataset", "cora", "--epochs", "3", "--method", "rk4", "--step_size", "0.25"])
+    out = capsys.readouterr().out
+    lines = out.strip().splitlines()
+    assert len([l for l in lines if l.startswith("Epoch: ")]) == 3
+    assert re.match(r"Epoch: 0001 loss_train: \d+\.\d{4} acc_train: \d\.\d{4} loss_val: \d+\.\d{4} acc_val: \d\.\d{4} "
+                    r"time: \d+\.\d{4}s nfe_f: 16 nfe_b: 16", lines[0])
+    assert any(l.startswith("Test set results: loss= ") for l in lines)
+    assert 'Optimization on dataset "cora" Finished!' in out
+    assert "#Parameters: 23383" in out                       # SURVEY 3.1's count for ode3 on Cora
+
+
+def test_train_layers_sweep(tmp_path, capsys):
+    from graph_odenet_amd import train_layers
+    train_layers.main(["--dataset", "cora", "--runs", "2", "--epochs", "4", "--layers_min", "3", "--layers_max", "4",
+                       "--models", "RESK2,ODEK1", "--method", "rk4", "--step_size", "0.5", "--out_dir", str(tmp_path)])
+    out = capsys.readouterr().out
+    runs = re.findall(r"^(\d) layers's run #(\d) Test -- epochs: (\d+) acc: (\d+\.\d{2})%$", out, flags=re.M)
+    # RESK2 cannot be built with 3 layers (skipped, min_layers raised); ODEK1 runs both depths
+    assert sorted((int(a), int(b)) for a, b, _, _ in runs) == [(3, 0), (3, 1), (4, 0), (4, 0), (4, 1), (4, 1)]
+    assert 'Optimization with model "RESK2" on dataset "cora" Finished!' in out
+    for fam, min_layers in (("RESK2", 4), ("ODEK1", 3)):
+        rec = pickle.load(open(tmp_path / ("cora_%s.pickle" % fam), "rb"))
+        assert rec["min_layers"] == min_layers and rec["max_layers"] == 5
+        assert rec["layer_val_acc"].shape == (5, 2, 4) and rec["layer_val_loss"].shape == (5, 2, 4)
+        assert rec["layer_convergence"].shape == rec["layer_test_acc"].shape == rec["layer_test_loss"].shape == (5, 2)
+        assert (rec["layer_test_acc"][4] > 0).all() and (rec["layer_convergence"][:3] == 4).all()
+        assert torch.isfinite(torch.from_numpy(rec["layer_val_loss"])).all()

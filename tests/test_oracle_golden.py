@@ -175,3 +175,23 @@ def test_set2set_oracle_vs_reference_golden(golden):
     close(x.grad, g["gx"], 2e-5)
     for q, k in zip(p, ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")):
         close(q.grad, g["g__lstm__" + k], 2e-5)
+
+
+DEPTH_CASES = [("GCNK", 2, 0, False), ("GCNK", 4, 0, False), ("GCNKnorm", 2, 0, True), ("GCNKnorm", 5, 0, True),
+               ("RESK1", 3, 1, False), ("RESK1", 5, 1, False), ("RESK2", 4, 2, False), ("RESK2", 7, 2, False),
+               ("RESK1norm", 3, 1, True), ("RESK1norm", 6, 1, True), ("RESK2norm", 4, 2, True), ("RESK2norm", 7, 2, True),
+               ("RESK", 5, 3, False), ("RESK", 6, 3, False), ("RESKnorm", 5, 3, True), ("RESKnorm", 6, 3, True)]
+
+
+@pytest.mark.parametrize("name,nl,res,norm", DEPTH_CASES)
+def test_depth_sweep_models_oracle_vs_reference_golden(golden, name, nl, res, norm):
+    g = golden("gcn_depth_models.npz")
+    n = int(g["n"])
+    adj = R.coo_adj(g["rows"], g["cols"], g["vals"], n, n)
+    key = "%s_%d" % (name, nl)
+    W = [T(g["%s__sd__gcs__%d__weight" % (key, k)]) for k in range(nl)]
+    b = [T(g["%s__sd__gcs__%d__bias" % (key, k)]) for k in range(nl)]
+    norms = [(T(g["%s__sd__norms__%d__weight" % (key, k)]), T(g["%s__sd__norms__%d__bias" % (key, k)]))
+             for k in range(nl - 2)] if norm else None
+    out = R.depth_stack(T(g["x"]), adj, W, b, norms, res, norm)
+    close(out, g[key + "__out"], 1e-5)
