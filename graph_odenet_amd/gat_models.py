@@ -1,11 +1,14 @@
 """GAT-family models (reference: GAT/models.py - the GCN zoo with (x, src, tgt, Mtgt) plumbing).
-Same plan interpreter as graph_odenet_amd.models; only the layer type and the graph arguments differ."""
+Every class of graph_odenet_amd.models exists here under the same name, assembled from the edge-attention layers:
+the model classes are kit-generic (models._PlanModel.kit), so this module defines the two ODE functions of the GAT
+variant and re-binds the zoo to them."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .gat_layers import FixedGraphConvolution, GraphConvolution
-from .models import ODEBlock, _PlanModel, _gn
+from . import models as _gcn_models
+from .models import ODEBlock, _gn
 
 
 class ODEfunc(nn.Module):
@@ -41,30 +44,42 @@ class ODEfunc(nn.Module):
         return gat_fields(self, y0)
 
 
-class _GatPlan(_PlanModel):
-    def forward(self, x, src, tgt, Mtgt):
-        return self.run_plan(x, (src, tgt, Mtgt))
+class ODEfunc2(nn.Module):
+    """Two stacked (edge-attention layer -> relu -> GroupNorm) with the time column re-attached before each layer
+    (reference: GAT/models.py ODEfunc2; the un-normalised state enters the first layer, as there)."""
 
-
-class GCN3(_GatPlan):
-    plan = (("gc", "gc1"), ("relu",), ("drop",), ("gc", "gc2"), ("relu",), ("drop",), ("gc", "gc3"))
-
-    def __init__(self, nfeat, nhid, nclass, dropout):
-        super(GCN3, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = GraphConvolution(nhid, nhid)
-        self.gc3 = GraphConvolution(nhid, nclass)
+    def __init__(self, dim, dropout):
+        super(ODEfunc2, self).__init__()
+        self.norm1, self.norm2 = _gn(dim), _gn(dim)
+        self.gc1 = FixedGraphConvolution(dim + 1, dim)
+        self.gc2 = FixedGraphConvolution(dim + 1, dim)
         self.dropout = dropout
+        self.nfe = 0
+
+    def set_adj(self, src, tgt, Mtgt):
+        self.gc1.set_adj(src, tgt, Mtgt)
+        self.gc2.set_adj(src, tgt, Mtgt)
+
+    def forward(self, t, x):
+        self.nfe += 1
+        tt = torch.ones_like(x[:, :1]) * t
+        x = self.norm1(F.relu(self.gc1(torch.cat([tt, x], 1))))
+        return self.norm2(F.relu(self.gc2(torch.cat([tt, x], 1))))
 
 
-class ODEGCN3(_GatPlan):
-    """GAT/models.py:204-226."""
-    plan = (("gc", "gc1"), ("relu",), ("drop",), ("gc", "gc2"), ("gc", "gc3"))
-    ode_attr = "gc2"
+class GatKit:
+    """Layer classes of the GAT variant (reference: GAT/layers.py, GAT/models.py)."""
+    GraphConvolution = GraphConvolution
+    ODEfunc = ODEfunc
+    ODEfunc2 = ODEfunc2
 
-    def __init__(self, nfeat, nhid, nclass, dropout, method=None, step_size=None, tol=1e-5):
-        super(ODEGCN3, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = ODEBlock(ODEfunc(nhid), tol=tol, method=method, step_size=step_size)
-        self.gc3 = GraphConvolution(nhid, nclass)
-        self.dropout = dropout
+
+def _rebind(name):
+    base = getattr(_gcn_models, name)
+    return type(name, (base,), {"kit": GatKit, "__module__": __name__,
+                                "__doc__": "%s over (x, src, tgt, Mtgt) with the edge-attention layers (reference: GAT/models.py)." % name})
+
+
+for _name in _gcn_models.ZOO:
+    globals()[_name] = _rebind(_name)
+del _name

@@ -36,8 +36,11 @@ def _gn(dim):
 
 
 class _PlanModel(nn.Module):
-    """Interprets `self.plan`; the trailing log_softmax is common to every reference model."""
+    """Interprets `self.plan`; the trailing log_softmax is common to every reference model.  `kit` names the layer
+    classes a model is assembled from (set after the GCN classes below; gat_models.py re-binds it to the GAT ones),
+    and the graph travels as `*graph`: (adj,) here, (src, tgt, Mtgt) for the GAT variant."""
     plan = ()
+    kit = None
     ode_attr = None          # name of the attribute holding the ODEBlock (for the nfe property)
 
     def run_plan(self, x, graph_args):
@@ -62,8 +65,8 @@ class _PlanModel(nn.Module):
                 raise ValueError("unknown plan step %r" % (step,))
         return F.log_softmax(x, dim=1)
 
-    def forward(self, x, adj):
-        return self.run_plan(x, (adj,))
+    def forward(self, x, *graph):
+        return self.run_plan(x, graph)
 
     # `model.nfe = 0` is executed on every model by the harness (GCN/train_res.py:64); ODE models
     # forward it to their block, the others just keep the number.
@@ -187,8 +190,8 @@ class GCN(_PlanModel):
 
     def __init__(self, nfeat, nhid, nclass, dropout):
         super(GCN, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = GraphConvolution(nhid, nclass)
+        self.gc1 = self.kit.GraphConvolution(nfeat, nhid)
+        self.gc2 = self.kit.GraphConvolution(nhid, nclass)
         self.dropout = dropout
 
 
@@ -197,8 +200,8 @@ class RGCN2(_PlanModel):
         super(RGCN2, self).__init__()
         if nhid < nclass:
             raise ValueError("nhid must be equal or larger than nclass")
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = GraphConvolution(nhid, nhid)
+        self.gc1 = self.kit.GraphConvolution(nfeat, nhid)
+        self.gc2 = self.kit.GraphConvolution(nhid, nhid)
         self.nclass = nclass
         self.dropout = dropout
         self.plan = (("gc", "gc1"), ("relu",), ("drop",), ("save",), ("gc", "gc2"), ("add",), ("head", nclass))
@@ -212,8 +215,8 @@ class ODEGCN2(_PlanModel):
         super(ODEGCN2, self).__init__()
         if nhid < nclass:
             raise ValueError("nhid must be equal or larger than nclass")
-        self.gc1 = GraphConvolution(nfeat, nhid)
-        self.gc2 = ODEBlock(ODEfunc(nhid), tol=tol, method=method, step_size=step_size)
+        self.gc1 = self.kit.GraphConvolution(nfeat, nhid)
+        self.gc2 = ODEBlock(self.kit.ODEfunc(nhid), tol=tol, method=method, step_size=step_size)
         self.nclass = nclass
         self.dropout = dropout
         self.plan = (("gc", "gc1"), ("relu",), ("gc", "gc2"), ("head", nclass))
@@ -224,13 +227,13 @@ class _Three(_PlanModel):
 
     def __init__(self, nfeat, nhid, nclass, dropout, norms=(), ode=None):
         super(_Three, self).__init__()
-        self.gc1 = GraphConvolution(nfeat, nhid)
+        self.gc1 = self.kit.GraphConvolution(nfeat, nhid)
         if "norm1" in norms:
             self.norm1 = _gn(nhid)
-        self.gc2 = GraphConvolution(nhid, nhid) if ode is None else ODEBlock(ODEfunc(nhid), **ode)
+        self.gc2 = self.kit.GraphConvolution(nhid, nhid) if ode is None else ODEBlock(self.kit.ODEfunc(nhid), **ode)
         if "norm2" in norms:
             self.norm2 = _gn(nhid)
-        self.gc3 = GraphConvolution(nhid, nclass)
+        self.gc3 = self.kit.GraphConvolution(nhid, nclass)
         self.dropout = dropout
 
 
@@ -294,7 +297,7 @@ class _Deep(_PlanModel):
     """`self.gcs` ModuleList: first layer, a list of middle blocks, last layer."""
 
     def _build(self, nfeat, nhid, nclass, dropout, middle):
-        self.gcs = nn.ModuleList([GraphConvolution(nfeat, nhid)] + list(middle) + [GraphConvolution(nhid, nclass)])
+        self.gcs = nn.ModuleList([self.kit.GraphConvolution(nfeat, nhid)] + list(middle) + [self.kit.GraphConvolution(nhid, nclass)])
         self.dropout = dropout
 
     @property
@@ -314,12 +317,12 @@ class GCNK(_Deep):
         if nlayers < 2:
             raise ValueError("Can't make a GCN with less than 2 layers")
         self.n_layers = nlayers
-        self._build(nfeat, nhid, nclass, dropout, [GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)])
+        self._build(nfeat, nhid, nclass, dropout, [self.kit.GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)])
 
-    def forward(self, x, adj):
+    def forward(self, x, *graph):
         for gc in self.gcs[:-1]:
-            x = F.dropout(F.relu(gc(x, adj)), self.dropout, training=self.training)
-        return F.log_softmax(self.gcs[-1](x, adj), dim=1)
+            x = F.dropout(F.relu(gc(x, *graph)), self.dropout, training=self.training)
+        return F.log_softmax(self.gcs[-1](x, *graph), dim=1)
 
 
 class _ResDeep(_Deep):
@@ -335,19 +338,19 @@ class _ResDeep(_Deep):
         if nlayers < need:
             raise ValueError(self.min_layers_msg.format(need, residue_layers))
         self.n_layers = nlayers
-        self._build(nfeat, nhid, nclass, dropout, [GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)])
+        self._build(nfeat, nhid, nclass, dropout, [self.kit.GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)])
         if self.with_norm:
             self.norms = nn.ModuleList([_gn(nhid) for _ in range(nlayers - 2)])
         self.residue_layers = residue_layers
 
-    def forward(self, x, adj):
-        x = F.dropout(F.relu(self.gcs[0](x, adj)), self.dropout, training=self.training)
+    def forward(self, x, *graph):
+        x = F.dropout(F.relu(self.gcs[0](x, *graph)), self.dropout, training=self.training)
         span = self.residue_layers
         left, saved = 0, None                     # layers left in the current residual block
         for k, gc in enumerate(self.gcs[1:-1]):
             if span and left == 0:
                 saved, left = x, span
-            x = F.relu(gc(x, adj))
+            x = F.relu(gc(x, *graph))
             x = self.norms[k](x) if self.with_norm else F.dropout(x, self.dropout, training=self.training)
             if span:
                 left -= 1
@@ -355,7 +358,7 @@ class _ResDeep(_Deep):
                     x = x + saved
         if span and left > 0:
             x = x + saved
-        return F.log_softmax(self.gcs[-1](x, adj), dim=1)
+        return F.log_softmax(self.gcs[-1](x, *graph), dim=1)
 
 
 class GCNKnorm(_ResDeep):
@@ -411,11 +414,11 @@ class RESK2norm(_ResDeep):
 
 
 class _OdeDeep(_Deep):
-    def forward(self, x, adj):
-        x = F.dropout(F.relu(self.gcs[0](x, adj)), self.dropout, training=self.training)
+    def forward(self, x, *graph):
+        x = F.dropout(F.relu(self.gcs[0](x, *graph)), self.dropout, training=self.training)
         for block in self.gcs[1:-1]:
-            x = block(x, adj)
-        return F.log_softmax(self.gcs[-1](x, adj), dim=1)
+            x = block(x, *graph)
+        return F.log_softmax(self.gcs[-1](x, *graph), dim=1)
 
 
 class ODEK1(_OdeDeep):
@@ -427,7 +430,7 @@ class ODEK1(_OdeDeep):
             raise ValueError("Can't make a Residual GCN with less than 3 layers")
         self.n_layers = nlayers
         self._build(nfeat, nhid, nclass, dropout,
-                    [ODEBlock(ODEfunc(nhid), method=method, step_size=step_size) for _ in range(nlayers - 2)])
+                    [ODEBlock(self.kit.ODEfunc(nhid), method=method, step_size=step_size) for _ in range(nlayers - 2)])
 
 
 class ODEK2(_OdeDeep):
@@ -439,8 +442,21 @@ class ODEK2(_OdeDeep):
         if nlayers < 4:
             raise ValueError("Can't make a Residual GCN with less than 4 layers using 2 layers for each residual block")
         self.n_layers = nlayers
-        middle = [ODEBlock(ODEfunc2(nhid, dropout), dropout, method=method, step_size=step_size)
+        middle = [ODEBlock(self.kit.ODEfunc2(nhid, dropout), dropout, method=method, step_size=step_size)
                   for _ in range((nlayers - 2) // 2)]
         if nlayers % 2 == 1:
-            middle.append(ODEBlock(ODEfunc(nhid), method=method, step_size=step_size))
+            middle.append(ODEBlock(self.kit.ODEfunc(nhid), method=method, step_size=step_size))
         self._build(nfeat, nhid, nclass, dropout, middle)
+
+
+class GcnKit:
+    """Layer classes of the GCN variant (reference: GCN/layers.py, GCN/models.py)."""
+    GraphConvolution = GraphConvolution
+    ODEfunc = ODEfunc
+    ODEfunc2 = ODEfunc2
+
+
+_PlanModel.kit = GcnKit
+
+ZOO = ("GCN", "RGCN2", "ODEGCN2", "GCN3", "GCN3norm", "RGCN3", "RGCN3norm", "RGCN3fullnorm", "ODEGCN3", "ODEGCN3fullnorm",
+       "GCNK", "GCNKnorm", "RESK1", "RESK2", "RESK", "RESK1norm", "RESK2norm", "RESKnorm", "ODEK1", "ODEK2")

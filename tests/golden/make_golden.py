@@ -14,6 +14,7 @@ What is captured (inputs AND expected outputs, fp32):
   scatter_kat.npz    the scatter_add docstring known-answer vector           (QC/torch_scatter.py:207-218)
   pubmed_graph_sym.npz  Pubmed topology, D^-1/2 (A+I) D^-1/2                 (GCN-dense-paper/utils.py:70-110)
   gcn_depth_models.npz  depth-sweep model family (GCNK*, RESK*) eval outputs + one gradient (GCN/models.py:255-522)
+  gat_zoo.npz        non-ODE GAT model zoo eval outputs + one gradient (GAT/models.py)
   set2set.npz        the reference's Set2Set readout alone: q_star + gradients (QC/set2set.py:6-75)
   qc_models.npz      QC model zoo outputs + small gradients on a synthetic batch (QC/layer_models.py:27-232)
 
@@ -266,12 +267,13 @@ if __name__ == "__main__":
         sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
         sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
         pubmed_topology()
-    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth"):
+    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth", "gat_zoo"):
         main()
         pubmed_topology()
         qc_models_golden()
         set2set_golden()
         depth_models_golden()
+        gat_zoo_golden()
 
 
 def qc_models_golden():
@@ -336,6 +338,36 @@ def depth_models_golden():
     save("gcn_depth_models.npz", **res)
 
 
+def gat_zoo_golden():
+    """Non-ODE members of the GAT model zoo (GAT/models.py) on a 40-node / 160-edge random multigraph, hidden 8:
+    eval-mode outputs and the gradient of the first layer's message bias."""
+    stub = types.ModuleType("torchdiffeq"); stub.odeint_adjoint = None; stub.odeint = None
+    sys.modules["torchdiffeq"] = stub
+    (gmodels,) = ref_import("GAT", "models")
+    n, E, nfeat, nhid, ncls = 40, 160, 10, 8, 3
+    gen = torch.Generator().manual_seed(21)
+    src = torch.randint(0, n, (E,), generator=gen)
+    tgt = torch.randint(0, n - 4, (E,), generator=gen)          # the last 4 nodes receive nothing
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+    x = torch.randn(n, nfeat, generator=gen)
+    gout = torch.randn(n, ncls, generator=gen)
+    res = dict(src=src, tgt=tgt, n=n, x=x, gout=gout)
+    torch.manual_seed(22)
+    for name, kw in (("GCN", {}), ("RGCN2", {}), ("GCN3", {}), ("GCN3norm", {}), ("RGCN3", {}), ("RGCN3norm", {}),
+                     ("RGCN3fullnorm", {}), ("GCNK", dict(nlayers=4)), ("RESK2", dict(nlayers=5)),
+                     ("RESK1norm", dict(nlayers=4))):
+        mdl = getattr(gmodels, name)(nfeat=nfeat, nhid=nhid, nclass=ncls, dropout=0.5, **kw)
+        mdl.eval()
+        out = mdl(x, src, tgt, Mtgt)
+        out.backward(gout)
+        first = mdl.gcs[0] if hasattr(mdl, "gcs") else mdl.gc1
+        res[name + "__out"] = out
+        res[name + "__gbias0"] = first.f.bias.grad
+        for k, p in mdl.state_dict().items():
+            res[name + "__sd__" + k.replace(".", "__")] = p
+    save("gat_zoo.npz", **res)
+
+
 def set2set_golden():
     """The reference's Set2Set module (QC/set2set.py:6-75) alone: h=24, 4 processing steps, 6 graphs of
     uneven size; inputs, lstm parameters, q_star and the gradients of x and of the lstm parameters."""
@@ -363,6 +395,9 @@ def set2set_golden():
 
 
 ROOT_REPO = os.path.dirname(os.path.dirname(OUT))
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "gat_zoo":
+    sys.dont_write_bytecode = True
+    gat_zoo_golden()
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "depth":
     sys.dont_write_bytecode = True
     depth_models_golden()
