@@ -74,9 +74,13 @@ class GatKit:
     ODEfunc2 = ODEfunc2
 
 
+def _forward(self, x, src, tgt, Mtgt):
+    return self._apply(x, (src, tgt, Mtgt))
+
+
 def _rebind(name):
     base = getattr(_gcn_models, name)
-    return type(name, (base,), {"kit": GatKit, "__module__": __name__,
+    return type(name, (base,), {"kit": GatKit, "forward": _forward, "__module__": __name__,
                                 "__doc__": "%s over (x, src, tgt, Mtgt) with the edge-attention layers (reference: GAT/models.py)." % name})
 
 
