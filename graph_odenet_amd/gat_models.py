@@ -75,7 +75,7 @@ class GatKit:
 
 
 def _forward(self, x, src, tgt, Mtgt):
-    return self._apply(x, (src, tgt, Mtgt))
+    return self._body(x, (src, tgt, Mtgt))
 
 
 def _rebind(name):

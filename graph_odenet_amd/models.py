@@ -66,9 +66,9 @@ class _PlanModel(nn.Module):
         return F.log_softmax(x, dim=1)
 
     def forward(self, x, adj):
-        return self._apply(x, (adj,))
+        return self._body(x, (adj,))
 
-    def _apply(self, x, graph):
+    def _body(self, x, graph):
         """Model body over the graph argument tuple; `forward` only fixes the public signature of the variant."""
         return self.run_plan(x, graph)
 
@@ -323,7 +323,7 @@ class GCNK(_Deep):
         self.n_layers = nlayers
         self._build(nfeat, nhid, nclass, dropout, [self.kit.GraphConvolution(nhid, nhid) for _ in range(nlayers - 2)])
 
-    def _apply(self, x, graph):
+    def _body(self, x, graph):
         for gc in self.gcs[:-1]:
             x = F.dropout(F.relu(gc(x, *graph)), self.dropout, training=self.training)
         return F.log_softmax(self.gcs[-1](x, *graph), dim=1)
@@ -347,7 +347,7 @@ class _ResDeep(_Deep):
             self.norms = nn.ModuleList([_gn(nhid) for _ in range(nlayers - 2)])
         self.residue_layers = residue_layers
 
-    def _apply(self, x, graph):
+    def _body(self, x, graph):
         x = F.dropout(F.relu(self.gcs[0](x, *graph)), self.dropout, training=self.training)
         span = self.residue_layers
         left, saved = 0, None                     # layers left in the current residual block
@@ -418,7 +418,7 @@ class RESK2norm(_ResDeep):
 
 
 class _OdeDeep(_Deep):
-    def _apply(self, x, graph):
+    def _body(self, x, graph):
         x = F.dropout(F.relu(self.gcs[0](x, *graph)), self.dropout, training=self.training)
         for block in self.gcs[1:-1]:
             x = block(x, *graph)
