@@ -72,18 +72,11 @@ class GatKit:
     GraphConvolution = GraphConvolution
     ODEfunc = ODEfunc
     ODEfunc2 = ODEfunc2
+    input_dropout = False
 
 
 def _forward(self, x, src, tgt, Mtgt):
-    return self._body(x, (src, tgt, Mtgt))
+    return self._body(self._input(x), (src, tgt, Mtgt))
 
 
-def _rebind(name):
-    base = getattr(_gcn_models, name)
-    return type(name, (base,), {"kit": GatKit, "forward": _forward, "__module__": __name__,
-                                "__doc__": "%s over (x, src, tgt, Mtgt) with the edge-attention layers (reference: GAT/models.py)." % name})
-
-
-for _name in _gcn_models.ZOO:
-    globals()[_name] = _rebind(_name)
-del _name
+_gcn_models.rebind_zoo(globals(), __name__, GatKit, forward=_forward, what="GAT")

@@ -66,7 +66,11 @@ class _PlanModel(nn.Module):
         return F.log_softmax(x, dim=1)
 
     def forward(self, x, adj):
-        return self._body(x, (adj,))
+        return self._body(self._input(x), (adj,))
+
+    def _input(self, x):
+        # GCN-dense-paper/models.py applies dropout to the input features of every model (e.g. :17, :222)
+        return F.dropout(x, self.dropout, training=self.training) if self.kit.input_dropout else x
 
     def _body(self, x, graph):
         """Model body over the graph argument tuple; `forward` only fixes the public signature of the variant."""
@@ -91,11 +95,12 @@ class ODEfunc(nn.Module):
     """f(t, x) = relu(gc1([t | norm1(x)])), counting calls in `nfe` (reference: GCN/models.py:161-179)."""
 
     _gode_counts_nfe = True
+    layer_cls = FixedGraphConvolution       # variants (dense_paper.py) substitute their own initialisation
 
     def __init__(self, dim):
         super(ODEfunc, self).__init__()
         self.norm1 = _gn(dim)
-        self.gc1 = FixedGraphConvolution(dim + 1, dim)
+        self.gc1 = self.layer_cls(dim + 1, dim)
         self.nfe = 0
         self._shared = None
 
@@ -139,11 +144,13 @@ class ODEfunc2(nn.Module):
     (reference: GCN/models.py:551-575).  norm1 is folded into the prologue of the second dense product;
     norm2 has no consumer inside f and runs as the stand-alone GroupNorm kernel."""
 
+    layer_cls = FixedGraphConvolution
+
     def __init__(self, dim, dropout):
         super(ODEfunc2, self).__init__()
         self.norm1, self.norm2 = _gn(dim), _gn(dim)
-        self.gc1 = FixedGraphConvolution(dim + 1, dim)
-        self.gc2 = FixedGraphConvolution(dim + 1, dim)
+        self.gc1 = self.layer_cls(dim + 1, dim)
+        self.gc2 = self.layer_cls(dim + 1, dim)
         self.dropout = dropout
         self.nfe = 0
 
@@ -454,13 +461,25 @@ class ODEK2(_OdeDeep):
 
 
 class GcnKit:
-    """Layer classes of the GCN variant (reference: GCN/layers.py, GCN/models.py)."""
+    """Layer classes of the GCN variant (reference: GCN/layers.py, GCN/models.py; GCN-sum is the same code)."""
     GraphConvolution = GraphConvolution
     ODEfunc = ODEfunc
     ODEfunc2 = ODEfunc2
+    input_dropout = False
 
 
 _PlanModel.kit = GcnKit
 
 ZOO = ("GCN", "RGCN2", "ODEGCN2", "GCN3", "GCN3norm", "RGCN3", "RGCN3norm", "RGCN3fullnorm", "ODEGCN3", "ODEGCN3fullnorm",
        "GCNK", "GCNKnorm", "RESK1", "RESK2", "RESK", "RESK1norm", "RESK2norm", "RESKnorm", "ODEK1", "ODEK2")
+
+
+def rebind_zoo(namespace, module_name, kit, forward=None, what=""):
+    """Defines every class of ZOO in `namespace` as a subclass assembled from `kit` (optionally with another public
+    forward signature): how the GAT, dense-paper and MLP-sum variants get their `models` module."""
+    for name in ZOO:
+        attrs = {"kit": kit, "__module__": module_name,
+                 "__doc__": "%s of the %s variant (same body as graph_odenet_amd.models.%s)." % (name, what, name)}
+        if forward is not None:
+            attrs["forward"] = forward
+        namespace[name] = type(name, (globals()[name],), attrs)

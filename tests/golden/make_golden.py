@@ -14,6 +14,7 @@ What is captured (inputs AND expected outputs, fp32):
   scatter_kat.npz    the scatter_add docstring known-answer vector           (QC/torch_scatter.py:207-218)
   pubmed_graph_sym.npz  Pubmed topology, D^-1/2 (A+I) D^-1/2                 (GCN-dense-paper/utils.py:70-110)
   gcn_depth_models.npz  depth-sweep model family (GCNK*, RESK*) eval outputs + one gradient (GCN/models.py:255-522)
+  gcn_variants.npz   GCN-mlp-sum layer / ODEfunc / models and GCN-dense-paper models (their layers.py, models.py)
   gat_zoo.npz        non-ODE GAT model zoo eval outputs + one gradient (GAT/models.py)
   set2set.npz        the reference's Set2Set readout alone: q_star + gradients (QC/set2set.py:6-75)
   qc_models.npz      QC model zoo outputs + small gradients on a synthetic batch (QC/layer_models.py:27-232)
@@ -267,13 +268,14 @@ if __name__ == "__main__":
         sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
         sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
         pubmed_topology()
-    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth", "gat_zoo"):
+    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth", "gat_zoo", "variants"):
         main()
         pubmed_topology()
         qc_models_golden()
         set2set_golden()
         depth_models_golden()
         gat_zoo_golden()
+        variants_golden()
 
 
 def qc_models_golden():
@@ -368,6 +370,53 @@ def gat_zoo_golden():
     save("gat_zoo.npz", **res)
 
 
+def variants_golden():
+    """GCN-mlp-sum (MLP graph layer + one model) and GCN-dense-paper (one model; eval mode, so its input dropout is the
+    identity) on a 50-node random graph: outputs, input / parameter gradients, state dicts."""
+    stub = types.ModuleType("torchdiffeq"); stub.odeint_adjoint = None; stub.odeint = None
+    sys.modules["torchdiffeq"] = stub
+    n, nfeat, nhid, ncls = 50, 9, 8, 3
+    r, c, v = rand_graph(n, 260, seed=31)
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n))
+    gen = torch.Generator().manual_seed(32)
+    x = torch.randn(n, nfeat, generator=gen)
+    res = dict(rows=r, cols=c, vals=v, n=n, x=x)
+    torch.manual_seed(33)
+    mlayers, mmodels = ref_import("GCN-mlp-sum", "layers", "models")
+    lay = mlayers.GraphConvolution(nfeat, nhid)
+    xi = x.clone().requires_grad_(True)
+    out = lay(xi, adj)
+    gout = torch.randn(out.shape, generator=gen)
+    out.backward(gout)
+    res.update(mlp_layer__out=out, mlp_layer__gout=gout, mlp_layer__gx=xi.grad)
+    for k, p in lay.state_dict().items():
+        res["mlp_layer__sd__" + k.replace(".", "__")] = p
+    for k, p in lay.named_parameters():
+        res["mlp_layer__g__" + k.replace(".", "__")] = p.grad
+    f = mmodels.ODEfunc(nhid)
+    f.set_adj(adj)
+    h = torch.randn(n, nhid, generator=gen)
+    res.update(mlp_odefunc__x=h, mlp_odefunc__out=f(torch.tensor(0.4), h))
+    for k, p in f.state_dict().items():
+        res["mlp_odefunc__sd__" + k.replace(".", "__")] = p
+    gm = torch.randn(n, ncls, generator=gen)
+    res["gmodel"] = gm
+    for tag, mods, name, kw in (("mlp", mmodels, "RGCN3norm", {}), ("mlp", mmodels, "RESK2", dict(nlayers=5)),
+                                ("dense", ref_import("GCN-dense-paper", "layers", "models")[1], "RGCN3fullnorm", {}),
+                                ("dense", ref_import("GCN-dense-paper", "layers", "models")[1], "GCNK", dict(nlayers=3))):
+        mdl = getattr(mods, name)(nfeat=nfeat, nhid=nhid, nclass=ncls, dropout=0.5, **kw)
+        mdl.eval()
+        o = mdl(x, adj)
+        o.backward(gm)
+        key = "%s_%s" % (tag, name)
+        res[key + "__out"] = o
+        for k, p in mdl.state_dict().items():
+            res[key + "__sd__" + k.replace(".", "__")] = p
+        k0, p0 = next(iter(mdl.named_parameters()))
+        res[key + "__g0"] = p0.grad
+    save("gcn_variants.npz", **res)
+
+
 def set2set_golden():
     """The reference's Set2Set module (QC/set2set.py:6-75) alone: h=24, 4 processing steps, 6 graphs of
     uneven size; inputs, lstm parameters, q_star and the gradients of x and of the lstm parameters."""
@@ -395,6 +444,9 @@ def set2set_golden():
 
 
 ROOT_REPO = os.path.dirname(os.path.dirname(OUT))
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "variants":
+    sys.dont_write_bytecode = True
+    variants_golden()
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "gat_zoo":
     sys.dont_write_bytecode = True
     gat_zoo_golden()

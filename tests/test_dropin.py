@@ -78,3 +78,34 @@ def test_qc_shims(shim_path):
     assert list(inspect.signature(m.forward).parameters) == ["x", "Esrc", "Etgt", "edge_data"]
     e = layers.EdgeGraphConvolution(13, 73, node_layers=1, edge_layers=1, bias=True)
     assert e.weight.shape == (13, 73) and list(inspect.signature(e.forward).parameters) == ["input", "Esrc", "Etgt", "edge_data"]
+
+
+REFERENCE_ZOO = ["GCN", "RGCN2", "ODEGCN2", "GCN3", "GCN3norm", "RGCN3", "RGCN3norm", "RGCN3fullnorm", "ODEfunc", "ODEBlock",
+                 "ODEGCN3", "ODEGCN3fullnorm", "GCNK", "GCNKnorm", "RESK1", "RESK2", "RESK", "RESK1norm", "RESK2norm",
+                 "RESKnorm", "ODEK1", "ODEfunc2", "ODEK2"]      # `grep ^class */models.py` of the reference, every variant
+
+
+@pytest.mark.parametrize("variant,first_keys", [
+    ("GCN", ["gc1.weight", "gc1.bias"]), ("GCN-sum", ["gc1.weight", "gc1.bias"]),
+    ("GCN-dense-paper", ["gc1.weight", "gc1.bias"]),
+    ("GCN-mlp-sum", ["gc1.mlp.layers.0.linear.weight", "gc1.mlp.layers.0.linear.bias"]),
+    ("GAT", ["gc1.f.weight", "gc1.f.bias"])])
+def test_every_variant_exports_the_reference_zoo(shim_path, variant, first_keys):
+    """`import models` / `import layers` from each variant's shim directory: every class name the reference's
+    models.py defines is there (train_res.py / train_layers.py index `models.<Name>` at import time), assembled from
+    that variant's layers."""
+    shim_path(variant)
+    models = importlib.import_module("models")
+    layers = importlib.import_module("layers")
+    for name in REFERENCE_ZOO:
+        assert hasattr(models, name), "%s lacks %s" % (variant, name)
+    assert hasattr(layers, "GraphConvolution") and hasattr(layers, "FixedGraphConvolution")
+    m = models.ODEGCN3(nfeat=7, nhid=8, nclass=3, dropout=0.5)
+    assert list(m.state_dict().keys())[:2] == first_keys
+    assert isinstance(m.gc1, layers.GraphConvolution)
+    deep = models.RESK2norm(nfeat=7, nhid=8, nclass=3, dropout=0.5, nlayers=5)
+    assert len(deep.gcs) == 5 and len(deep.norms) == 3 and isinstance(deep.gcs[2], layers.GraphConvolution)
+    if variant == "GCN-mlp-sum":
+        assert all(hasattr(layers, n) for n in ("MyLinear", "NonLinear", "MLP"))
+    expected = ["x", "src", "tgt", "Mtgt"] if variant == "GAT" else ["x", "adj"]
+    assert list(inspect.signature(m.forward).parameters) == expected
