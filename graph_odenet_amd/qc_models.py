@@ -197,6 +197,19 @@ def _output_function(kind, target_features):
     return lambda x: F.log_softmax(x, dim=1)
 
 
+get_output_function = _output_function       # the reference's name (QC/layer_models.py:10)
+
+
+class UnimplementedModel(nn.Module):
+    """Placeholder QC/train_egcn.py's model_dict maps three of its choices to (QC/layer_models.py:19-24)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("Model not implemented yet")
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("Model not implemented yet")
+
+
 # ---- models -------------------------------------------------------------------------------------------
 class _QCBase(nn.Module):
     def _finish(self, kind, target_features):
@@ -322,3 +335,97 @@ class EdgeRES1_K_Set2Set(_QCBase):
         x = self.gcmid(self.mlpin(node_features), Esrc, Etgt, self.ee(edge_features))
         x = self.s2s(x, batch)[:, :x.size(1)]
         return self.output_function(self.mlpout(x))
+
+
+# ---- the fixed-depth models of QC/models.py (used by QC/train_egcn_multitask.py) ------------------------------------
+class _Fixed(nn.Module):
+    """`type` decides between raw outputs and log_softmax (QC/models.py:36,64; the two EdgeGCN3 classes read
+    self.type without ever setting it - it is set here)."""
+
+    def _out(self, x):
+        return F.log_softmax(x, dim=1) if self.type == "classification" else x
+
+
+class MPNN_ENN_Sum(_Fixed):
+    """QC/models.py:10-36: input Linear, edge encoder, MPNN_enn_edge (its own default T = 8), output Linear, per-graph sum."""
+
+    def __init__(self, node_features, edge_features, hidden_features, out_features, processing_steps=12,
+                 type="regression", **kwargs):
+        super().__init__()
+        self.input = nn.Linear(node_features, hidden_features)
+        self.ee = EdgeEncoderMLP(edge_features, hidden_features)
+        self.mpnn = MPNN_enn_edge(edge_features, hidden_features)
+        self.output = nn.Linear(hidden_features, out_features)
+        self.type = type
+
+    def forward(self, node_features, edge_features, Esrc, Etgt, batch):
+        x = self.mpnn(self.input(node_features), Esrc, Etgt, self.ee(edge_features))
+        return self._out(segment_sum(self.output(x), batch))
+
+
+class MPNN_ENN_Set2Set(_Fixed):
+    """QC/models.py:38-66."""
+
+    def __init__(self, node_features, edge_features, hidden_features, out_features, processing_steps=12,
+                 type="regression", **kwargs):
+        super().__init__()
+        self.input = nn.Linear(node_features, hidden_features)
+        self.ee = EdgeEncoderMLP(edge_features, hidden_features)
+        self.mpnn = MPNN_enn_edge(edge_features, hidden_features)
+        self.s2s = Set2Set(hidden_features, processing_steps, num_layers=1)
+        self.output = nn.Linear(hidden_features, out_features)
+        self.type = type
+
+    def forward(self, node_features, edge_features, Esrc, Etgt, batch):
+        x = self.mpnn(self.input(node_features), Esrc, Etgt, self.ee(edge_features))
+        return self._out(self.output(self.s2s(x, batch)[:, :x.size(1)]))
+
+
+class _EdgeGCN3(_Fixed):
+    def _init3(self, node_features, edge_features, hidden_features, out_features, dropout, type):
+        self.gc1 = EdgeGraphConvolution(node_features, hidden_features)
+        self.gc2 = EdgeGraphConvolution(hidden_features, hidden_features)
+        self.gc3 = EdgeGraphConvolution(hidden_features, out_features)
+        self.dropout = dropout
+        self.ee1 = EdgeEncoderMLP(edge_features, hidden_features)
+        self.ee2 = EdgeEncoderMLP(edge_features, hidden_features)
+        self.ee3 = EdgeEncoderMLP(edge_features, out_features)
+        self.type = type
+
+    def _convs(self, x, edge_features, Esrc, Etgt):
+        for gc, ee in ((self.gc1, self.ee1), (self.gc2, self.ee2)):
+            x = F.dropout(F.relu(gc(x, Esrc, Etgt, ee(edge_features))), self.dropout, training=self.training)
+        return self.gc3(x, Esrc, Etgt, self.ee3(edge_features))
+
+
+class EdgeGCN3_Sum(_EdgeGCN3):
+    """QC/models.py:69-103: three edge-conditioned convolutions, each with its own edge encoder, per-graph sum."""
+
+    def __init__(self, node_features, edge_features, hidden_features, out_features, dropout=0, type="regression"):
+        super().__init__()
+        self._init3(node_features, edge_features, hidden_features, out_features, dropout, type)
+
+    def forward(self, node_features, edge_features, Esrc, Etgt, batch):
+        return self._out(segment_sum(self._convs(node_features, edge_features, Esrc, Etgt), batch))
+
+
+class EdgeGCN3_Set2Set(_EdgeGCN3):
+    """QC/models.py:106-143."""
+
+    def __init__(self, node_features, edge_features, hidden_features, out_features, dropout=0, processing_steps=8,
+                 type="regression"):
+        super().__init__()
+        self._init3(node_features, edge_features, hidden_features, out_features, dropout, type)
+        self.s2s = Set2Set(out_features, processing_steps, num_layers=1)
+
+    def forward(self, node_features, edge_features, Esrc, Etgt, batch):
+        x = self._convs(node_features, edge_features, Esrc, Etgt)
+        return self._out(self.s2s(x, batch)[:, :x.size(1)])
+
+
+def scatter_add(src, index, dim=-1, out=None, dim_size=None, fill_value=0):
+    """The one way the reference calls QC/torch_scatter.py:170 on this path: rows of a 2-D tensor summed per graph
+    (dim = 0, no `out`, zero fill)."""
+    if dim not in (0, -2) or out is not None or fill_value != 0 or src.dim() != 2:
+        raise NotImplementedError("scatter_add: only scatter_add(x[N, d], batch[N], dim=0, dim_size=B) is on the hot path")
+    return segment_sum(src, index, dim_size)

@@ -307,6 +307,29 @@ def qc_models_golden():
         for k, p in m.named_parameters():
             if p.grad is not None and p.numel() <= 600:          # small ones only: biases, norms, output layers
                 res[name + "__g__" + k.replace(".", "__")] = p.grad
+    # the fixed-depth classes of QC/models.py (train_egcn_multitask.py); EdgeGCN3_* read self.type without setting it
+    sys.modules.pop("models", None)
+    sys.path.insert(0, os.path.join(REF, "QC"))
+    try:
+        qm = importlib.import_module("models")
+    finally:
+        sys.path.pop(0)
+    for name, kw in (("MPNN_ENN_Sum", {}), ("MPNN_ENN_Set2Set", dict(processing_steps=3)), ("EdgeGCN3_Sum", {}),
+                     ("EdgeGCN3_Set2Set", dict(processing_steps=3))):
+        m = getattr(qm, name)(13, 5, 16, 12, **kw)
+        if not hasattr(m, "type"):
+            m.type = "regression"
+        m.eval()
+        out = m(x, ef, Esrc, Etgt, batch)
+        gout = torch.randn_like(out)
+        out.backward(gout)
+        res[name + "__out"] = out
+        res[name + "__gout"] = gout
+        for k, p in m.state_dict().items():
+            res[name + "__sd__" + k.replace(".", "__")] = p
+        for k, p in m.named_parameters():
+            if p.grad is not None and p.numel() <= 600:
+                res[name + "__g__" + k.replace(".", "__")] = p.grad
     save("qc_models.npz", **res)
 
 

@@ -109,3 +109,30 @@ def test_every_variant_exports_the_reference_zoo(shim_path, variant, first_keys)
         assert all(hasattr(layers, n) for n in ("MyLinear", "NonLinear", "MLP"))
     expected = ["x", "src", "tgt", "Mtgt"] if variant == "GAT" else ["x", "adj"]
     assert list(inspect.signature(m.forward).parameters) == expected
+
+
+def test_qc_shims_cover_the_reference_imports(shim_path):
+    """Every bare-name import of QC/train_egcn.py, train_egcn_multitask.py, layer_models.py and models.py resolves."""
+    shim_path("QC")
+    for k in ("layer_models", "set2set", "torch_scatter"):
+        sys.modules.pop(k, None)
+    lm = importlib.import_module("layer_models")
+    for name in ("EdgeGCN_K_Sum", "EdgeGCN_K_Set2Set", "MPNN_ENN_K_Sum", "MPNN_ENN_K_Set2Set", "EdgeRES1_K_Set2Set",
+                 "UnimplementedModel", "RESKnorm", "get_output_function"):      # QC/train_egcn.py:85-94
+        assert hasattr(lm, name), name
+    with pytest.raises(NotImplementedError):
+        lm.UnimplementedModel()
+    layers = importlib.import_module("layers")
+    for name in ("MyLinear", "NonLinear", "MLP", "TransitionMLP", "EdgeEncoderMLP", "EdgeGraphConvolution",
+                 "GraphConvolution", "FixedGraphConvolution"):                  # classes of QC/layers.py in use
+        assert hasattr(layers, name), name
+    models = importlib.import_module("models")
+    for name in ("MPNN_ENN_Sum", "MPNN_ENN_Set2Set", "EdgeGCN3_Sum", "EdgeGCN3_Set2Set"):   # QC/models.py
+        assert hasattr(models, name), name
+    assert hasattr(importlib.import_module("mpnn"), "MPNN_enn_edge")
+    assert hasattr(importlib.import_module("set2set"), "Set2Set")
+    assert hasattr(importlib.import_module("torch_scatter"), "scatter_add")
+    for k in ("layer_models", "set2set", "torch_scatter"):
+        sys.modules.pop(k, None)
+    m = models.EdgeGCN3_Set2Set(13, 5, 8, 4, processing_steps=2)
+    assert "ee3.mlp.layers.0.linear.weight" in m.state_dict() or any(k.startswith("ee3.") for k in m.state_dict())

@@ -278,7 +278,8 @@ def test_gat_fused_field_matches_autograd_path(golden, method, opts):
 
 
 @pytest.mark.parametrize("name", ["MPNN_ENN_K_Sum", "MPNN_ENN_K_Set2Set", "EdgeGCN_K_Sum", "EdgeGCN_K_Set2Set",
-                                  "EdgeRES1_K_Set2Set"])
+                                  "EdgeRES1_K_Set2Set", "MPNN_ENN_Sum", "MPNN_ENN_Set2Set", "EdgeGCN3_Sum",
+                                  "EdgeGCN3_Set2Set"])
 def test_qc_model_zoo_vs_reference_golden(golden, name):
     """QC/layer_models.py classes: same state_dict keys (checkpoint-compatible), outputs and the captured
     gradients of the reference classes on a synthetic 4-molecule batch."""
@@ -291,8 +292,12 @@ def test_qc_model_zoo_vs_reference_golden(golden, name):
     Etgt = torch.zeros(n, e)
     Etgt[etgt, torch.arange(e)] = 1.0
     Etgt = Etgt.to(dev())
-    m = getattr(qc_models, name)(node_features=13, edge_features=5, target_features=12, hidden_features=16,
-                                 num_layers=3, s2s_processing_steps=3, dropout=0.0).to(dev())
+    if "_K_" in name:        # QC/layer_models.py
+        m = getattr(qc_models, name)(node_features=13, edge_features=5, target_features=12, hidden_features=16,
+                                     num_layers=3, s2s_processing_steps=3, dropout=0.0).to(dev())
+    else:                    # QC/models.py: (node_features, edge_features, hidden_features, out_features, ...)
+        kw = dict(processing_steps=3) if "Set2Set" in name else {}
+        m = getattr(qc_models, name)(13, 5, 16, 12, **kw).to(dev())
     pre = name + "__sd__"
     sd = {k[len(pre):].replace("__", "."): T(v) for k, v in g.items() if k.startswith(pre)}
     assert set(sd) == set(m.state_dict().keys())
