@@ -96,11 +96,13 @@ SIGNATURES = {
     "gode_edge_softmax_agg_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p,
                                             c_i64, c_p, c_p, c_p]),
     "gode_gat_logits_f32": (c_i, [ctypes.POINTER(GatProj), c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
-    "gode_gat_agg_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(GatProj), c_i64, c_p, c_p, c_p, c_f, c_i64,
+    "gode_gat_agg_f32_fwd": (c_i, [ctypes.POINTER(Graph), c_p, c_p, ctypes.POINTER(GatProj), c_i64, c_p, c_p, c_p, c_f,
                                    c_p, c_p, c_p, c_p]),
-    "gode_gat_agg_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.POINTER(GatProj), c_i64, c_p, c_p, c_p, c_p, c_p,
-                                   ctypes.POINTER(LinComb), c_f, c_i64, c_p, c_p, c_p]),
-    "gode_gat_maxpath_f32": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
+    "gode_gat_agg_f32_bwd": (c_i, [ctypes.POINTER(Graph), c_p, c_p, ctypes.POINTER(GatProj), c_i64, c_p, c_p, c_p, c_p,
+                                   c_p, ctypes.POINTER(LinComb), c_f, c_p, c_p, c_p, c_i64, c_p, c_i64,
+                                   ctypes.POINTER(ctypes.c_int32), c_p]),
+    "gode_gat_maxpath_scratch_bytes": (c_i64, [c_i64]),
+    "gode_gat_maxpath_f32": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_p]),
     "gode_gat_scatter_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64,
                                    c_p]),
     "gode_time_row_fixup_f32": (c_i, [c_p, c_p, c_i64, c_f, c_p, c_i, c_p]),

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_kernel(const int* __restrict_
     for (int q = 0; q < MAXC; ++q) { acc[q] = 0.f; const int c = lane + q * G; bias[q] = (bf && c < o) ? bf[c] : 0.f; }
     float s = 0.f;
     for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
-        const int e = eid[k];
+        const int e = eid ? eid[k] : k;
         const float w = expf(a[e] - m);
         const float we = (val ? val[k] : 1.f) * w;
         if (lane == 0) w_out[e] = w;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_kernel(const int* __restrict_
     for (int off = G >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
     const float dsum = -dot / dn;
     for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
-        const int e = eid[k];
+        const int e = eid ? eid[k] : k;
         const float we = w[e];
         const float vv = val ? val[k] : 1.f;
         const float* ps = pv.ps + (int64_t)src[e] * pv.lds;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_wave_kernel(const int* __rest
     float s = 0.f;
     const int end = rowptr[v + 1];
     for (int k = rowptr[v] + sg; k < end; k += ns) {
-        const int e = eid[k];
+        const int e = eid ? eid[k] : k;
         const float w = expf(a[e] - m);
         const float we = (val ? val[k] : 1.f) * w;
         if (lane == 0) w_out[e] = w;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_wave_kernel(const int* __rest
     const float dsum = -dot / dn;
     const int end = rowptr[v + 1];
     for (int k = rowptr[v] + sg; k < end; k += ns) {
-        const int e = eid[k];
+        const int e = eid ? eid[k] : k;
         const float we = w[e];
         const float vv = val ? val[k] : 1.f;
         const float* ps = pv.ps + (int64_t)src[e] * pv.lds;
@@ -265,6 +265,259 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_wave_kernel(const int* __rest
         }
         for (int off = G >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
         if (lane == 0) da[e] = vv * (part + dsum) * we;
+    }
+}
+
+// ---- large-graph variants: nnz-balanced records, as in the SpMM (csrc/spmm.hip) ---------------------------------
+// Edges are in target-sorted order (the caller passes eid == NULL: edge k IS position k of the CSR), so every
+// per-edge array (a, w, dz, da, src) is read and written as a stream and the only gather is Ps[src_k]: one
+// coalesced o*4-byte row per edge with 16 B per lane.  A group of LPR = o/4 lanes owns one record {row, begin, end,
+// slot}; rows longer than the graph's split length are cut into records that write raw partial sums into the slab
+// (row stride o+4: o numerator columns + the denominator) and are finished in slot order by a second small kernel.
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_agg_fwd_rec_kernel(const int4* __restrict__ items, int n_items,
+                                                              const int* __restrict__ src, const float* __restrict__ val,
+                                                              Proj pv, const float* __restrict__ bf,
+                                                              const float* __restrict__ a, const float* __restrict__ amax,
+                                                              float eps, float* __restrict__ out, float* __restrict__ w_out,
+                                                              float* __restrict__ den_out, float* __restrict__ partial) {
+    constexpr int U = 4, O = LPR * 4;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (int)(tid / LPR);
+    const int lane = threadIdx.x & (LPR - 1);
+    const bool active = gid < n_items;
+    int row = 0, b = 0, e = 0, slot = -1;
+    if (active) { const int4 it = items[gid]; row = it.x; b = it.y; e = it.z; slot = it.w; }
+    const int len = e - b;
+    const float m = amax[0];
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        c = *reinterpret_cast<const float4*>(pv.pt + (int64_t)row * pv.ldt + lane * 4);
+        if (bf) { const float4 q = *reinterpret_cast<const float4*>(bf + lane * 4); c.x += q.x; c.y += q.y; c.z += q.z; c.w += q.w; }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f;
+    const float* Xl = pv.ps + lane * 4;
+    for (int base = 0; __any(base < len); base += LPR) {
+        int sc = 0; float we = 0.f;
+        if (base + lane < len) {
+            const int k = b + base + lane;
+            sc = src[k];
+            const float w = expf(a[k] - m);
+            w_out[k] = w;
+            we = (val ? val[k] : 1.f) * w;
+        }
+        const int cnt = len - base;
+        for (int k = 0; k < LPR; k += U) {
+            if (!__any(k < cnt)) break;
+            int cc[U]; float vv[U]; float4 xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cc[u] = __shfl(sc, k + u, LPR); vv[u] = __shfl(we, k + u, LPR); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k + u < cnt && k + u < LPR) xv[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)cc[u] * pv.lds);
+                else vv[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                s += vv[u];
+                acc.x = fmaf(vv[u], fmaxf(xv[u].x + c.x, 0.f), acc.x); acc.y = fmaf(vv[u], fmaxf(xv[u].y + c.y, 0.f), acc.y);
+                acc.z = fmaf(vv[u], fmaxf(xv[u].z + c.z, 0.f), acc.z); acc.w = fmaf(vv[u], fmaxf(xv[u].w + c.w, 0.f), acc.w);
+            }
+        }
+    }
+    if (!active) return;
+    if (slot < 0) {
+        const float den = s + eps;
+        if (lane == 0) den_out[row] = den;
+        *reinterpret_cast<float4*>(out + (int64_t)row * O + lane * 4) = make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den);
+    } else {
+        float* p = partial + (int64_t)slot * (O + 4);
+        *reinterpret_cast<float4*>(p + lane * 4) = acc;
+        if (lane == 0) *reinterpret_cast<float4*>(p + O) = make_float4(s, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_agg_fwd_finish_kernel(const int4* __restrict__ long_rows, int n_long,
+                                                                 const float* __restrict__ partial, float eps,
+                                                                 float* __restrict__ out, float* __restrict__ den_out) {
+    constexpr int O = LPR * 4;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (int)(tid / LPR);
+    const int lane = threadIdx.x & (LPR - 1);
+    if (gid >= n_long) return;
+    const int4 lr = long_rows[gid];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f;
+    for (int q = lr.y; q < lr.z; ++q) {
+        const float* p = partial + (int64_t)q * (O + 4);
+        const float4 v = *reinterpret_cast<const float4*>(p + lane * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        s += p[O];
+    }
+    const float den = s + eps;
+    if (lane == 0) den_out[lr.x] = den;
+    *reinterpret_cast<float4*>(out + (int64_t)lr.x * O + lane * 4) = make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den);
+}
+
+// Backward over records.  Besides dz[k,:] and da[k] it accumulates the target-side sums dpt[v,:] = sum_k dz[k,:]
+// and dat[v] = sum_k da[k] of its record (rows of edge cotangents are contiguous per target in this order), so the
+// caller needs incidence products only for the source side.
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_agg_bwd_rec_kernel(const int4* __restrict__ items, int n_items,
+                                                              const int* __restrict__ src, const float* __restrict__ val,
+                                                              Proj pv, const float* __restrict__ bf,
+                                                              const float* __restrict__ w, const float* __restrict__ den,
+                                                              const float* __restrict__ out, const float* __restrict__ dout,
+                                                              LinComb cot, float cot_scale,
+                                                              float* __restrict__ dz, float* __restrict__ da,
+                                                              float* __restrict__ dpt, int64_t ld_dpt, float* __restrict__ dat,
+                                                              int64_t ld_dat, float* __restrict__ partial) {
+    constexpr int U = 4, O = LPR * 4;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (int)(tid / LPR);
+    const int lane = threadIdx.x & (LPR - 1);
+    const bool active = gid < n_items;
+    int row = 0, b = 0, e = 0, slot = -1;
+    if (active) { const int4 it = items[gid]; row = it.x; b = it.y; e = it.z; slot = it.w; }
+    const int len = e - b;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f), dA = c;
+    float dsum = 0.f;
+    if (active) {
+        c = *reinterpret_cast<const float4*>(pv.pt + (int64_t)row * pv.ldt + lane * 4);
+        if (bf) { const float4 q = *reinterpret_cast<const float4*>(bf + lane * 4); c.x += q.x; c.y += q.y; c.z += q.z; c.w += q.w; }
+        const float dn = den[row];
+        const float4 ov = *reinterpret_cast<const float4*>(out + (int64_t)row * O + lane * 4);
+        float4 g;
+        if (cot.n > 0) {
+            g = lc_load4(cot, (int64_t)row * O + lane * 4);
+            g.x = ov.x > 0.f ? cot_scale * g.x : 0.f; g.y = ov.y > 0.f ? cot_scale * g.y : 0.f;
+            g.z = ov.z > 0.f ? cot_scale * g.z : 0.f; g.w = ov.w > 0.f ? cot_scale * g.w : 0.f;
+        } else {
+            g = *reinterpret_cast<const float4*>(dout + (int64_t)row * O + lane * 4);
+        }
+        float dot = (g.x * ov.x + g.y * ov.y) + (g.z * ov.z + g.w * ov.w);
+        for (int off = LPR >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, LPR);
+        dA = make_float4(g.x / dn, g.y / dn, g.z / dn, g.w / dn);
+        dsum = -dot / dn;
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sda = 0.f;
+    const float* Xl = pv.ps + lane * 4;
+    for (int base = 0; __any(base < len); base += LPR) {
+        int sc = 0; float we = 0.f, vk = 0.f;
+        if (base + lane < len) {
+            const int k = b + base + lane;
+            sc = src[k];
+            vk = val ? val[k] : 1.f;
+            we = w[k];
+        }
+        const int cnt = len - base;
+        float da_lane = 0.f;                       // da of edge base + lane, filled below
+        for (int k = 0; k < LPR; k += U) {
+            if (!__any(k < cnt)) break;
+            int cc[U]; float ww[U], vv[U]; float4 xv[U]; float part[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cc[u] = __shfl(sc, k + u, LPR); ww[u] = __shfl(we, k + u, LPR); vv[u] = __shfl(vk, k + u, LPR); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k + u < cnt && k + u < LPR) xv[u] = *reinterpret_cast<const float4*>(Xl + (int64_t)cc[u] * pv.lds);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = k + u < cnt && k + u < LPR;
+                const float4 z = make_float4(xv[u].x + c.x, xv[u].y + c.y, xv[u].z + c.z, xv[u].w + c.w);
+                part[u] = (dA.x * fmaxf(z.x, 0.f) + dA.y * fmaxf(z.y, 0.f)) + (dA.z * fmaxf(z.z, 0.f) + dA.w * fmaxf(z.w, 0.f));
+                const float f = vv[u] * ww[u];
+                const float4 t = make_float4(z.x > 0.f ? f * dA.x : 0.f, z.y > 0.f ? f * dA.y : 0.f,
+                                             z.z > 0.f ? f * dA.z : 0.f, z.w > 0.f ? f * dA.w : 0.f);
+                if (live) {
+                    *reinterpret_cast<float4*>(dz + (int64_t)(b + base + k + u) * O + lane * 4) = t;
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                }
+            }
+            for (int off = LPR >> 1; off > 0; off >>= 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) part[u] += __shfl_xor(part[u], off, LPR);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (lane == k + u) da_lane = vv[u] * (part[u] + dsum) * ww[u];
+        }
+        if (base + lane < len) { da[b + base + lane] = da_lane; sda += da_lane; }
+    }
+    for (int off = LPR >> 1; off > 0; off >>= 1) sda += __shfl_xor(sda, off, LPR);
+    if (!active) return;
+    if (slot < 0) {
+        *reinterpret_cast<float4*>(dpt + (int64_t)row * ld_dpt + lane * 4) = acc;
+        if (lane == 0) dat[(int64_t)row * ld_dat] = sda;
+    } else {
+        float* p = partial + (int64_t)slot * (O + 4);
+        *reinterpret_cast<float4*>(p + lane * 4) = acc;
+        if (lane == 0) *reinterpret_cast<float4*>(p + O) = make_float4(sda, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_agg_bwd_finish_kernel(const int4* __restrict__ long_rows, int n_long,
+                                                                 const float* __restrict__ partial,
+                                                                 float* __restrict__ dpt, int64_t ld_dpt,
+                                                                 float* __restrict__ dat, int64_t ld_dat) {
+    constexpr int O = LPR * 4;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = (int)(tid / LPR);
+    const int lane = threadIdx.x & (LPR - 1);
+    if (gid >= n_long) return;
+    const int4 lr = long_rows[gid];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f;
+    for (int q = lr.y; q < lr.z; ++q) {
+        const float* p = partial + (int64_t)q * (O + 4);
+        const float4 v = *reinterpret_cast<const float4*>(p + lane * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        s += p[O];
+    }
+    *reinterpret_cast<float4*>(dpt + (int64_t)lr.x * ld_dpt + lane * 4) = acc;
+    if (lane == 0) dat[(int64_t)lr.x * ld_dat] = s;
+}
+
+// Two-stage max-path correction for large edge lists: block sums / first arg-max per block, then one block combines
+// them in block order and applies  da[e*] -= S  (and, when given, dat[tgt_row(e*)] -= S for sums already formed).
+__global__ __launch_bounds__(256) void gat_maxpath_part_kernel(const float* __restrict__ a, const float* __restrict__ amax,
+                                                               const float* __restrict__ da, int n_edges,
+                                                               float* __restrict__ psum, int* __restrict__ pidx) {
+    __shared__ float ssum[4];
+    __shared__ int sidx[4];
+    const float m = amax[0];
+    float s = 0.f;
+    int first = INT32_MAX;
+    const int per = (n_edges + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n_edges, lo + per);
+    for (int e = lo + threadIdx.x; e < hi; e += 256) {
+        s += da[e];
+        if (a[e] == m && e < first) first = e;
+    }
+    s = wave_sum(s);
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off, 64));
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; sidx[threadIdx.x >> 6] = first; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        psum[blockIdx.x] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        pidx[blockIdx.x] = min(min(sidx[0], sidx[1]), min(sidx[2], sidx[3]));
+    }
+}
+__global__ void gat_maxpath_final_kernel(const float* __restrict__ psum, const int* __restrict__ pidx, int n_part,
+                                         float* __restrict__ da, int n_edges, const int* __restrict__ tgt,
+                                         float* __restrict__ dat, int64_t ld_dat) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float t = 0.f; int f = INT32_MAX;
+    for (int j = 0; j < n_part; ++j) { t += psum[j]; f = min(f, pidx[j]); }
+    if (f < n_edges) {
+        da[f] -= t;
+        if (dat && tgt) dat[(int64_t)tgt[f] * ld_dat] -= t;
     }
 }
 
@@ -388,7 +641,7 @@ __global__ __launch_bounds__(256) void edge_matvec_fwd_kernel(const int* __restr
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < h; i += 256) macc[i] = 0.f;
     for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
-        const int e = eid[k];
+        const int e = eid ? eid[k] : k;
         const float vv = val ? val[k] : 1.f;
         __syncthreads();
         for (int j = threadIdx.x; j < h; j += 256) xs[j] = X[(int64_t)src[e] * ldx + j];
@@ -563,44 +816,121 @@ extern "C" int gode_gat_logits_f32(const gode_gat_proj_t* proj, const float* bw,
     return launch_logits(pv, bw, src, tgt, n_edges, a, amax, scratch, (hipStream_t)stream);
 }
 
-extern "C" int gode_gat_agg_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
-                                    const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj, int64_t o,
-                                    const float* bf, const float* a, const float* amax, float eps, int64_t n_rows,
-                                    float* out, float* w_out, float* den_out, void* stream) {
+namespace {
+bool rec_ok(const gode_graph_t* mt, const Proj& pv, int64_t o, const void* p0, const void* p1) {
+    if (!mt->items || mt->col || mt->n_rows <= kWaveRows) return false;      // records + target-sorted edges only
+    if (o % 4 || o < 16 || o > 256 || (o & (o - 1))) return false;
+    if (mt->n_long > 0 && !mt->partial) return false;
+    if ((pv.lds % 4) || (pv.ldt % 4)) return false;
+    const uintptr_t al = (uintptr_t)pv.ps | (uintptr_t)pv.pt | (uintptr_t)p0 | (uintptr_t)p1;
+    return !(al & 15);
+}
+}  // namespace
+
+extern "C" int gode_gat_agg_f32_fwd(const gode_graph_t* mt, const int32_t* src, const int32_t* tgt,
+                                    const gode_gat_proj_t* proj, int64_t o, const float* bf, const float* a,
+                                    const float* amax, float eps, float* out, float* w_out, float* den_out, void* stream) {
+    if (!mt) return GODE_E_NULLPTR;
+    const int64_t n_rows = mt->n_rows;
     if (n_rows < 0 || o <= 0) return GODE_E_SHAPE;
     if (n_rows == 0) return 0;
-    if (!proj || !rowptr || !eid || !src || !tgt || !a || !amax || !out || !w_out || !den_out) return GODE_E_NULLPTR;
+    if (!proj || !mt->rowptr || !src || !tgt || !a || !amax || !out || !w_out || !den_out) return GODE_E_NULLPTR;
     if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
     const Proj pv = proj_of(proj);
     int rc = check_proj(pv, o); if (rc) return rc;
-    return launch_agg_fwd(rowptr, eid, val, src, tgt, pv, o, bf, a, amax, eps, n_rows, out, w_out, den_out,
-                          (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    if (rec_ok(mt, pv, o, out, bf ? (const void*)bf : (const void*)out)) {
+        const int lpr = (int)(o / 4);
+        const int64_t blocks = (mt->n_items * lpr + 255) / 256;
+        const int64_t fblocks = (mt->n_long * lpr + 255) / 256;
+#define GODE_REC(L)                                                                                                   \
+        do {                                                                                                          \
+            hipLaunchKernelGGL(gat_agg_fwd_rec_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, (const int4*)mt->items, \
+                               (int)mt->n_items, src, mt->val, pv, bf, a, amax, eps, out, w_out, den_out, mt->partial); \
+            if (mt->n_long > 0)                                                                                       \
+                hipLaunchKernelGGL(gat_agg_fwd_finish_kernel<L>, dim3((unsigned)fblocks), dim3(256), 0, s,            \
+                                   (const int4*)mt->long_rows, (int)mt->n_long, (const float*)mt->partial, eps, out, den_out); \
+        } while (0)
+        switch (lpr) { case 4: GODE_REC(4); break; case 8: GODE_REC(8); break; case 16: GODE_REC(16); break;
+                       case 32: GODE_REC(32); break; default: GODE_REC(64); break; }
+#undef GODE_REC
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
+    return launch_agg_fwd(mt->rowptr, mt->col, mt->val, src, tgt, pv, o, bf, a, amax, eps, n_rows, out, w_out, den_out, s);
 }
 
-extern "C" int gode_gat_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, const float* val,
-                                    const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj, int64_t o,
-                                    const float* bf, const float* w, const float* den, const float* out,
-                                    const float* dout, const gode_lincomb_t* cot, float cot_scale, int64_t n_rows,
-                                    float* dz, float* da, void* stream) {
+extern "C" int gode_gat_agg_f32_bwd(const gode_graph_t* mt, const int32_t* src, const int32_t* tgt,
+                                    const gode_gat_proj_t* proj, int64_t o, const float* bf, const float* w,
+                                    const float* den, const float* out, const float* dout, const gode_lincomb_t* cot,
+                                    float cot_scale, float* dz, float* da, float* dpt, int64_t ld_dpt, float* dat,
+                                    int64_t ld_dat, int32_t* did_target_sums, void* stream) {
+    if (!mt) return GODE_E_NULLPTR;
+    const int64_t n_rows = mt->n_rows;
+    if (did_target_sums) *did_target_sums = 0;
     if (n_rows < 0 || o <= 0) return GODE_E_SHAPE;
     if (n_rows == 0) return 0;
-    if (!proj || !rowptr || !eid || !src || !tgt || !w || !den || !out || !dz || !da) return GODE_E_NULLPTR;
+    if (!proj || !mt->rowptr || !src || !tgt || !w || !den || !out || !dz || !da) return GODE_E_NULLPTR;
     if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
     const bool use_cot = cot && cot->n > 0;
     if (use_cot) { int rc = check_lincomb(cot, true); if (rc) return rc; }
     else if (!dout) return GODE_E_NULLPTR;
     const Proj pv = proj_of(proj);
     int rc = check_proj(pv, o); if (rc) return rc;
-    return launch_agg_bwd(rowptr, eid, val, src, tgt, pv, o, bf, w, den, out, dout, make_lincomb(use_cot ? cot : nullptr),
-                          cot_scale, n_rows, dz, da, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    const LinComb lc = make_lincomb(use_cot ? cot : nullptr);
+    if (dpt && dat && did_target_sums && ld_dpt >= o && !(ld_dpt % 4) && ld_dat >= 1 && !(((uintptr_t)dpt | (uintptr_t)dz) & 15) &&
+        (!use_cot || lincomb_aligned16(cot)) && rec_ok(mt, pv, o, out, use_cot ? (const void*)out : (const void*)dout)) {
+        const int lpr = (int)(o / 4);
+        const int64_t blocks = (mt->n_items * lpr + 255) / 256;
+        const int64_t fblocks = (mt->n_long * lpr + 255) / 256;
+#define GODE_REC(L)                                                                                                   \
+        do {                                                                                                          \
+            hipLaunchKernelGGL(gat_agg_bwd_rec_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, (const int4*)mt->items, \
+                               (int)mt->n_items, src, mt->val, pv, bf, w, den, out, dout, lc, cot_scale, dz, da, dpt,  \
+                               ld_dpt, dat, ld_dat, mt->partial);                                                     \
+            if (mt->n_long > 0)                                                                                       \
+                hipLaunchKernelGGL(gat_agg_bwd_finish_kernel<L>, dim3((unsigned)fblocks), dim3(256), 0, s,            \
+                                   (const int4*)mt->long_rows, (int)mt->n_long, (const float*)mt->partial, dpt, ld_dpt, \
+                                   dat, ld_dat);                                                                      \
+        } while (0)
+        switch (lpr) { case 4: GODE_REC(4); break; case 8: GODE_REC(8); break; case 16: GODE_REC(16); break;
+                       case 32: GODE_REC(32); break; default: GODE_REC(64); break; }
+#undef GODE_REC
+        GODE_LAUNCH_CHECK();
+        *did_target_sums = 1;
+        return 0;
+    }
+    return launch_agg_bwd(mt->rowptr, mt->col, mt->val, src, tgt, pv, o, bf, w, den, out, dout, lc, cot_scale, n_rows,
+                          dz, da, s);
 }
 
-extern "C" int gode_gat_maxpath_f32(const float* a, const float* amax, float* da, int64_t n_edges, void* stream) {
+extern "C" int64_t gode_gat_maxpath_scratch_bytes(int64_t n_edges) {
+    (void)n_edges;
+    return 1024 * (int64_t)(sizeof(float) + sizeof(int));
+}
+
+extern "C" int gode_gat_maxpath_f32(const float* a, const float* amax, float* da, int64_t n_edges,
+                                    const int32_t* tgt, float* dat, int64_t ld_dat, void* scratch, void* stream) {
     if (n_edges < 0) return GODE_E_SHAPE;
     if (n_edges == 0) return 0;
     if (!a || !amax || !da) return GODE_E_NULLPTR;
     if (n_edges > INT32_MAX) return GODE_E_RANGE;
-    hipLaunchKernelGGL(gat_maxpath_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, amax, da, (int)n_edges);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_edges <= kOneBlockEdges && !dat) {
+        hipLaunchKernelGGL(gat_maxpath_kernel, dim3(1), dim3(1024), 0, s, a, amax, da, (int)n_edges);
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!scratch) return GODE_E_NULLPTR;
+    int64_t nb = (n_edges + 4095) / 4096; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+    float* psum = (float*)scratch;
+    int* pidx = (int*)(psum + 1024);
+    hipLaunchKernelGGL(gat_maxpath_part_kernel, dim3((unsigned)nb), dim3(256), 0, s, a, amax, (const float*)da, (int)n_edges,
+                       psum, pidx);
+    GODE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_maxpath_final_kernel, dim3(1), dim3(64), 0, s, (const float*)psum, (const int*)pidx, (int)nb, da,
+                       (int)n_edges, tgt, dat, ld_dat);
     GODE_LAUNCH_CHECK();
     return 0;
 }

@@ -8,8 +8,9 @@
 The reference gathers h = [x[src] | x[tgt]] (E x 2i) and applies f and w per edge.  Here f and w are
 applied per NODE (one dense GEMM on N rows, `x @ [Wf_src | Wf_tgt | ww_src | ww_tgt]`), and the
 per-edge work (logit, global-max shift, exp, per-target normalised sum of relu messages) runs in the
-HIP kernels of csrc/edge.hip; the scatter back to the nodes in the backward pass is two SpMM
-launches over the source / target incidence matrices.
+HIP kernels of csrc/edge.hip (a wave per target on citation-graph sizes, nnz-balanced records above 65 536
+targets); the backward pass returns the edge cotangents to the nodes with one fused launch (small graphs) or inside
+the record kernel plus source-side SpMMs (large graphs).
 """
 import torch
 import torch.nn as nn
@@ -17,27 +18,51 @@ import torch.nn.functional as F
 from torch.nn.modules.module import Module
 
 from . import ops
-from .graph import as_graph, incidence_from_index
+from .graph import CSRGraph, as_graph, incidence_from_index
 
 _edge_cache = {}
 
 
 class EdgeGraph:
-    """(src, tgt, Mtgt) normalised once: int32 indices, CSR of Mtgt, incidence CSR by src and by tgt."""
+    """(src, tgt, Mtgt) normalised once.  The edges are re-ordered by target (a stable sort, so the edges of one
+    target keep their relative order - the order torch.spmm sums a coalesced Mtgt): edge k is then position k of the
+    CSR of Mtgt, every per-edge array of the kernels is a stream, and `Mt` carries the balanced record list of the
+    SpMM.  An Mtgt whose rows disagree with `tgt` (never produced by the reference's loaders) keeps the given order
+    and the edge-id indirection instead (`canonical` False)."""
 
     def __init__(self, src, tgt, Mtgt):
         self.n = Mtgt.shape[0] if torch.is_tensor(Mtgt) else Mtgt.n_rows
         self.E = src.numel()
-        self.src = src.to(torch.int32).contiguous()
-        self.tgt = tgt.to(torch.int32).contiguous()
-        self.Mt = as_graph(Mtgt)
-        if self.Mt.n_cols != self.E:
+        mt = as_graph(Mtgt)
+        if mt.n_cols != self.E:
             raise ValueError("Mtgt must be N x E with E = len(src)")
-        cols = self.Mt.col.to(torch.int64)
+        cols = mt.col.to(torch.int64)
         if cols.numel() and torch.bincount(cols, minlength=self.E).max().item() > 1:
             raise NotImplementedError("Mtgt with more than one entry per edge column is not supported")
-        self.Ms_inc = incidence_from_index(self.src, self.n)     # N x E, row = src[e]
-        self.Mt_inc = incidence_from_index(self.tgt, self.n)     # N x E, row = tgt[e]
+        rp = mt.rowptr.to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(self.n, device=rp.device), rp[1:] - rp[:-1])
+        src64, tgt64 = src.to(torch.int64), tgt.to(torch.int64)
+        self.canonical = bool(mt.nnz == self.E and (self.E == 0 or bool((tgt64[cols] == rows).all().item())))
+        if self.canonical:
+            self.perm = cols                                              # edge id at CSR position k
+            self.src = src64[cols].to(torch.int32).contiguous()
+            self.tgt = rows.to(torch.int32).contiguous()
+            self.Mt = CSRGraph(mt.rowptr, torch.arange(self.E, device=rp.device), mt.val, self.n, self.E)
+        else:
+            self.perm = None
+            self.src = src.to(torch.int32).contiguous()
+            self.tgt = tgt.to(torch.int32).contiguous()
+            self.Mt = mt
+        self.Ms_inc = incidence_from_index(self.src, self.n)     # N x E, row = src of the (re-ordered) edge
+        self.Mt_inc = incidence_from_index(self.tgt, self.n)     # N x E, row = tgt
+        self._scratch = None
+
+    def maxpath_scratch(self):
+        if self._scratch is None:
+            from . import _lib
+            nb = _lib.load().gode_gat_maxpath_scratch_bytes(self.E)
+            self._scratch = torch.empty(nb, dtype=torch.uint8, device=self.src.device)
+        return self._scratch
 
 
 def edge_graph(src, tgt, Mtgt):
@@ -53,36 +78,37 @@ def edge_graph(src, tgt, Mtgt):
 
 
 class _EdgeAttentionFn(torch.autograd.Function):
-    """out = per-target softmax-weighted sum of relu messages, from node-level projections P (N x (2o+2))."""
+    """out = per-target softmax-weighted sum of relu messages, from the node-level projections
+    Ps, Pt (N x o: message parts by source / by target) and A2 (N x 2: logit parts)."""
 
     @staticmethod
-    def forward(ctx, eg, P, bf, bw, o, eps):
-        P = P.contiguous()
-        a, amax = ops.edge_softmax_logits(P, o, bw, eg.src, eg.tgt)
-        out, w, den = ops.edge_softmax_agg_fwd(eg.Mt, eg.src, eg.tgt, P, o, bf, a, amax, eps)
-        ctx.eg, ctx.o = eg, o
-        ctx.save_for_backward(P, bf, a, amax, w, den, out)
+    def forward(ctx, eg, Ps, Pt, A2, bf, bw, eps):
+        Ps, Pt, A2 = Ps.contiguous(), Pt.contiguous(), A2.contiguous()
+        n, o = Ps.shape
+        f = dict(dtype=torch.float32, device=Ps.device)
+        a, amax = torch.empty(eg.E, **f), torch.empty(1, **f)
+        out, w, den = torch.empty(n, o, **f), torch.empty(eg.E, **f), torch.empty(n, **f)
+        proj = ops.gat_proj(Ps, Pt, A2)
+        ops.gat_logits(proj, bw, eg.src, eg.tgt, a, amax)
+        ops.gat_agg_fwd(eg, proj, o, bf, a, amax, eps, out, w, den)
+        ctx.eg = eg
+        ctx.save_for_backward(Ps, Pt, A2, bf, a, amax, w, den, out)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        P, bf, a, amax, w, den, out = ctx.saved_tensors
-        eg, o = ctx.eg, ctx.o
-        dz, da = ops.edge_softmax_agg_bwd(eg.Mt, eg.src, eg.tgt, P, o, bf, w, den, out, dout.contiguous())
-        # path through the global max (GAT/layers.py:47): d amax = -sum_e da_e, routed to the arg-max edge
-        if eg.E > 0:
-            idx = torch.argmax(a)
-            da[idx] -= da.sum()
-        dP = torch.zeros_like(P)
-        dP[:, :o] = ops.spmm(eg.Ms_inc, dz)                     # sum over edges leaving each node
-        dP[:, o:2 * o] = ops.spmm(eg.Mt_inc, dz)                # sum over edges entering each node
-        da2 = da.view(-1, 1).contiguous()
-        dP[:, 2 * o] = ops.spmm(eg.Ms_inc, da2).view(-1)
-        dP[:, 2 * o + 1] = ops.spmm(eg.Mt_inc, da2).view(-1)
+        Ps, Pt, A2, bf, a, amax, w, den, out = ctx.saved_tensors
+        eg = ctx.eg
+        n, o = Ps.shape
+        f = dict(dtype=torch.float32, device=Ps.device)
+        dz, da = torch.empty(eg.E, o, **f), torch.empty(eg.E, **f)
+        dPs, dPt, dA2 = torch.empty(n, o, **f), torch.empty(n, o, **f), torch.empty(n, 2, **f)
+        proj = ops.gat_proj(Ps, Pt, A2)
+        ops.gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=dout.contiguous())
         dbf = torch.empty_like(bf)
         ops.colsum_(dbf, dz)
         dbw = da.sum().reshape(1)
-        return None, dP, dbf, dbw, None, None
+        return None, dPs, dPt, dA2, dbf, dbw, None
 
 
 def _gat_forward(layer, x, src, tgt, Mtgt):
@@ -91,11 +117,12 @@ def _gat_forward(layer, x, src, tgt, Mtgt):
     eg = edge_graph(src, tgt, Mtgt)
     i, o = layer.in_features, layer.out_features
     Wf, ww = layer.f.weight, layer.w.weight                      # (o, 2i), (1, 2i)
-    Wcat = torch.cat([Wf[:, :i].t(), Wf[:, i:].t(), ww[:, :i].t(), ww[:, i:].t()], 1)   # i x (2o+2)
-    P = torch.mm(x, Wcat)                                        # node-level projections (dense GEMM)
+    # node-level projections (dense GEMMs), split by role: message parts by source / target, logit parts
+    Ps, Pt = torch.mm(x, Wf[:, :i].t()), torch.mm(x, Wf[:, i:].t())
+    A2 = torch.mm(x, torch.stack([ww[0, :i], ww[0, i:]], 1))
     if eg.E == 0:                                                # no edges: every node is 0 / eps = 0
-        return torch.zeros(x.shape[0], o, dtype=x.dtype, device=x.device) + 0.0 * P.sum()
-    return _EdgeAttentionFn.apply(eg, P, layer.f.bias, layer.w.bias, o, layer.eps)
+        return torch.zeros(x.shape[0], o, dtype=x.dtype, device=x.device) + 0.0 * (Ps.sum() + Pt.sum() + A2.sum())
+    return _EdgeAttentionFn.apply(eg, Ps, Pt, A2, layer.f.bias, layer.w.bias, layer.eps)
 
 
 class GraphConvolution(Module):

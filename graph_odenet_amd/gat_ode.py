@@ -114,7 +114,7 @@ class GatOdeField(Field):
         s, w, eg = self.s, self.w, self.s.eg
         terms = self._project(t, y_terms)
         ops.gat_logits(w.proj, s.bw, eg.src, eg.tgt, w.a, w.amax)
-        ops.gat_agg_fwd(eg.Mt, eg.src, eg.tgt, w.proj, s.d, s.bf, w.a, w.amax, s.eps, out, w.wgt, w.den)
+        ops.gat_agg_fwd(eg, w.proj, s.d, s.bf, w.a, w.amax, s.eps, out, w.wgt, w.den)
         return terms                 # the outer relu of ODEfunc is the identity on a weighted mean of relu's
 
     def eval(self, t, terms, out):
@@ -151,11 +151,8 @@ class GatOdeAdjointField(GatOdeField):
         xt = self._forward(t, terms[0], out[0])
         g = s.views(out[3])
         # cotangent -a of the VJP, masked by the outer relu, is formed inside the kernel
-        ops.gat_agg_bwd(eg.Mt, eg.src, eg.tgt, w.proj, o, s.bf, w.wgt, w.den, out[0], w.dz, w.da,
-                        cot_terms=terms[1], cot_scale=-1.0)
-        if eg.E > 0:
-            ops.gat_maxpath_(w.a, w.amax, w.da)            # path through the global max (GAT/layers.py:47)
-        ops.gat_scatter(eg.Ms_inc, eg.Mt_inc, w.dz, w.da, w.dPs, w.dPt, w.dA2)
+        ops.gat_vjp(eg, w.proj, o, s.bf, w.a, w.amax, w.wgt, w.den, out[0], w.dz, w.da, w.dPs, w.dPt, w.dA2,
+                    cot_terms=terms[1], cot_scale=-1.0)
         ops.colsum_(g["bf"], w.dz)
         ops.colsum_(g["bw"], w.da.view(-1, 1))
         nb = w.np_b

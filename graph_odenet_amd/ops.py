@@ -307,34 +307,70 @@ def gat_logits(proj, bw, src, tgt, a, amax):
                                   stream_ptr()), "gode_gat_logits_f32")
 
 
-def gat_agg_fwd(Mt, src, tgt, proj, o, bf, a, amax, eps, out, w, den):
+def _edge_csr(eg, width):
+    """gode_graph_t of the CSR-by-target of an EdgeGraph (col = NULL when the edges are target-sorted)."""
+    mt = eg.Mt
+    gs = _lib.Graph()
+    gs.rowptr = mt.rowptr.data_ptr()
+    gs.col = None if eg.canonical else mt.col.data_ptr()
+    gs.val = mt.val.data_ptr() if mt.val is not None else None
+    gs.items, gs.n_items = mt.items.data_ptr(), mt.n_items
+    gs.long_rows = mt.long_rows.data_ptr() if mt.long_rows is not None else None
+    gs.n_long = mt.n_long
+    part = mt.partial(width)
+    gs.partial = part.data_ptr() if part is not None else None
+    gs.n_rows, gs.nnz = mt.n_rows, mt.nnz
+    return gs
+
+
+def gat_agg_fwd(eg, proj, o, bf, a, amax, eps, out, w, den):
     lib = _lib.load()
     _need(out, "out"); _need(w, "w"); _need(den, "den"); _need(bf, "bf")
-    check(lib.gode_gat_agg_f32_fwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ctypes.byref(proj), o,
-                                   ptr(bf), ptr(a), ptr(amax), float(eps), Mt.n_rows, ptr(out), ptr(w), ptr(den),
-                                   stream_ptr()), "gode_gat_agg_f32_fwd")
+    gs = _edge_csr(eg, o + 4)
+    check(lib.gode_gat_agg_f32_fwd(ctypes.byref(gs), ptr(eg.src), ptr(eg.tgt), ctypes.byref(proj), o, ptr(bf), ptr(a),
+                                   ptr(amax), float(eps), ptr(out), ptr(w), ptr(den), stream_ptr()), "gode_gat_agg_f32_fwd")
 
 
-def gat_agg_bwd(Mt, src, tgt, proj, o, bf, w, den, out, dz, da, dout=None, cot_terms=None, cot_scale=1.0):
-    """dz[E, o], da[E] from the cotangent `dout`, or from cot_scale * (sum cot_terms) masked by out > 0."""
+def gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=None, cot_terms=None, cot_scale=1.0):
+    """Vector-Jacobian product of the edge-attention aggregation w.r.t. the projections: fills dz[E, o], da[E] (with the
+    path through the global maximum folded in), dPs, dPt (N x o) and dA2 (N x 2).  The cotangent is `dout`, or
+    cot_scale * (sum cot_terms) masked by out > 0."""
     lib = _lib.load()
-    _need(out, "out"); _need(dz, "dz"); _need(da, "da"); _need(dout, "dout")
+    for t, nm in ((out, "out"), (dz, "dz"), (da, "da"), (dout, "dout"), (dPs, "dPs"), (dPt, "dPt"), (dA2, "dA2")):
+        _need(t, nm)
     lc = None
     if cot_terms is not None:
         if _need_terms(cot_terms, "cot") != out.numel():
-            raise ValueError("gat_agg_bwd: cotangent terms have wrong size")
+            raise ValueError("gat_vjp: cotangent terms have wrong size")
         lc = lincomb(cot_terms)
     elif dout is None:
-        raise ValueError("gat_agg_bwd: dout or cot_terms required")
-    check(lib.gode_gat_agg_f32_bwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ctypes.byref(proj), o,
-                                   ptr(bf), ptr(w), ptr(den), ptr(out), ptr(dout),
-                                   ctypes.byref(lc) if lc is not None else None, float(cot_scale), Mt.n_rows,
-                                   ptr(dz), ptr(da), stream_ptr()), "gode_gat_agg_f32_bwd")
+        raise ValueError("gat_vjp: dout or cot_terms required")
+    gs = _edge_csr(eg, o + 4)
+    did = ctypes.c_int32(0)
+    at_ptr = ctypes.c_void_p(dA2.data_ptr() + 4)
+    check(lib.gode_gat_agg_f32_bwd(ctypes.byref(gs), ptr(eg.src), ptr(eg.tgt), ctypes.byref(proj), o, ptr(bf), ptr(w),
+                                   ptr(den), ptr(out), ptr(dout), ctypes.byref(lc) if lc is not None else None,
+                                   float(cot_scale), ptr(dz), ptr(da), ptr(dPt), o, at_ptr, 2, ctypes.byref(did),
+                                   stream_ptr()), "gode_gat_agg_f32_bwd")
+    if eg.E > 0:                                                   # path through the global max (GAT/layers.py:47)
+        big = bool(did.value)
+        check(lib.gode_gat_maxpath_f32(ptr(a), ptr(amax), ptr(da), eg.E, ptr(eg.tgt) if big else None,
+                                       at_ptr if big else None, 2, ptr(eg.maxpath_scratch()), stream_ptr()),
+              "gode_gat_maxpath_f32")
+    if did.value:
+        # the record kernel already summed per target; the source side is two incidence products
+        spmm(eg.Ms_inc, dz, out=dPs)
+        spmm(eg.Ms_inc, da.view(-1, 1), out=dA2[:, 0:1])
+    else:
+        gat_scatter(eg.Ms_inc, eg.Mt_inc, dz, da, dPs, dPt, dA2)
 
 
 def gat_maxpath_(a, amax, da):
+    """da[first argmax(a)] -= da.sum()   (stand-alone form; gat_vjp applies it itself)."""
     lib = _lib.load()
-    check(lib.gode_gat_maxpath_f32(ptr(a), ptr(amax), ptr(da), a.numel(), stream_ptr()), "gode_gat_maxpath_f32")
+    sc = _scratch(a.device, lib.gode_gat_maxpath_scratch_bytes(a.numel()))
+    check(lib.gode_gat_maxpath_f32(ptr(a), ptr(amax), ptr(da), a.numel(), None, None, 0, ptr(sc), stream_ptr()),
+          "gode_gat_maxpath_f32")
 
 
 def gat_scatter(Ms_inc, Mt_inc, dz, da, dPs, dPt, dA2):

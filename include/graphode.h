@@ -200,6 +200,14 @@ int gode_edge_softmax_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, con
                                   const float* w, const float* den, const float* out, const float* dout,
                                   int64_t n_rows, float* dz, float* da, void* stream);
 
+/* A CSR matrix with its balanced record list, as the multi-launch entry points take it. */
+typedef struct gode_graph {
+    const int32_t* rowptr; const int32_t* col; const float* val;      /* CSR, val nullable */
+    const int32_t* items;  int64_t n_items;                             /* balanced records (nullable) */
+    const int32_t* long_rows; int64_t n_long; float* partial;           /* split rows + their slab */
+    int64_t n_rows; int64_t nnz;
+} gode_graph_t;
+
 /* The same three steps over separately stored node-level projections, and the fused pieces of the VJP of the
  * GAT ODE function (GAT/models.py:172-179 -> GAT/layers.py:95-122).  Splitting P lets the caller produce the two
  * d x d message blocks with the square MFMA kernel (gode_gn_time_gemm_f32, once per block) and the two logit
@@ -213,19 +221,30 @@ typedef struct gode_gat_proj {
 } gode_gat_proj_t;
 int gode_gat_logits_f32(const gode_gat_proj_t* proj, const float* bw, const int32_t* src, const int32_t* tgt,
                         int64_t n_edges, float* a, float* amax, float* scratch, void* stream);
-int gode_gat_agg_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
-                         const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj, int64_t o,
-                         const float* bf, const float* a, const float* amax, float eps, int64_t n_rows,
-                         float* out, float* w_out, float* den_out, void* stream);
+/* mt: CSR by target over the edges (col = edge ids of each target in increasing order, or NULL when the edge list is
+ * target-sorted so that edge k is CSR position k), val = Mtgt values (nullable), plus the balanced record list.
+ * Above 65 536 targets, with col == NULL and o in {16, 32, 64, 128, 256}, the aggregation runs over the records like
+ * the SpMM (streamed per-edge arrays, one coalesced o*4-byte gather per edge); mt->partial must then hold
+ * n_slots * (o + 4) floats.  Otherwise a lane group (a whole wave below 65 536 targets) works on one target. */
+int gode_gat_agg_f32_fwd(const gode_graph_t* mt, const int32_t* src, const int32_t* tgt,
+                         const gode_gat_proj_t* proj, int64_t o, const float* bf, const float* a, const float* amax,
+                         float eps, float* out, float* w_out, float* den_out, void* stream);
 /* cotangent: dout (n_rows x o), or - when cot (host, nullable) has terms - cot_scale * (sum_j cot_j) masked by out > 0,
- * i.e. the stage cotangent of the adjoint solve pushed through the relu that follows the layer. */
-int gode_gat_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, const float* val,
-                         const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj, int64_t o,
-                         const float* bf, const float* w, const float* den, const float* out,
-                         const float* dout, const gode_lincomb_t* cot, float cot_scale, int64_t n_rows,
-                         float* dz, float* da, void* stream);
-/* gradient path through the global maximum of the logits (GAT/layers.py:47): da[e*] -= sum(da), e* = first argmax */
-int gode_gat_maxpath_f32(const float* a, const float* amax, float* da, int64_t n_edges, void* stream);
+ * i.e. the stage cotangent of the adjoint solve pushed through the relu that follows the layer.
+ * dz[E x o], da[E] are always written.  dpt / dat / did_target_sums (all nullable): on the record path the kernel also
+ * forms dpt[v,:] = sum_{e: tgt_e = v} dz[e,:] and dat[v*ld_dat] = sum da[e] and sets *did_target_sums = 1 (host int);
+ * otherwise it leaves them untouched and sets 0 (use gode_gat_scatter_f32). */
+int gode_gat_agg_f32_bwd(const gode_graph_t* mt, const int32_t* src, const int32_t* tgt,
+                         const gode_gat_proj_t* proj, int64_t o, const float* bf, const float* w, const float* den,
+                         const float* out, const float* dout, const gode_lincomb_t* cot, float cot_scale,
+                         float* dz, float* da, float* dpt, int64_t ld_dpt, float* dat, int64_t ld_dat,
+                         int32_t* did_target_sums, void* stream);
+/* gradient path through the global maximum of the logits (GAT/layers.py:47): da[e*] -= S, S = sum(da), e* = first
+ * argmax; when dat (nullable, with tgt) holds target-side sums formed before the correction, dat[tgt[e*]*ld_dat] -= S.
+ * scratch: >= gode_gat_maxpath_scratch_bytes(n_edges) bytes (may be NULL for n_edges <= 32 768 without dat). */
+int64_t gode_gat_maxpath_scratch_bytes(int64_t n_edges);
+int gode_gat_maxpath_f32(const float* a, const float* amax, float* da, int64_t n_edges, const int32_t* tgt,
+                         float* dat, int64_t ld_dat, void* scratch, void* stream);
 /* dps[v,:] = sum_{e: src_e = v} dz[e,:], dpt[v,:] = sum_{e: tgt_e = v} dz[e,:], das / dat likewise from da; the
  * incidence lists are CSR (rowptr over nodes, eid = edge ids in increasing order). */
 int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* eid_src, const int32_t* rowptr_tgt,
@@ -271,12 +290,6 @@ int gode_segment_attention_f32_bwd(const int32_t* segptr, const int32_t* perm, c
  * floats and is updated in place.  With ws->S2 set, the adjoint runs its forward-recompute chain and its
  * VJP chain on two streams (one private side stream per process, joined back into `stream` before the
  * call returns; GODE_OVERLAP=0 disables it): one adjoint solve at a time per process. */
-typedef struct gode_graph {
-    const int32_t* rowptr; const int32_t* col; const float* val;      /* CSR, val nullable */
-    const int32_t* items;  int64_t n_items;                             /* balanced records (nullable) */
-    const int32_t* long_rows; int64_t n_long; float* partial;           /* split rows + their slab */
-    int64_t n_rows; int64_t nnz;
-} gode_graph_t;
 
 typedef struct gode_gcn_odefunc {
     gode_graph_t A, AT;                 /* adjacency and its transpose */

@@ -488,3 +488,41 @@ def test_gat_zoo_has_every_reference_class():
         assert hasattr(gat_models, name), name
     m = gat_models.ODEK2(nfeat=6, nhid=8, nclass=2, dropout=0.5, nlayers=5)
     assert type(m.gcs[1].odefunc) is gat_models.ODEfunc2 and type(m.gcs[2].odefunc) is gat_models.ODEfunc
+
+
+@pytest.mark.parametrize("o", [16, 128])
+def test_gat_layer_record_path_vs_oracle_large(o):
+    """Above 65 536 targets the attention kernels run over nnz-balanced records (csrc/edge.hip: gat_agg_*_rec_kernel)
+    on the target-sorted edge list.  70 000 nodes / 300 000 edges in random order, a 3 000-edge hub (split into
+    records with a partial slab), nodes without incoming edges; forward and all gradients against the oracle's
+    restatement of GAT/layers.py:31-58 evaluated in float64 on the CPU (in float32 torch's own CPU backward is 1e-2
+    off at the hub for o = 128, tools/dev/gat_layer_check.py)."""
+    from graph_odenet_amd.gat_layers import GraphConvolution, edge_graph
+    from oracle import layers_ref as R
+    gen = torch.Generator().manual_seed(o)
+    n, E, i = 70000, 300000, 8
+    src = torch.randint(0, n, (E,), generator=gen)
+    tgt = torch.randint(0, n - 100, (E,), generator=gen)
+    tgt[:3000] = 5
+    p = torch.randperm(E, generator=gen)
+    src, tgt = src[p], tgt[p]
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+    x = torch.randn(n, i, generator=gen)
+    gout = torch.randn(n, o, generator=gen)
+    torch.manual_seed(1)
+    lay = GraphConvolution(i, o)
+    ref_p = [q.detach().double().requires_grad_(True) for q in (lay.f.weight, lay.f.bias, lay.w.weight, lay.w.bias)]
+    xr = x.double().requires_grad_(True)
+    ref = R.gat_layer(xr, src, tgt, Mtgt.coalesce().double(), *ref_p)
+    ref.backward(gout.double())
+    lay = lay.to(dev())
+    xd = x.to(dev()).requires_grad_(True)
+    srcd, tgtd, Md = src.to(dev()), tgt.to(dev()), Mtgt.to(dev())
+    out = lay(xd, srcd, tgtd, Md)
+    eg = edge_graph(srcd, tgtd, Md)
+    assert eg.canonical and eg.Mt.n_long >= 1 and eg.n > 65536
+    close(out, ref, 2e-5, "out")
+    out.backward(gout.to(dev()))
+    close(xd.grad, xr.grad, 2e-5, "gx")
+    for q, r, nm in zip((lay.f.weight, lay.f.bias, lay.w.weight, lay.w.bias), ref_p, ("Wf", "bf", "ww", "bw")):
+        close(q.grad, r.grad, 1e-4 if nm == "bw" else 1e-5, "grad " + nm)      # bw: analytically 0, sum of 3e5 roundings

@@ -1,0 +1,33 @@
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from graph_odenet_amd.gat_layers import GraphConvolution, edge_graph
+from oracle import layers_ref as R
+dev = torch.device("cuda:0")
+for o in (16, 64, 128):
+    gen = torch.Generator().manual_seed(o)
+    n, E, i = 70000, 300000, 8
+    src = torch.randint(0, n, (E,), generator=gen); tgt = torch.randint(0, n - 100, (E,), generator=gen); tgt[:3000] = 5
+    p = torch.randperm(E, generator=gen); src, tgt = src[p], tgt[p]
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+    x = torch.randn(n, i, generator=gen); gout = torch.randn(n, o, generator=gen)
+    torch.manual_seed(1)
+    lay = GraphConvolution(i, o)
+    for dt in (torch.float32, torch.float64):
+        ref_p = [q.detach().clone().to(dt).requires_grad_(True) for q in (lay.f.weight, lay.f.bias, lay.w.weight, lay.w.bias)]
+        xr = x.clone().to(dt).requires_grad_(True)
+        ref = R.gat_layer(xr, src, tgt, Mtgt.coalesce().to(dt), *ref_p)
+        ref.backward(gout.to(dt))
+        if dt == torch.float32:
+            r32 = (ref.detach(), xr.grad, [q.grad for q in ref_p])
+        else:
+            r64 = (ref.detach(), xr.grad, [q.grad for q in ref_p])
+    l2 = GraphConvolution(i, o); l2.load_state_dict(lay.state_dict()); l2 = l2.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = l2(xd, src.to(dev), tgt.to(dev), Mtgt.to(dev))
+    out.backward(gout.to(dev))
+    e = lambda a, b: float((a.cpu().double() - b.double()).abs().max())
+    print("o=%d  out: gpu-vs-64 %.2e  cpu32-vs-64 %.2e | gx: %.2e  %.2e (scale %.2e)" % (o, e(out, r64[0]), e(r32[0], r64[0]),
+          e(xd.grad, r64[1]), e(r32[1], r64[1]), float(r64[1].abs().max())))
+    for q, a, b, nm in zip((l2.f.weight, l2.f.bias, l2.w.weight, l2.w.bias), r32[2], r64[2], ("Wf", "bf", "ww", "bw")):
+        print("    %s: gpu-vs-64 %.2e cpu32-vs-64 %.2e (scale %.2e)" % (nm, e(q.grad, b), e(a, b), float(b.abs().max())))

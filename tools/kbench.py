@@ -93,6 +93,45 @@ def main():
         _, dgp, dbp = ops.gn_time_gemm_bwd(t2, n, d, 32, 1e-5, gam, W, True, Y, out=OUT)
         o2 = torch.empty(d, device=dev)
         rec("reduce_parts dgamma (%d parts)" % dgp.shape[0], timeit(lambda: ops.reduce_parts_(o2, dgp)))
+    if want("gat"):
+        # GAT edge attention at the benchmark scale: the graph's nnz are the edges, o = d
+        from graph_odenet_amd.gat_layers import EdgeGraph
+        rp = g.rowptr.to(torch.int64)
+        tgt = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+        src = g.col.to(torch.int64)
+        E = src.numel()
+        perm = torch.randperm(E, device=dev)                       # an edge list in no particular order
+        src, tgt = src[perm], tgt[perm]
+        Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E, device=dev)]), torch.ones(E, device=dev), (n, E))
+        eg = EdgeGraph(src, tgt, Mtgt)
+        print("edge graph: canonical %s, records %d, split rows %d" % (eg.canonical, eg.Mt.n_items, eg.Mt.n_long))
+        Ps, Pt, A2 = torch.randn(n, d, device=dev), torch.randn(n, d, device=dev), torch.randn(n, 2, device=dev)
+        proj = ops.gat_proj(Ps, Pt, A2)
+        bw, bf = torch.zeros(1, device=dev), torch.randn(d, device=dev)
+        a, amax = torch.empty(E, device=dev), torch.empty(1, device=dev)
+        wgt, den, out = torch.empty(E, device=dev), torch.empty(n, device=dev), torch.empty(n, d, device=dev)
+        dz, da = torch.empty(E, d, device=dev), torch.empty(E, device=dev)
+        dPs, dPt, dA2 = torch.empty(n, d, device=dev), torch.empty(n, d, device=dev), torch.empty(n, 2, device=dev)
+        rec("gat logits + max", timeit(lambda: ops.gat_logits(proj, bw, eg.src, eg.tgt, a, amax)), E * 20 / 1e9)
+        b_fwd = (E * (4 + 4 * d + 4 + 4 + 4) + 3 * n * d * 4) / 1e9     # src, gathered Ps row, logit, val, weight out; Pt, out
+        rec("gat agg fwd", timeit(lambda: ops.gat_agg_fwd(eg, proj, d, bf, a, amax, 1e-6, out, wgt, den)), b_fwd)
+        b_vjp = (E * (4 + 4 * d + 4 + 4 + 4 * d + 4) + 4 * n * d * 4 + E * (4 + 4 * d) + n * d * 4) / 1e9
+        rec("gat vjp (agg bwd + max path + node sums)",
+            timeit(lambda: ops.gat_vjp(eg, proj, d, bf, a, amax, wgt, den, out, dz, da, dPs, dPt, dA2, dout=Y)), b_vjp)
+    if want("qc"):
+        # QC edge-conditioned messages: 2000 molecules' worth of edges (the reference batches 20), h = 73
+        from graph_odenet_amd.graph import incidence_from_index
+        h, nq, Eq = 73, 36000, 76000
+        gq = torch.Generator(device=dev).manual_seed(0)
+        srcq = torch.randint(0, nq, (Eq,), generator=gq, device=dev).to(torch.int32)
+        tgtq = torch.randint(0, nq, (Eq,), generator=gq, device=dev).to(torch.int32)
+        Mtq = incidence_from_index(tgtq, nq)
+        Aq = torch.randn(Eq, h, h, device=dev)
+        Xq, dMq = torch.randn(nq, h, device=dev), torch.randn(nq, h, device=dev)
+        bq = (Eq * h * h * 4 + Eq * h * 8 + nq * h * 8) / 1e9
+        rec("qc edge matvec fwd (E=76k, h=73)", timeit(lambda: ops.edge_matvec_fwd(Mtq, srcq, Aq, Xq)), bq)
+        erow = tgtq.clone(); evalq = torch.ones(Eq, device=dev)
+        rec("qc edge matvec bwd (dA + dx)", timeit(lambda: ops.edge_matvec_bwd(erow, evalq, srcq, Aq, Xq, dMq)), 2 * bq)
     if want("ew"):
         o2 = torch.empty(d, device=dev)
         rec("colsum", timeit(lambda: ops.colsum_(o2, X)), nd)
