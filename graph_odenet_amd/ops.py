@@ -392,6 +392,9 @@ def time_row_fixup_(g_row0, w_row0, t, at, accumulate):
 
 
 # ---- QC edge-conditioned messages ---------------------------------------------------------------
+EDGE_MSG_MIN_EDGES = 4096      # from this many edges on, the message step runs as per-edge matvec + SpMM
+
+
 def edge_matvec_fwd(Mt, src, A, X):
     """M[v] = sum_{(e,val) in row v} val * A[e] @ X[src[e]]."""
     lib = _lib.load()
@@ -399,6 +402,13 @@ def edge_matvec_fwd(Mt, src, A, X):
     h = X.shape[1]
     if A.dim() != 3 or A.shape[1] != h or A.shape[2] != h or A.shape[0] != src.numel():
         raise ValueError("edge_matvec: edge_data must be E x h x h with h = %d, got %s" % (h, tuple(A.shape)))
+    E = src.numel()
+    if E >= EDGE_MSG_MIN_EDGES:
+        # large batches: a workgroup per edge streams its matrix, the per-target sum is an SpMM over Etgt
+        msg = torch.empty(E, h, dtype=torch.float32, device=X.device)
+        check(lib.gode_edge_matvec_msg_f32(ptr(src), ptr(A), ptr(X), h, h, E, ptr(msg), stream_ptr()),
+              "gode_edge_matvec_msg_f32")
+        return spmm(Mt, msg)
     out = torch.empty(Mt.n_rows, h, dtype=torch.float32, device=X.device)
     check(lib.gode_edge_matvec_f32_fwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(A), ptr(X), h, h,
                                        Mt.n_rows, ptr(out), h, stream_ptr()), "gode_edge_matvec_f32_fwd")

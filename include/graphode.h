@@ -263,6 +263,10 @@ int gode_time_row_fixup_f32(float* g_row0, const float* w_row0, int64_t len, flo
 int gode_edge_matvec_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
                              const int32_t* src, const float* A, const float* X, int64_t ldx,
                              int64_t h, int64_t n_rows, float* out, int64_t ldo, void* stream);
+/* msg[e,:] = A[e] * X[src[e],:] for every edge (n_edges x h); with gode_spmm_csr_f32 over Etgt this is the two-launch
+ * form of gode_edge_matvec_f32_fwd for large batches (a workgroup per edge instead of per target). */
+int gode_edge_matvec_msg_f32(const int32_t* src, const float* A, const float* X, int64_t ldx, int64_t h,
+                             int64_t n_edges, float* msg, void* stream);
 int gode_edge_matvec_f32_bwd(const int32_t* edge_row, const float* edge_val, const int32_t* src,
                              const float* A, const float* X, int64_t ldx, const float* dM, int64_t ldm,
                              int64_t h, int64_t n_edges, float* dA, float* dxe, void* stream);

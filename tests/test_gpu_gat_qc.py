@@ -526,3 +526,30 @@ def test_gat_layer_record_path_vs_oracle_large(o):
     close(xd.grad, xr.grad, 2e-5, "gx")
     for q, r, nm in zip((lay.f.weight, lay.f.bias, lay.w.weight, lay.w.bias), ref_p, ("Wf", "bf", "ww", "bw")):
         close(q.grad, r.grad, 1e-4 if nm == "bw" else 1e-5, "grad " + nm)      # bw: analytically 0, sum of 3e5 roundings
+
+
+def test_edge_matvec_large_batch_path_matches_fused_path():
+    """From 4096 edges on the QC message step is a per-edge matvec kernel plus an SpMM over Etgt; same sums as the
+    fused per-target kernel (both visit a target's edges in edge-id order) and as the oracle."""
+    from graph_odenet_amd import ops
+    from graph_odenet_amd.graph import incidence_from_index
+    from oracle import layers_ref as R
+    gen = torch.Generator().manual_seed(7)
+    n, E, h = 1500, 5000, 73
+    src, tgt = torch.randint(0, n, (E,), generator=gen), torch.randint(0, n - 20, (E,), generator=gen)
+    A, X = torch.randn(E, h, h, generator=gen) / h ** 0.5, torch.randn(n, h, generator=gen)
+    Mt = incidence_from_index(tgt.to(dev()).to(torch.int32), n)
+    srcd = src.to(dev()).to(torch.int32)
+    big = ops.edge_matvec_fwd(Mt, srcd, A.to(dev()), X.to(dev()))
+    old = ops.EDGE_MSG_MIN_EDGES
+    ops.EDGE_MSG_MIN_EDGES = 1 << 30
+    try:
+        fused = ops.edge_matvec_fwd(Mt, srcd, A.to(dev()), X.to(dev()))
+    finally:
+        ops.EDGE_MSG_MIN_EDGES = old
+    Etgt = torch.zeros(n, E)
+    Etgt[tgt, torch.arange(E)] = 1.0
+    ref = R.edge_message_aggregate(X, src, Etgt, A)
+    close(big, ref, 1e-5, "per-edge + SpMM path")
+    close(fused, ref, 1e-5, "fused path")
+    close(big, fused, 2e-6, "paths agree")
