@@ -737,6 +737,241 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(LinComb xin, int n_rows, 
 }
 
 // ---------------------------------------------------------------------------------
+// Narrow products: d_out = NC in {1, 2, 4} columns (the two logit columns of the GAT ODE function), d_in = 16*NJ.
+// One memory-layout tile of 16 rows per wave as above, but no matrix pipe: the NC weight columns live in registers,
+// every lane multiplies its 4*NJ normalised values and the four lanes of a row are combined with two xor-shuffles.
+// HBM-bound (reads x once); the generic kernels below take 1.6 - 2.1 ms for these shapes at 2^20 rows.
+// ---------------------------------------------------------------------------------
+template <int NJ, int NC>
+__device__ __forceinline__ void narrow_load_w(float (&wk)[NJ][4][NC], const float* __restrict__ W, int has_time, int mg) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wk[j][q][c] = W[(int64_t)(has_time + 16 * j + 4 * mg + q) * NC + c];
+}
+
+template <int NJ, int CG, int NC>
+__global__ __launch_bounds__(256) void gn_narrow_fwd_kernel(LinComb xin, int n_rows, float eps,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ W, int has_time, float t,
+                                                            float* __restrict__ S, float* __restrict__ xout)
+{
+    constexpr int D = 16 * NJ;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int mr = l >> 2, mg = l & 3;
+    float wk[NJ][4][NC];
+    narrow_load_w<NJ, NC>(wk, W, has_time, mg);
+    float t0[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t0[c] = has_time ? t * W[c] : 0.f;
+    const int n_tiles = (n_rows + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 16 + mr;
+        const bool valid = row < n_rows;
+        float4 xv[NJ];
+        load_tile<NJ, 2>(xin, (int64_t)row * D + 4 * mg, valid, xv);
+        float p[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) p[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (xout != nullptr && valid) *reinterpret_cast<float4*>(xout + (int64_t)row * D + 16 * j + 4 * mg) = xv[j];
+            const float4 gm = gamma ? ld4(gamma + 16 * j + 4 * mg) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 bt = beta ? ld4(beta + 16 * j + 4 * mg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 xn = gn_forward_v<CG>(xv[j], eps, gm, bt);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                p[c] += (xn.x * wk[j][0][c] + xn.y * wk[j][1][c]) + (xn.z * wk[j][2][c] + xn.w * wk[j][3][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { p[c] += __shfl_xor(p[c], 1, 64); p[c] += __shfl_xor(p[c], 2, 64); }
+        if (valid && mg == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) S[(int64_t)row * NC + c] = t0[c] + p[c];
+        }
+    }
+}
+
+template <int NJ, int CG, int NC>
+__global__ __launch_bounds__(256) void gn_narrow_bwd_kernel(LinComb xin, int n_rows, float eps,
+                                                            const float* __restrict__ gamma, const float* __restrict__ W,
+                                                            int has_time, const float* __restrict__ dS, float out_scale,
+                                                            LinComb pre, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                                            int n_part)
+{
+    constexpr int D = 16 * NJ;
+    __shared__ float red[2 * 4 * D];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int mr = l >> 2, mg = l & 3;
+    float wk[NJ][4][NC];
+    narrow_load_w<NJ, NC>(wk, W, has_time, mg);
+    float4 dgs[NJ], dbs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { dgs[j] = make_float4(0.f, 0.f, 0.f, 0.f); dbs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    const int n_tiles = (n_rows + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 16 + mr;
+        const bool valid = row < n_rows;
+        float ds[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ds[c] = valid ? dS[(int64_t)row * NC + c] : 0.f;
+        float4 xt[NJ];
+        if (CG != 0) load_tile<NJ>(xin, (int64_t)row * D + 4 * mg, valid, xt);
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            const int c0 = 16 * tt + 4 * mg;
+            float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                dy.x = fmaf(ds[c], wk[tt][0][c], dy.x); dy.y = fmaf(ds[c], wk[tt][1][c], dy.y);
+                dy.z = fmaf(ds[c], wk[tt][2][c], dy.z); dy.w = fmaf(ds[c], wk[tt][3][c], dy.w);
+            }
+            float4 out = dy;
+            if (CG != 0) {          // GroupNorm backward, ATen's form - the same algebra as in gn_gemm_bwd_kernel
+                const float4 x = xt[tt];
+                float4 mean, rstd;
+                gn_stats<CG>(x, eps, mean, rstd);
+                const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y,
+                                              (x.z - mean.z) * rstd.z, (x.w - mean.w) * rstd.w);
+                const float4 gm = gamma ? ld4(gamma + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+                if (valid) {
+                    dgs[tt].x += dy.x * xh.x; dgs[tt].y += dy.y * xh.y; dgs[tt].z += dy.z * xh.z; dgs[tt].w += dy.w * xh.w;
+                    dbs[tt].x += dy.x; dbs[tt].y += dy.y; dbs[tt].z += dy.z; dbs[tt].w += dy.w;
+                }
+                const float4 px = make_float4(dh.x * x.x, dh.y * x.y, dh.z * x.z, dh.w * x.w);
+                float4 dsg, dbg;
+                if (CG == 1) {
+                    dsg = px; dbg = dh;
+                } else if (CG == 2) {
+                    dsg = make_float4(px.x + px.y, px.x + px.y, px.z + px.w, px.z + px.w);
+                    dbg = make_float4(dh.x + dh.y, dh.x + dh.y, dh.z + dh.w, dh.z + dh.w);
+                } else {
+                    const float a = (px.x + px.y) + (px.z + px.w);
+                    const float b = (dh.x + dh.y) + (dh.z + dh.w);
+                    dsg = make_float4(a, a, a, a); dbg = make_float4(b, b, b, b);
+                }
+                constexpr float sc = 1.0f / (CG > 0 ? CG : 1);
+                const float4 r3 = make_float4(rstd.x * rstd.x * rstd.x * sc, rstd.y * rstd.y * rstd.y * sc,
+                                              rstd.z * rstd.z * rstd.z * sc, rstd.w * rstd.w * rstd.w * sc);
+                const float4 c2 = make_float4((dbg.x * mean.x - dsg.x) * r3.x, (dbg.y * mean.y - dsg.y) * r3.y,
+                                              (dbg.z * mean.z - dsg.z) * r3.z, (dbg.w * mean.w - dsg.w) * r3.w);
+                const float4 c3 = make_float4(-c2.x * mean.x - dbg.x * rstd.x * sc, -c2.y * mean.y - dbg.y * rstd.y * sc,
+                                              -c2.z * mean.z - dbg.z * rstd.z * sc, -c2.w * mean.w - dbg.w * rstd.w * sc);
+                out = make_float4(rstd.x * gm.x * dy.x + c2.x * x.x + c3.x, rstd.y * gm.y * dy.y + c2.y * x.y + c3.y,
+                                  rstd.z * gm.z * dy.z + c2.z * x.z + c3.z, rstd.w * gm.w * dy.w + c2.w * x.w + c3.w);
+            }
+            if (valid) {
+                float4 o = make_float4(out_scale * out.x, out_scale * out.y, out_scale * out.z, out_scale * out.w);
+                if (pre.n > 0) {
+                    const float4 pv = lc_load4(pre, (int64_t)row * D + c0);
+                    o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+                }
+                *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) = o;
+            }
+        }
+    }
+    if (CG != 0 && dgamma_part) {
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            float4 a = dgs[tt], b = dbs[tt];
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) {
+                a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+                b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+            }
+            if (mr == 0) {
+                *reinterpret_cast<float4*>(red + wave * D + 16 * tt + 4 * mg) = a;
+                *reinterpret_cast<float4*>(red + (4 + wave) * D + 16 * tt + 4 * mg) = b;
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            dgamma_part[(int64_t)blockIdx.x * D + c] = (red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c]);
+            dbeta_part[(int64_t)blockIdx.x * D + c] = (red[4 * D + c] + red[5 * D + c]) + (red[6 * D + c] + red[7 * D + c]);
+        }
+        for (int p = gridDim.x + blockIdx.x; p < n_part; p += gridDim.x)
+            for (int c = threadIdx.x; c < D; c += 256) { dgamma_part[(int64_t)p * D + c] = 0.f; dbeta_part[(int64_t)p * D + c] = 0.f; }
+    }
+}
+
+template <int NJ, int CG, int NC>
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(LinComb xin, int n_rows, float eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dS, int has_time,
+                                                           float* __restrict__ dW_part)
+{
+    constexpr int D = 16 * NJ;
+    __shared__ float red[4][(D + 1) * NC];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int mr = l >> 2, mg = l & 3;
+    float acc[NJ][4][NC], acc0[NC];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[j][q][c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc0[c] = 0.f;
+    const int n_tiles = (n_rows + 15) / 16;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const int row = tile * 16 + mr;
+        const bool valid = row < n_rows;
+        float ds[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ds[c] = valid ? dS[(int64_t)row * NC + c] : 0.f; if (mg == 0) acc0[c] += ds[c]; }
+        float4 xv[NJ];
+        load_tile<NJ, 2>(xin, (int64_t)row * D + 4 * mg, valid, xv);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float4 gm = gamma ? ld4(gamma + 16 * j + 4 * mg) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 bt = beta ? ld4(beta + 16 * j + 4 * mg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 xn = gn_forward_v<CG>(xv[j], eps, gm, bt);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {      // ds is 0 on invalid rows
+                acc[j][0][c] = fmaf(xn.x, ds[c], acc[j][0][c]); acc[j][1][c] = fmaf(xn.y, ds[c], acc[j][1][c]);
+                acc[j][2][c] = fmaf(xn.z, ds[c], acc[j][2][c]); acc[j][3][c] = fmaf(xn.w, ds[c], acc[j][3][c]);
+            }
+        }
+    }
+    // lanes with equal mg hold the same channels: xor 4 .. 32; then the four waves through LDS
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[j][q][c] += __shfl_xor(acc[j][q][c], o, 64);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc0[c] += __shfl_xor(acc0[c], o, 64);
+    }
+    if (mr == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) red[wave][(1 + 16 * j + 4 * mg + q) * NC + c] = acc[j][q][c];
+        if (mg == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) red[wave][c] = acc0[c];
+        }
+    }
+    __syncthreads();
+    float* out = dW_part + (int64_t)blockIdx.x * (D + has_time) * NC;
+    for (int idx = threadIdx.x; idx < (D + has_time) * NC; idx += 256) {
+        const int src_idx = idx + (has_time ? 0 : NC);           // without a time row the colsum(dS) row is dropped
+        out[idx] = (red[0][src_idx] + red[1][src_idx]) + (red[2][src_idx] + red[3][src_idx]);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------
 // generic fallbacks (any d_in, d_out, groups): correct, not tuned.
 // block = 256 threads, RB rows per block pass, rows staged (normalised) in LDS.
 // ---------------------------------------------------------------------------------
@@ -940,6 +1175,16 @@ int fast_cg(int64_t d_in, int64_t d_out, int32_t groups) {
     return -1;
 }
 
+int narrow_cg(int64_t d_in, int64_t d_out, int32_t groups) {
+    // CG when the narrow (2-column) kernels apply, else -1
+    if (d_out != 2) return -1;
+    if (d_in != 16 && d_in != 32 && d_in != 64 && d_in != 128) return -1;
+    if (groups == 0) return 0;
+    if (d_in % groups) return -1;
+    const int64_t cg = d_in / groups;
+    return (cg == 1 || cg == 2 || cg == 4) ? (int)cg : -1;
+}
+
 int64_t fwd_blocks(int64_t n_rows) {
     int64_t b = ((n_rows + 15) / 16 + 3) / 4;
     if (b < 1) b = 1;
@@ -1019,6 +1264,19 @@ extern "C" int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin, int64_t n_r
         GODE_DISPATCH_ALL(GODE_FWD)
 #undef GODE_FWD
     }
+    {
+        const int cg = narrow_cg(d_in, d_out, groups);
+        if (cg >= 0 && al) {
+            const int nj = (int)(d_in / 16);
+            const int64_t blocks = fwd_blocks(n_rows);
+#define GODE_NFWD(NJV, CGV)                                                                                 \
+            { hipLaunchKernelGGL((gn_narrow_fwd_kernel<NJV, CGV, 2>), dim3((unsigned)blocks), dim3(256), 0, s, \
+                                 lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S, x_out);              \
+              GODE_LAUNCH_CHECK(); return 0; }
+            GODE_DISPATCH_ALL(GODE_NFWD)
+#undef GODE_NFWD
+        }
+    }
     if (x_out) { rc = gode_lincomb_f32(x_out, xin, n_rows * d_in, stream); if (rc) return rc; }
     const size_t lds = ((size_t)RB * d_in + (size_t)RB * (groups > 0 ? groups : 1) * 2) * sizeof(float);
     rc = set_lds(gn_gemm_fwd_generic, lds); if (rc) return rc;
@@ -1069,6 +1327,21 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
         GODE_DISPATCH_ALL(GODE_BWD)
 #undef GODE_BWD
     }
+    {
+        const int ncg = narrow_cg(d_in, d_out, groups);
+        if (ncg >= 0 && al) {
+            const int nj = (int)(d_in / 16);
+            const int cg = ncg;
+            const int64_t blocks = fwd_blocks(n_rows);
+#define GODE_NBWD(NJV, CGV)                                                                                 \
+            { hipLaunchKernelGGL((gn_narrow_bwd_kernel<NJV, CGV, 2>), dim3((unsigned)blocks), dim3(256), 0, s, \
+                                 lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, \
+                                 dbeta_part, (int)n_part);                                                  \
+              GODE_LAUNCH_CHECK(); return 0; }
+            GODE_DISPATCH_ALL(GODE_NBWD)
+#undef GODE_NBWD
+        }
+    }
     if (dgamma_part && groups > 0) {        // the generic kernel accumulates into its block partials
         hipError_t e = hipMemsetAsync(dgamma_part, 0, (size_t)n_part * d_in * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
@@ -1112,6 +1385,19 @@ extern "C" int gode_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_WG)
 #undef GODE_WG
+    }
+    {
+        const int ncg = narrow_cg(d_in, d_out, groups);
+        if (ncg >= 0 && al && !(((uintptr_t)dW_part) & 3)) {
+            const int nj = (int)(d_in / 16);
+            const int cg = ncg;
+#define GODE_NWG(NJV, CGV)                                                                                  \
+            { hipLaunchKernelGGL((narrow_wgrad_kernel<NJV, CGV, 2>), dim3((unsigned)blocks), dim3(256), 0, s, \
+                                 lc, (int)n_rows, eps, gamma, beta, dS, has_time, dW_part);                 \
+              GODE_LAUNCH_CHECK(); return 0; }
+            GODE_DISPATCH_ALL(GODE_NWG)
+#undef GODE_NWG
+        }
     }
     const size_t lds = ((size_t)RB * d_in + (size_t)RB * (groups > 0 ? groups : 1) * 2) * sizeof(float);
     rc = set_lds(wgrad_generic, lds); if (rc) return rc;

@@ -208,6 +208,46 @@ def test_gn_time_gemm_rectangular(d, dout, groups):
     close(gW[0] * t, W.grad[0], 2e-5 * n ** 0.5, "dW time row")
 
 
+@pytest.mark.parametrize("d,groups", [(16, 16), (32, 16), (64, 32), (128, 32), (128, 0), (64, 16)])
+@pytest.mark.parametrize("n", [5, 1000, 70001])
+def test_gn_time_gemm_two_columns(d, groups, n):
+    """d_out = 2 (the logit columns of the GAT ODE function): the narrow register kernels (csrc/gemm.hip,
+    gn_narrow_*), incl. a multi-term input written out through x_out, accumulation into `pre`, affine partials and the
+    time row, against torch CPU ops.  (64, 16) has 4 channels per group at d = 64."""
+    from graph_odenet_amd import ops
+    import torch.nn.functional as F
+    torch.manual_seed(d + n)
+    y, k1 = torch.randn(n, d), torch.randn(n, d)
+    x = (y + 0.25 * k1).requires_grad_(True)
+    gam = (torch.rand(d) + 0.5).requires_grad_(True)
+    bet = (torch.rand(d) - 0.5).requires_grad_(True)
+    W = (torch.randn(d + 1, 2) / d ** 0.5).requires_grad_(True)
+    t = 0.61
+    xn = F.group_norm(x, groups, gam, bet, 1e-5) if groups else x
+    S = torch.cat([torch.full((n, 1), t), xn], 1) @ W
+    dS = torch.randn(n, 2)
+    S.backward(dS)
+    D = dev()
+    g_, b_ = (gam.detach().to(D), bet.detach().to(D)) if groups else (None, None)
+    terms = [(1.0, y.to(D)), (0.25, k1.to(D))]
+    cg = d // groups if groups else 0
+    tol = {0: TOL, 1: 2e-4, 2: 2e-5}.get(cg, TOL)
+    xo = torch.empty(n, d, device=D)
+    close(ops.gn_time_gemm(terms, n, d, groups, 1e-5, g_, b_, W.detach().to(D), True, t, x_out=xo), S, tol, "fwd")
+    close(xo, x.detach(), 1e-6, "x_out")
+    pre = torch.randn(n, d)
+    dx, dgp, dbp = ops.gn_time_gemm_bwd(terms, n, d, groups, 1e-5, g_, W.detach().to(D), True, dS.to(D), out_scale=0.5,
+                                        pre_terms=[(1.0, pre.to(D))])
+    close(dx, pre + 0.5 * x.grad, {0: TOL, 1: 2e-3, 2: 1e-4}.get(cg, 2e-5), "pre + scale * dx")
+    if groups:
+        close(dgp.sum(0), gam.grad, (2e-3 if cg == 1 else 2e-5) * max(1, n ** 0.5), "dgamma")
+        close(dbp.sum(0), bet.grad, 2e-5 * max(1, n ** 0.5), "dbeta")
+    part = ops.wgrad(terms, n, d, groups, 1e-5, g_, b_, dS.to(D), True)
+    gW = part.sum(0).view(d + 1, 2)
+    close(gW[1:], W.grad[1:], max(tol, 2e-5) * max(1, n ** 0.5), "dW")
+    close(gW[0] * t, W.grad[0], 2e-5 * max(1, n ** 0.5), "dW time row")
+
+
 def test_spmm_strided_output():
     from graph_odenet_amd import graph as G, ops
     n, d = 500, 16
