@@ -89,12 +89,7 @@ SIGNATURES = {
     "gode_reduce_parts_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
     "gode_colsum_scratch_bytes": (c_i64, [c_i64, c_i64]),
     "gode_colsum_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p, c_p]),
-    "gode_edge_softmax_scratch_bytes": (c_i64, [c_i64]),
-    "gode_edge_softmax_logits_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
-    "gode_edge_softmax_agg_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_f, c_i64,
-                                            c_p, c_p, c_p, c_p]),
-    "gode_edge_softmax_agg_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p,
-                                            c_i64, c_p, c_p, c_p]),
+    "gode_gat_logits_scratch_bytes": (c_i64, [c_i64]),
     "gode_gat_logits_f32": (c_i, [ctypes.POINTER(GatProj), c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
     "gode_gat_agg_f32_fwd": (c_i, [ctypes.POINTER(Graph), c_p, c_p, ctypes.POINTER(GatProj), c_i64, c_p, c_p, c_p, c_f,
                                    c_p, c_p, c_p, c_p]),

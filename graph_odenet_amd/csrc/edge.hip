@@ -23,7 +23,6 @@ struct Proj {
     const float* pt; int64_t ldt;     // message part gathered by target
     const float* as; const float* at; int64_t lda;   // logit parts per node
 };
-Proj proj_of(const float* P, int64_t ldp, int64_t o) { return Proj{P, ldp, P + o, ldp, P + 2 * o, P + 2 * o + 1, ldp}; }
 Proj proj_of(const gode_gat_proj_t* p) { return Proj{p->ps, p->ld_s, p->pt, p->ld_t, p->as, p->at, p->ld_a}; }
 
 __device__ __forceinline__ float block_max(float v) {
@@ -740,7 +739,7 @@ int pow2_group(int o) { int G = 1; while (G < o && G < 64) G <<= 1; return G; }
 
 }  // namespace
 
-extern "C" int64_t gode_edge_softmax_scratch_bytes(int64_t n_edges) {
+extern "C" int64_t gode_gat_logits_scratch_bytes(int64_t n_edges) {
     int64_t b = (n_edges + 255) / 256; if (b > 1024) b = 1024; if (b < 1) b = 1;
     return b * (int64_t)sizeof(float);
 }
@@ -813,42 +812,6 @@ int launch_agg_bwd(const int32_t* rowptr, const int32_t* eid, const float* val, 
 }
 
 }  // namespace
-
-extern "C" int gode_edge_softmax_logits_f32(const float* P, int64_t ldp, int64_t o, const float* bw,
-                                            const int32_t* src, const int32_t* tgt, int64_t n_edges,
-                                            float* a, float* amax, float* scratch, void* stream) {
-    if (n_edges < 0 || o <= 0 || ldp < 2 * o + 2) return GODE_E_SHAPE;
-    if (!amax || !scratch) return GODE_E_NULLPTR;
-    if (n_edges > 0 && (!P || !src || !tgt || !a)) return GODE_E_NULLPTR;
-    if (n_edges > INT32_MAX || o > (1 << 20)) return GODE_E_RANGE;
-    return launch_logits(proj_of(P, ldp, o), bw, src, tgt, n_edges, a, amax, scratch, (hipStream_t)stream);
-}
-
-extern "C" int gode_edge_softmax_agg_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
-                                             const int32_t* src, const int32_t* tgt,
-                                             const float* P, int64_t ldp, int64_t o, const float* bf,
-                                             const float* a, const float* amax, float eps, int64_t n_rows,
-                                             float* out, float* w_out, float* den_out, void* stream) {
-    if (n_rows < 0 || o <= 0 || ldp < 2 * o + 2) return GODE_E_SHAPE;
-    if (n_rows == 0) return 0;
-    if (!rowptr || !eid || !src || !tgt || !P || !a || !amax || !out || !w_out || !den_out) return GODE_E_NULLPTR;
-    if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
-    return launch_agg_fwd(rowptr, eid, val, src, tgt, proj_of(P, ldp, o), o, bf, a, amax, eps, n_rows, out, w_out,
-                          den_out, (hipStream_t)stream);
-}
-
-extern "C" int gode_edge_softmax_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, const float* val,
-                                             const int32_t* src, const int32_t* tgt,
-                                             const float* P, int64_t ldp, int64_t o, const float* bf,
-                                             const float* w, const float* den, const float* out, const float* dout,
-                                             int64_t n_rows, float* dz, float* da, void* stream) {
-    if (n_rows < 0 || o <= 0 || ldp < 2 * o + 2) return GODE_E_SHAPE;
-    if (n_rows == 0) return 0;
-    if (!rowptr || !eid || !src || !tgt || !P || !w || !den || !out || !dout || !dz || !da) return GODE_E_NULLPTR;
-    if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
-    return launch_agg_bwd(rowptr, eid, val, src, tgt, proj_of(P, ldp, o), o, bf, w, den, out, dout, make_lincomb(nullptr),
-                          1.f, n_rows, dz, da, (hipStream_t)stream);
-}
 
 // ---- the same three steps over separately stored projections, plus the fused pieces of the ODE-function VJP --------
 extern "C" int gode_gat_logits_f32(const gode_gat_proj_t* proj, const float* bw, const int32_t* src, const int32_t* tgt,

@@ -246,47 +246,7 @@ def colsum_(out, X, scale=1.0, accumulate=False):
 
 
 # ---- GAT-style edge attention ---------------------------------------------------------------
-def edge_softmax_logits(P, o, bw, src, tgt):
-    """a[e] = P[src,2o] + P[tgt,2o+1] + bw ; returns (a[E], amax[1])."""
-    lib = _lib.load()
-    _need(P, "P"); _need(bw, "bw"); _need(src, "src", torch.int32); _need(tgt, "tgt", torch.int32)
-    E = src.numel()
-    a = torch.empty(E, dtype=torch.float32, device=P.device)
-    amax = torch.empty(1, dtype=torch.float32, device=P.device)
-    sc = _scratch(P.device, lib.gode_edge_softmax_scratch_bytes(E))
-    check(lib.gode_edge_softmax_logits_f32(ptr(P), P.shape[1], o, ptr(bw), ptr(src), ptr(tgt), E, ptr(a), ptr(amax),
-                                           ptr(sc), stream_ptr()), "gode_edge_softmax_logits_f32")
-    return a, amax
-
-
-def edge_softmax_agg_fwd(Mt, src, tgt, P, o, bf, a, amax, eps, out=None):
-    lib = _lib.load()
-    _need(P, "P"); _need(bf, "bf"); _need(a, "a"); _need(amax, "amax")
-    n = Mt.n_rows
-    if out is None:
-        out = torch.empty(n, o, dtype=torch.float32, device=P.device)
-    _need(out, "out")
-    w = torch.zeros(src.numel(), dtype=torch.float32, device=P.device)
-    den = torch.empty(n, dtype=torch.float32, device=P.device)
-    check(lib.gode_edge_softmax_agg_f32_fwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ptr(P),
-                                            P.shape[1], o, ptr(bf), ptr(a), ptr(amax), float(eps), n, ptr(out),
-                                            ptr(w), ptr(den), stream_ptr()), "gode_edge_softmax_agg_f32_fwd")
-    return out, w, den
-
-
-def edge_softmax_agg_bwd(Mt, src, tgt, P, o, bf, w, den, out, dout):
-    lib = _lib.load()
-    _need(dout, "dout"); _need(out, "out")
-    E = src.numel()
-    dz = torch.zeros(E, o, dtype=torch.float32, device=P.device)
-    da = torch.zeros(E, dtype=torch.float32, device=P.device)
-    check(lib.gode_edge_softmax_agg_f32_bwd(ptr(Mt.rowptr), ptr(Mt.col), ptr(Mt.val), ptr(src), ptr(tgt), ptr(P),
-                                            P.shape[1], o, ptr(bf), ptr(w), ptr(den), ptr(out), ptr(dout), Mt.n_rows,
-                                            ptr(dz), ptr(da), stream_ptr()), "gode_edge_softmax_agg_f32_bwd")
-    return dz, da
-
-
-# ---- GAT over separately stored projections + fused VJP pieces (gat_ode.py) ------------------------
+# (projections stored by role + fused VJP pieces; gat_layers.py, gat_ode.py)
 def gat_proj(Ps, Pt, A2):
     """gode_gat_proj_t over Ps, Pt (n x o each) and A2 (n x 2: logit parts by source / by target)."""
     _need(Ps, "Ps"); _need(Pt, "Pt"); _need(A2, "A2")
@@ -302,7 +262,7 @@ def gat_logits(proj, bw, src, tgt, a, amax):
     lib = _lib.load()
     _need(bw, "bw"); _need(a, "a"); _need(amax, "amax")
     E = src.numel()
-    sc = _scratch(a.device, lib.gode_edge_softmax_scratch_bytes(E))
+    sc = _scratch(a.device, lib.gode_gat_logits_scratch_bytes(E))
     check(lib.gode_gat_logits_f32(ctypes.byref(proj), ptr(bw), ptr(src), ptr(tgt), E, ptr(a), ptr(amax), ptr(sc),
                                   stream_ptr()), "gode_gat_logits_f32")
 

@@ -22,7 +22,7 @@
  *   gode_wgrad_f32               autograd of GCN/layers.py:70 w.r.t. weight
  *   gode_lincomb_f32             torchdiffeq RK stage input / solution combine (call site GCN/models.py:192)
  *   gode_rk_errnorm_f32          torchdiffeq dopri5 mixed-tolerance error ratio (same call site)
- *   gode_edge_softmax_*          GAT/layers.py:40-55 (and :104-120)
+ *   gode_gat_*                   GAT/layers.py:40-55 (and :104-120)
  *   gode_edge_matvec_*           QC/mpnn.py:27-29, QC/layers.py:143-145
  */
 #ifndef GRAPHODE_H
@@ -175,30 +175,15 @@ int gode_colsum_f32(float* out, const float* X, int64_t n_rows, int64_t d, float
 int64_t gode_colsum_scratch_bytes(int64_t n_rows, int64_t d);
 
 /* ---- GAT-style edge attention (GAT/layers.py:40-55, :104-120) --------------------------
- * The two Linear layers of the reference act on h = [x[src] | x[tgt]]; the caller applies them at
- * node level: P (n_nodes x ldp, ldp >= 2o+2) = x * [Wf_src^T | Wf_tgt^T | ww_src^T | ww_tgt^T].
- *   a[e]   = P[src[e], 2o] + P[tgt[e], 2o+1] + bw[0]         amax[0] = max_e a[e]   (GLOBAL max, :47)
- *   w[e]   = exp(a[e] - amax)
- *   out[v] = sum_k val[k]*w[e_k]*relu(P[src,0:o] + P[tgt,o:2o] + bf) / (sum_k val[k]*w[e_k] + eps)
- * over the entries k of row v of Mtgt in CSR form (rowptr, eid = column = edge id, val or NULL = 1).
- * den_out[v] holds the denominator, w_out[e] the unnormalised weight (both needed by the backward).
- * Backward returns dz (E x o: gradient w.r.t. the pre-activation z_e) and da (E: gradient w.r.t. a[e]
- * through w only; the caller adds the path through the global max and scatters both to the nodes
- * with gode_spmm_csr_f32 over the src / tgt incidence matrices). */
-int64_t gode_edge_softmax_scratch_bytes(int64_t n_edges);
-int gode_edge_softmax_logits_f32(const float* P, int64_t ldp, int64_t o, const float* bw /* nullable */,
-                                 const int32_t* src, const int32_t* tgt, int64_t n_edges,
-                                 float* a, float* amax, float* scratch, void* stream);
-int gode_edge_softmax_agg_f32_fwd(const int32_t* rowptr, const int32_t* eid, const float* val,
-                                  const int32_t* src, const int32_t* tgt,
-                                  const float* P, int64_t ldp, int64_t o, const float* bf /* nullable */,
-                                  const float* a, const float* amax, float eps, int64_t n_rows,
-                                  float* out, float* w_out, float* den_out, void* stream);
-int gode_edge_softmax_agg_f32_bwd(const int32_t* rowptr, const int32_t* eid, const float* val,
-                                  const int32_t* src, const int32_t* tgt,
-                                  const float* P, int64_t ldp, int64_t o, const float* bf,
-                                  const float* w, const float* den, const float* out, const float* dout,
-                                  int64_t n_rows, float* dz, float* da, void* stream);
+ * The two Linear layers of the reference act on h = [x[src] | x[tgt]]; the caller applies them at node level and
+ * hands over the projections split by role (gode_gat_proj_t below):
+ *   z_e = ps[src_e, 0:o] + pt[tgt_e, 0:o] + bf        a_e = as[src_e] + at[tgt_e] + bw      amax = max_e a_e (GLOBAL, :47)
+ *   w_e = exp(a_e - amax)
+ *   out[v] = sum_k val[k]*w[e_k]*relu(z[e_k]) / (sum_k val[k]*w[e_k] + eps)    over the entries k of row v of Mtgt.
+ * den_out[v] holds the denominator, w_out[e] the unnormalised weight (both needed by the backward).  The backward
+ * returns dz (E x o: gradient w.r.t. z_e) and da (E: gradient w.r.t. a_e through w only); gode_gat_maxpath_f32 adds
+ * the path through the global maximum and gode_gat_scatter_f32 / gode_spmm_csr_f32 sum both per node. */
+int64_t gode_gat_logits_scratch_bytes(int64_t n_edges);
 
 /* A CSR matrix with its balanced record list, as the multi-launch entry points take it. */
 typedef struct gode_graph {
@@ -208,11 +193,8 @@ typedef struct gode_graph {
     int64_t n_rows; int64_t nnz;
 } gode_graph_t;
 
-/* The same three steps over separately stored node-level projections, and the fused pieces of the VJP of the
- * GAT ODE function (GAT/models.py:172-179 -> GAT/layers.py:95-122).  Splitting P lets the caller produce the two
- * d x d message blocks with the square MFMA kernel (gode_gn_time_gemm_f32, once per block) and the two logit
- * columns with a 2-column product:
- *   z_e = ps[src_e, 0:o] + pt[tgt_e, 0:o] + bf ;  a_e = as[src_e] + at[tgt_e] + bw. */
+/* Node-level projections.  Keeping the roles apart lets the caller produce the two d x d message blocks with the
+ * square MFMA kernel (gode_gn_time_gemm_f32, once per block) and the two logit columns with the 2-column kernels. */
 typedef struct gode_gat_proj {
     const float* ps; int64_t ld_s;      /* message part gathered by source, n x o, row stride ld_s */
     const float* pt; int64_t ld_t;      /* message part gathered by target */
