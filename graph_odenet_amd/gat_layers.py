@@ -106,8 +106,8 @@ class _EdgeAttentionFn(torch.autograd.Function):
         proj = ops.gat_proj(Ps, Pt, A2)
         ops.gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=dout.contiguous())
         dbf = torch.empty_like(bf)
-        ops.colsum_(dbf, dz)
-        dbw = da.sum().reshape(1)
+        ops.colsum_(dbf, dPt)                                    # sum_e dz_e = sum_v (sum over the edges entering v)
+        dbw = dA2[:, 1].sum().reshape(1)
         return None, dPs, dPt, dA2, dbf, dbw, None
 
 

@@ -153,8 +153,10 @@ class GatOdeAdjointField(GatOdeField):
         # cotangent -a of the VJP, masked by the outer relu, is formed inside the kernel
         ops.gat_vjp(eg, w.proj, o, s.bf, w.a, w.amax, w.wgt, w.den, out[0], w.dz, w.da, w.dPs, w.dPt, w.dA2,
                     cot_terms=terms[1], cot_scale=-1.0)
-        ops.colsum_(g["bf"], w.dz)
-        ops.colsum_(g["bw"], w.da.view(-1, 1))
+        # bias gradients: sum over edges of dz / da = sum over nodes of the per-target sums just formed (every edge has
+        # exactly one target) - N rows instead of E
+        ops.colsum_(g["bf"], w.dPt)
+        ops.colsum_(g["bw"], w.dA2[:, 1:2].contiguous())
         nb = w.np_b
         affine = s.groups > 0
         for j, (Wj, dPj) in enumerate(((s.Wsrc, w.dPs), (s.Wtgt, w.dPt), (s.Wlog, w.dA2))):
