@@ -52,6 +52,29 @@ __global__ __launch_bounds__(256) void ratio_sumsq_kernel(double* part, LinComb 
     block_reduce_store(s, part);
 }
 
+// 16-byte form of the same reduction (n % 4 == 0, aligned operands): all term loads of an iteration are in flight
+// together; the scalar form above reaches 2 TB/s at 2^27 elements, this one streams.
+template <int MODE>
+__global__ __launch_bounds__(256) void ratio_sumsq4_kernel(double* part, LinComb lc, const float* y0,
+                                                           const float* y1, float rtol, float atol, int64_t n4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double s = 0.0;
+    for (; i < n4; i += stride) {
+        const float4 a = *reinterpret_cast<const float4*>(y0 + i * 4);
+        float4 m = make_float4(fabsf(a.x), fabsf(a.y), fabsf(a.z), fabsf(a.w));
+        if (MODE == 0) {
+            const float4 b = *reinterpret_cast<const float4*>(y1 + i * 4);
+            m = make_float4(fmaxf(m.x, fabsf(b.x)), fmaxf(m.y, fabsf(b.y)), fmaxf(m.z, fabsf(b.z)), fmaxf(m.w, fabsf(b.w)));
+        }
+        const float4 e = lc_load4(lc, i * 4);
+        const float r0 = e.x / (atol + rtol * m.x), r1 = e.y / (atol + rtol * m.y);
+        const float r2 = e.z / (atol + rtol * m.z), r3 = e.w / (atol + rtol * m.w);
+        s += ((double)r0 * (double)r0 + (double)r1 * (double)r1) + ((double)r2 * (double)r2 + (double)r3 * (double)r3);
+    }
+    block_reduce_store(s, part);
+}
+
 __global__ __launch_bounds__(256) void final_sum_kernel(double* out, const double* part, int nparts) {
     __shared__ double sm[256];
     double s = 0.0;
@@ -207,8 +230,12 @@ extern "C" int gode_rk_errnorm_f32(double* out, const float* y0, const float* y1
     int rc = check_lincomb(elc, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int nb = red_blocks(n);
-    hipLaunchKernelGGL(ratio_sumsq_kernel<0>, dim3(nb), dim3(256), 0, s, (double*)scratch, make_lincomb(elc),
-                       y0, y1, rtol, atol, n);
+    if (n % 4 == 0 && lincomb_aligned16(elc) && !((((uintptr_t)y0) | ((uintptr_t)y1)) & 15))
+        hipLaunchKernelGGL(ratio_sumsq4_kernel<0>, dim3(nb), dim3(256), 0, s, (double*)scratch, make_lincomb(elc),
+                           y0, y1, rtol, atol, n / 4);
+    else
+        hipLaunchKernelGGL(ratio_sumsq_kernel<0>, dim3(nb), dim3(256), 0, s, (double*)scratch, make_lincomb(elc),
+                           y0, y1, rtol, atol, n);
     GODE_LAUNCH_CHECK();
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, out, (const double*)scratch, nb);
     GODE_LAUNCH_CHECK();
@@ -222,8 +249,12 @@ extern "C" int gode_rk_scaled_sumsq_f32(double* out, const gode_lincomb_t* lc, c
     int rc = check_lincomb(lc, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int nb = red_blocks(n);
-    hipLaunchKernelGGL(ratio_sumsq_kernel<1>, dim3(nb), dim3(256), 0, s, (double*)scratch, make_lincomb(lc),
-                       y, y, rtol, atol, n);
+    if (n % 4 == 0 && lincomb_aligned16(lc) && !(((uintptr_t)y) & 15))
+        hipLaunchKernelGGL(ratio_sumsq4_kernel<1>, dim3(nb), dim3(256), 0, s, (double*)scratch, make_lincomb(lc),
+                           y, y, rtol, atol, n / 4);
+    else
+        hipLaunchKernelGGL(ratio_sumsq_kernel<1>, dim3(nb), dim3(256), 0, s, (double*)scratch, make_lincomb(lc),
+                           y, y, rtol, atol, n);
     GODE_LAUNCH_CHECK();
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, s, out, (const double*)scratch, nb);
     GODE_LAUNCH_CHECK();
