@@ -142,6 +142,19 @@ class _Plan:
         self.adj = None
         self.seen_f = self.seen_b = 0
         self.gf = self.gb = None
+        self.no_capture = False          # set when a capture attempt failed: the plan stays on the eager path
+
+
+def _try_capture(plan, field, comps, t0, t1):
+    """A captured solve, or None (and the plan switched to the eager path for good) when the capture fails."""
+    try:
+        return _GraphedSolve(field, comps, t0, t1, plan.n_steps)
+    except RuntimeError as exc:
+        import warnings
+        plan.no_capture = True
+        warnings.warn("graph_odenet_amd: HIP-graph capture of a fixed-grid solve failed (%s); staying on the eager path"
+                      % (str(exc).splitlines()[0],))
+        return None
 
 
 def _plan_for(func, y0, tl, method, options, params):
@@ -219,8 +232,8 @@ class _OdeintAdjoint(torch.autograd.Function):
         plan, (fwd, mk_adj, plist) = _plan_for(func, y0, tl, method, options, params)
         stats = Dopri5Stats()
         y_start = y0.detach().contiguous()
-        if plan is not None and plan.gf is None and plan.seen_f >= 1:
-            plan.gf = _GraphedSolve(fwd, [y_start.clone()], tl[0], tl[1], plan.n_steps)
+        if plan is not None and plan.gf is None and plan.seen_f >= 1 and not plan.no_capture:
+            plan.gf = _try_capture(plan, fwd, [y_start.clone()], tl[0], tl[1])
         if plan is not None and plan.gf is not None:
             (y_end,) = plan.gf.run([y_start])
             stats.nfe += plan.gf.nfe
@@ -249,11 +262,12 @@ class _OdeintAdjoint(torch.autograd.Function):
         func, tl = ctx.func, ctx.tl
         grad_out = grad_out.contiguous()
         plan = ctx.plan
-        if plan is not None and plan.seen_b >= 1:
+        if plan is not None and plan.seen_b >= 1 and plan.gb is None and not plan.no_capture:
             with torch.no_grad():
-                if plan.gb is None:
-                    plan.adj = plan.mk_adj()
-                    plan.gb = _GraphedSolve(plan.adj, plan.adj.new_state(ans[1]), tl[1], tl[0], plan.n_steps)
+                plan.adj = plan.mk_adj()
+                plan.gb = _try_capture(plan, plan.adj, plan.adj.new_state(ans[1]), tl[1], tl[0])
+        if plan is not None and plan.gb is not None:
+            with torch.no_grad():
                 vals = [ans[1], grad_out[1]] + [None] * (len(plan.gb.inputs) - 2)
                 comps = plan.gb.run(vals)
                 comps[1].add_(grad_out[0])

@@ -468,3 +468,25 @@ def test_depth_sweep_models_refuse_too_few_layers():
                      ("ODEK2", 3)):
         with pytest.raises(ValueError):
             getattr(models, name)(nfeat=4, nhid=4, nclass=2, dropout=0.5, nlayers=nl)
+
+
+def test_failed_graph_capture_falls_back_to_eager(monkeypatch):
+    """A capture attempt that raises leaves the plan on the eager path (one warning), with the same results."""
+    from graph_odenet_amd import models, odeint as OI
+    n, d = 400, 16
+    adj = (torch.rand(n, n) < 0.02).float() + torch.eye(n)
+    adj = (adj / adj.sum(1, keepdim=True)).to(dev())
+    x = torch.randn(n, d, device=dev())
+
+    def boom(*a, **k):
+        raise RuntimeError("capture refused (test)")
+    torch.manual_seed(0)
+    blk = models.ODEBlock(models.ODEfunc(d), method="rk4", step_size=0.5).to(dev())
+    ref = blk(x, adj).detach().clone()                       # first call: eager by design
+    monkeypatch.setattr(OI, "_GraphedSolve", boom)
+    with pytest.warns(UserWarning, match="capture of a fixed-grid solve failed"):
+        out = blk(x, adj)
+    assert torch.equal(out, ref)
+    plan = list(blk.odefunc.__dict__["_gode_plans"].values())[0]
+    assert plan.no_capture and plan.gf is None
+    assert torch.equal(blk(x, adj), ref)                     # and no further attempts
