@@ -111,6 +111,13 @@ SIGNATURES = {
                                        c_f, c_f, ctypes.c_int32, c_p]),
     "gode_gcn_ode_rk4_adjoint": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_p, ctypes.POINTER(c_p), ctypes.POINTER(c_p),
                                        ctypes.POINTER(Rk4Workspace), c_f, c_f, ctypes.c_int32, c_p]),
+    "gode_gcn_ode_dopri5_step_forward": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, ctypes.POINTER(c_p), c_p,
+                                               ctypes.POINTER(Rk4Workspace), ctypes.c_double, ctypes.c_double, c_f, c_f,
+                                               c_p, c_p, c_p]),
+    "gode_gcn_ode_dopri5_step_adjoint": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_p, ctypes.POINTER(c_p),
+                                               ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_p,
+                                               ctypes.POINTER(Rk4Workspace), ctypes.c_double, ctypes.c_double, c_f, c_f,
+                                               c_p, c_p, c_p]),
     "gode_prof_create": (c_p, [c_i]),
     "gode_prof_destroy": (None, [c_p]),
     "gode_prof_enable": (None, [c_p]),

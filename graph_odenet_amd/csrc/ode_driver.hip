@@ -222,3 +222,130 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
     *a_result = acur;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// One Dormand-Prince 5(4) step of the same ODE function per C-ABI call (adaptive solves on launch-bound sizes).
+// The controller stays with the caller: it passes the FSAL stage in k[0], gets the 5th-order solution in y1 (and a1 /
+// theta1), the remaining stages in k[1..6] and the squared error-ratio sums of the tensors torchdiffeq's norm treats
+// separately as fp64 device scalars, reads those (its one synchronisation per step) and decides.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+const double DPC[7] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+const double DPA[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
+};
+const double DPB[7] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0};
+const double DPE[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
+                       -2187.0 / 6784 - -12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60.0};
+
+// terms of  y + h * sum_j coef[j] * k[j]  (zero coefficients dropped; first = number of leading k's considered)
+gode_lincomb_t dp_terms(const float* y, float* const* k, const double* coef, int count, double h, bool with_y) {
+    gode_lincomb_t lc;
+    lc.n = 0;
+    if (with_y) { lc.coef[0] = 1.f; lc.ptr[0] = y; lc.n = 1; }
+    for (int j = 0; j < count; ++j)
+        if (coef[j] != 0.0) { lc.coef[lc.n] = (float)(h * coef[j]); lc.ptr[lc.n] = k[j]; ++lc.n; }
+    return lc;
+}
+
+int dp_eval_forward(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws, const gode_lincomb_t* yin, float t,
+                    float* k_out, void* stream) {
+    GODE_TRY(gode_gn_time_gemm_f32(yin, f->n, f->d, f->groups, f->eps, f->gamma, f->beta, f->W, f->d, 1, t, ws->S, stream));
+    gode_spmm_epilogue_t ep = {};
+    ep.bias = f->b; ep.relu = 1; ep.alpha = 1.f;
+    return spmm(f->A, ws->S, k_out, f->d, &ep, stream);
+}
+
+// One evaluation of the augmented adjoint field: k_y = f(t, y), k_a = -a^T df/dy, k_theta = [-a^T df/dW | .. b | .. gamma |
+// .. beta | -a^T df/dt]  (the launch sequence of GcnOdeAdjointField._stage, single stream).
+int dp_eval_adjoint(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws, gode_lincomb_t yin,
+                    const gode_lincomb_t& ain, float t, float* ky, float* ka, float* kth, void* stream) {
+    const int64_t n = f->n, d = f->d, nW = (d + 1) * d, P = gode_gcn_ode_theta_len(d);
+    float* xo = (yin.n >= 3 && ws->X[0]) ? ws->X[0] : nullptr;
+    GODE_TRY(gode_gn_time_gemm_xout_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1, t, ws->S, xo, stream));
+    if (xo) { yin.n = 1; yin.coef[0] = 1.f; yin.ptr[0] = xo; }
+    gode_spmm_epilogue_t ep = {};
+    ep.bias = f->b; ep.relu = 1; ep.alpha = 1.f;
+    ep.cot = ain;
+    for (int j = 0; j < ep.cot.n; ++j) ep.cot.coef[j] = -ep.cot.coef[j];
+    ep.Y2 = ws->dZ;
+    GODE_TRY(spmm(f->A, ws->S, ky, d, &ep, stream));
+    GODE_TRY(spmm(f->AT, ws->dZ, ws->dS, d, nullptr, stream));
+    GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->W, d, 1, ws->dS, 1.f, nullptr, ka,
+                                       f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr, stream));
+    GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, ws->dS, d, 1, ws->wpart, stream));
+    GODE_TRY(gode_reduce_parts_f32(kth, ws->wpart, gode_wgrad_parts(n), nW, 1.f, 0, stream));
+    hipLaunchKernelGGL(theta_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kth, f->W, t, (int)d, P - 1);
+    GODE_LAUNCH_CHECK();
+    GODE_TRY(gode_colsum_f32(kth + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, stream));
+    if (f->groups > 0) {
+        const int64_t gparts = gode_gemm_bwd_parts(n);
+        GODE_TRY(gode_reduce_parts_f32(kth + nW + d, ws->gpart, gparts, d, 1.f, 0, stream));
+        GODE_TRY(gode_reduce_parts_f32(kth + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
+    } else {
+        GODE_HIP(hipMemsetAsync(kth + nW + d, 0, (size_t)2 * d * sizeof(float), (hipStream_t)stream));
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gode_gcn_ode_dopri5_step_forward(const gode_gcn_odefunc_t* f, const float* y, float* const* k, float* y1,
+                                                const gode_rk4_workspace_t* ws, double t, double h, float rtol,
+                                                float atol, double* sums, void* err_scratch, void* stream)
+{
+    if (!f || !y || !k || !y1 || !ws || !sums || !err_scratch) return GODE_E_NULLPTR;
+    if (f->n <= 0 || f->d <= 0) return GODE_E_SHAPE;
+    for (int s = 0; s < 7; ++s) if (!k[s]) return GODE_E_NULLPTR;
+    if (!ws->S) return GODE_E_NULLPTR;
+    const int64_t nd = f->n * f->d;
+    for (int s = 1; s < 7; ++s) {
+        gode_lincomb_t yin = dp_terms(y, k, DPA[s], s, h, true);
+        GODE_TRY(dp_eval_forward(f, ws, &yin, (float)(t + DPC[s] * h), k[s], stream));
+    }
+    gode_lincomb_t sol = dp_terms(y, k, DPB, 7, h, true);
+    GODE_TRY(gode_lincomb_f32(y1, &sol, nd, stream));
+    gode_lincomb_t err = dp_terms(nullptr, k, DPE, 7, h, false);
+    return gode_rk_errnorm_f32(sums, y, y1, &err, rtol, atol, nd, err_scratch, stream);
+}
+
+extern "C" int gode_gcn_ode_dopri5_step_adjoint(const gode_gcn_odefunc_t* f, const float* y, const float* a,
+                                                const float* theta, float* const* ky, float* const* ka,
+                                                float* const* kth, float* y1, float* a1, float* theta1,
+                                                const gode_rk4_workspace_t* ws, double t, double h, float rtol,
+                                                float atol, double* sums /* 4 */, void* err_scratch, void* stream)
+{
+    if (!f || !y || !a || !theta || !ky || !ka || !kth || !y1 || !a1 || !theta1 || !ws || !sums || !err_scratch)
+        return GODE_E_NULLPTR;
+    if (f->n <= 0 || f->d <= 0) return GODE_E_SHAPE;
+    for (int s = 0; s < 7; ++s) if (!ky[s] || !ka[s] || !kth[s]) return GODE_E_NULLPTR;
+    if (!ws->S || !ws->dZ || !ws->dS || !ws->wpart || !ws->colsum_scratch) return GODE_E_NULLPTR;
+    if (f->groups > 0 && (!ws->gpart || !ws->bpart)) return GODE_E_NULLPTR;
+    const int64_t nd = f->n * f->d, P = gode_gcn_ode_theta_len(f->d);
+    for (int s = 1; s < 7; ++s) {
+        gode_lincomb_t yin = dp_terms(y, ky, DPA[s], s, h, true);
+        gode_lincomb_t ain = dp_terms(a, ka, DPA[s], s, h, true);
+        GODE_TRY(dp_eval_adjoint(f, ws, yin, ain, (float)(t + DPC[s] * h), ky[s], ka[s], kth[s], stream));
+    }
+    gode_lincomb_t sy = dp_terms(y, ky, DPB, 7, h, true), sa = dp_terms(a, ka, DPB, 7, h, true),
+                   st = dp_terms(theta, kth, DPB, 7, h, true);
+    GODE_TRY(gode_lincomb_f32(y1, &sy, nd, stream));
+    GODE_TRY(gode_lincomb_f32(a1, &sa, nd, stream));
+    GODE_TRY(gode_lincomb_f32(theta1, &st, P, stream));
+    gode_lincomb_t ey = dp_terms(nullptr, ky, DPE, 7, h, false), ea = dp_terms(nullptr, ka, DPE, 7, h, false),
+                   et = dp_terms(nullptr, kth, DPE, 7, h, false);
+    GODE_TRY(gode_rk_errnorm_f32(sums + 0, y, y1, &ey, rtol, atol, nd, err_scratch, stream));
+    GODE_TRY(gode_rk_errnorm_f32(sums + 1, a, a1, &ea, rtol, atol, nd, err_scratch, stream));
+    // a_t is the last entry of the packed vector, the flattened parameters the P-1 before it
+    gode_lincomb_t et_at = et;
+    for (int j = 0; j < et_at.n; ++j) et_at.ptr[j] = et.ptr[j] + (P - 1);
+    GODE_TRY(gode_rk_errnorm_f32(sums + 2, theta + (P - 1), theta1 + (P - 1), &et_at, rtol, atol, 1, err_scratch, stream));
+    return gode_rk_errnorm_f32(sums + 3, theta, theta1, &et, rtol, atol, P - 1, err_scratch, stream);
+}

@@ -157,6 +157,20 @@ class GcnOdeField(Field):
         ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0], pre_terms=pre[0], alpha=coef)
         return (0,)
 
+    def dopri5_step_native(self, y, kk, y1, t, h, rtol, atol):
+        """One adaptive step in one C call (csrc/ode_driver.hip); returns the error sums as an fp64 device tensor."""
+        lib = _lib.load()
+        s, w = self.s, self.w
+        fs, ws = _func_struct(s), w.workspace_struct(False)
+        kptr = (ctypes.c_void_p * 7)(*[kk[i][0].data_ptr() for i in range(7)])
+        sums = torch.empty(1, dtype=torch.float64, device=y[0].device)
+        sc = ops._scratch(y[0].device, lib.gode_rk_errnorm_scratch_bytes())
+        _lib.check(lib.gode_gcn_ode_dopri5_step_forward(ctypes.byref(fs), _lib.ptr(y[0]), kptr, _lib.ptr(y1[0]),
+                                                        ctypes.byref(ws), float(t), float(h), float(rtol), float(atol),
+                                                        _lib.ptr(sums), _lib.ptr(sc), _lib.stream_ptr()),
+                   "gode_gcn_ode_dopri5_step_forward")
+        return sums
+
 
 class GcnOdeAdjointField(Field):
     """Components: [y, a, a_t, W, b, gamma, beta] (b may be absent -> never, FixedGC always has bias here)."""
@@ -176,8 +190,10 @@ class GcnOdeAdjointField(Field):
         nW = (d + 1) * d
         self.theta = torch.zeros(nW + 3 * d + 1, dtype=torch.float32, device=y_end.device)
         th = self.theta
-        return [y_end.clone(), torch.zeros_like(y_end), th[nW + 3 * d:], th[:nW].view(d + 1, d), th[nW:nW + d],
-                th[nW + d:nW + 2 * d], th[nW + 2 * d:nW + 3 * d]]
+        comps = [y_end.clone(), torch.zeros_like(y_end), th[nW + 3 * d:], th[:nW].view(d + 1, d), th[nW:nW + d],
+                 th[nW + d:nW + 2 * d], th[nW + 2 * d:nW + 3 * d]]
+        comps[2]._gode_packed = th
+        return comps
 
     def rk4_native(self, comps, t0, t1, n_steps):
         lib = _lib.load()
@@ -200,6 +216,40 @@ class GcnOdeAdjointField(Field):
     def param_grads(self, comps):
         m = {"W": comps[3], "b": comps[4], "gamma": comps[5], "beta": comps[6]}
         return [m[k] for k in self.params_order]
+
+    def _packed_like(self, y):
+        """A work copy of the state with the small components as views of ONE packed buffer, as new_state lays it out."""
+        d = self.s.d
+        nW = (d + 1) * d
+        th = torch.empty(nW + 3 * d + 1, dtype=torch.float32, device=y[0].device)
+        comps = [torch.empty_like(y[0]), torch.empty_like(y[1]), th[nW + 3 * d:], th[:nW].view(d + 1, d), th[nW:nW + d],
+                 th[nW + d:nW + 2 * d], th[nW + 2 * d:nW + 3 * d]]
+        comps[2]._gode_packed = th            # keeps the base alive and lets the native step find it
+        return comps
+
+    def alloc_like(self, y, n):
+        return [self._packed_like(y) for _ in range(n)]
+
+    @staticmethod
+    def _theta_of(comps):
+        th = getattr(comps[2], "_gode_packed", None)
+        if th is None:
+            raise RuntimeError("adjoint state is not in the packed layout")
+        return th
+
+    def dopri5_step_native(self, y, kk, y1, t, h, rtol, atol):
+        lib = _lib.load()
+        s, w = self.s, self.w
+        fs, ws = _func_struct(s), w.workspace_struct(True)
+        arr = lambda idx: (ctypes.c_void_p * 7)(*[kk[i][idx].data_ptr() for i in range(7)])      # noqa: E731
+        kth = (ctypes.c_void_p * 7)(*[self._theta_of(kk[i]).data_ptr() for i in range(7)])
+        sums = torch.empty(4, dtype=torch.float64, device=y[0].device)
+        sc = ops._scratch(y[0].device, lib.gode_rk_errnorm_scratch_bytes())
+        _lib.check(lib.gode_gcn_ode_dopri5_step_adjoint(
+            ctypes.byref(fs), _lib.ptr(y[0]), _lib.ptr(y[1]), _lib.ptr(self._theta_of(y)), arr(0), arr(1), kth,
+            _lib.ptr(y1[0]), _lib.ptr(y1[1]), _lib.ptr(self._theta_of(y1)), ctypes.byref(ws), float(t), float(h),
+            float(rtol), float(atol), _lib.ptr(sums), _lib.ptr(sc), _lib.stream_ptr()), "gode_gcn_ode_dopri5_step_adjoint")
+        return sums
 
     def eval(self, t, terms, out):
         self._stage(t, terms, out, None, 0.0)

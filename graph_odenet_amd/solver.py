@@ -118,6 +118,9 @@ def integrate_rk4(field, y, t0, t1, n_steps, work=None):
     return nfe
 
 
+DOPRI5_NATIVE = True      # fused fields: one C-ABI call per adaptive step (False: per-stage Python driver)
+
+
 class Dopri5Stats:
     def __init__(self):
         self.accepted = 0
@@ -167,9 +170,12 @@ def integrate_dopri5(field, y, t0, t1, rtol, atol, stats=None, max_steps=100000)
     nc = len(y)
     sgn = 1.0 if t1 >= t0 else -1.0
     span = abs(t1 - t0)
-    ks = _alloc_like(y, 7)
-    y1 = [torch.empty_like(c) for c in y]
-    tmp = [torch.empty_like(c) for c in y]
+    # a field may lay out the work copies of the state itself (e.g. small components packed in one buffer) and may
+    # offer the whole step as one native call (csrc/ode_driver.hip) when `dopri5_native` is set
+    alloc = getattr(field, "alloc_like", None) or (lambda yy, n: _alloc_like(yy, n))
+    native = getattr(field, "dopri5_step_native", None) if DOPRI5_NATIVE else None
+    ks = alloc(y, 7)
+    y1, tmp = alloc(y, 2)
     field.eval(t0, [[(1.0, y[c])] for c in range(nc)], ks[0])
     stats.nfe += 1
     dt = _initial_step(field, t0, y, ks[0], rtol, atol, sgn, tmp, y1, stats)
@@ -186,16 +192,21 @@ def integrate_dopri5(field, y, t0, t1, rtol, atol, stats=None, max_steps=100000)
         order = [fsal] + [i for i in range(7) if i != fsal]
         kk = [ks[i] for i in order]
         t = t0 + sgn * tau
-        for s in range(1, 7):
-            field.eval(t + DP_C[s] * h, _stage_terms(y, kk, DP_A[s], h), kk[s])
-            stats.nfe += 1
-        for c in range(nc):
-            ops.lincomb_(y1[c], [(1.0, y[c])] + [(h * DP_B[s], kk[s][c]) for s in range(7) if DP_B[s] != 0.0])
-        sums = [ops.rk_error_sumsq(y[c], y1[c], [(h * DP_E[s], kk[s][c]) for s in range(7) if DP_E[s] != 0.0],
-                                   rtol, atol) for c in range(nc)]
-        sums = torch.cat(sums).tolist()          # the one device->host sync of this step
         groups = getattr(field, "ratio_groups", None) or [[c] for c in range(nc)]
-        ratios = [sum(sums[c] for c in grp) / sum(y[c].numel() for c in grp) for grp in groups]
+        if native is not None:
+            gsums = native(y, kk, y1, t, h, rtol, atol).tolist()     # one call, one device->host sync
+            stats.nfe += 6
+            ratios = [gs / sum(y[c].numel() for c in grp) for gs, grp in zip(gsums, groups)]
+        else:
+            for s in range(1, 7):
+                field.eval(t + DP_C[s] * h, _stage_terms(y, kk, DP_A[s], h), kk[s])
+                stats.nfe += 1
+            for c in range(nc):
+                ops.lincomb_(y1[c], [(1.0, y[c])] + [(h * DP_B[s], kk[s][c]) for s in range(7) if DP_B[s] != 0.0])
+            sums = [ops.rk_error_sumsq(y[c], y1[c], [(h * DP_E[s], kk[s][c]) for s in range(7) if DP_E[s] != 0.0],
+                                       rtol, atol) for c in range(nc)]
+            sums = torch.cat(sums).tolist()          # the one device->host sync of this step
+            ratios = [sum(sums[c] for c in grp) / sum(y[c].numel() for c in grp) for grp in groups]
         ratio = max(ratios)
         if all(r <= 1.0 for r in ratios):
             stats.accepted += 1

@@ -305,6 +305,23 @@ int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, float* a, fl
                              float** y_result, float** a_result,
                              const gode_rk4_workspace_t* ws, float t0, float t1, int32_t n_steps, void* stream);
 
+/* One Dormand-Prince 5(4) step of the same ODE function per call (adaptive solves on launch-bound sizes; the controller
+ * - step-size selection, accept / reject, interpolation - stays with the caller, as in torchdiffeq).
+ * forward: k[0] = f(t, y) on entry (FSAL); on return k[1..6] hold the other stages, y1 the 5th-order solution and
+ *   sums[0] = sum_i (err_i / (atol + rtol*max(|y_i|, |y1_i|)))^2 as an fp64 device scalar.
+ * adjoint: the augmented state is (y, a, theta) with theta = [W | b | gamma | beta | a_t] packed
+ *   (gode_gcn_ode_theta_len floats; ktheta stages likewise); h < 0.  sums[0..3] = the same sums for y, a, a_t and the
+ *   flattened parameters (the tensors torchdiffeq's mixed-tolerance norm keeps apart).
+ * ws as for the rk4 driver (S2 / X optional); err_scratch >= gode_rk_errnorm_scratch_bytes(). */
+int gode_gcn_ode_dopri5_step_forward(const gode_gcn_odefunc_t* f, const float* y, float* const* k /* 7 */, float* y1,
+                                     const gode_rk4_workspace_t* ws, double t, double h, float rtol, float atol,
+                                     double* sums, void* err_scratch, void* stream);
+int gode_gcn_ode_dopri5_step_adjoint(const gode_gcn_odefunc_t* f, const float* y, const float* a, const float* theta,
+                                     float* const* ky /* 7 */, float* const* ka /* 7 */, float* const* ktheta /* 7 */,
+                                     float* y1, float* a1, float* theta1, const gode_rk4_workspace_t* ws,
+                                     double t, double h, float rtol, float atol, double* sums /* 4 */,
+                                     void* err_scratch, void* stream);
+
 /* ---- measurement aid (bench.py): HIP-event brackets around the SpMM main kernel ----------
  * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 fast-path launch
  * records a start/stop event pair on its stream (up to `capacity` launches).
