@@ -23,7 +23,7 @@ def _graph_struct(g, d):
     gs = _lib.Graph()
     gs.rowptr, gs.col = g.rowptr.data_ptr(), g.col.data_ptr()
     gs.val = g.val.data_ptr() if g.val is not None else None
-    gs.items, gs.n_items = g.items.data_ptr(), g.n_items
+    gs.items, gs.n_items = (g.items.data_ptr() if g.items is not None else None), g.n_items
     gs.long_rows = g.long_rows.data_ptr() if g.long_rows is not None else None
     gs.n_long = g.n_long
     part = g.partial(d)

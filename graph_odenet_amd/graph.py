@@ -31,7 +31,7 @@ def auto_split(nnz):
 class CSRGraph:
     """CSR of an (n_rows x n_cols) sparse matrix + balanced record list."""
 
-    def __init__(self, rowptr, col, val, n_rows, n_cols, split=DEFAULT_SPLIT):
+    def __init__(self, rowptr, col, val, n_rows, n_cols, split=DEFAULT_SPLIT, records=True):
         self.rowptr = rowptr.to(torch.int32).contiguous()
         self.col = col.to(torch.int32).contiguous()
         self.val = None if val is None else val.to(torch.float32).contiguous()
@@ -40,7 +40,12 @@ class CSRGraph:
         self.nnz = int(self.col.numel())
         self.device = self.col.device
         self.split = int(split) if split is not None else auto_split(self.nnz)
-        self._build_items()
+        if records:
+            self._build_items()
+        else:
+            # no record list: the kernels walk whole rows (one lane group / wave per row).  For matrices that are
+            # rebuilt all the time and have no long rows (a QM9 mini-batch): building the list costs several host syncs.
+            self.items, self.n_items, self.long_rows, self.n_long, self.n_slots = None, self.n_rows, None, 0, 0
         self._partial = {}
         self._T = None
 
@@ -174,8 +179,27 @@ def as_graph(adj, split=DEFAULT_SPLIT):
     return g
 
 
+RECORDS_MIN_NNZ = 1 << 16      # assignment matrices below this size skip the record list (see CSRGraph.__init__)
+
+
+def csr_from_assignment(index, n_rows, vals=None, split=DEFAULT_SPLIT, records=None):
+    """CSR of the (n_rows x E) matrix with exactly one entry per column e, at row index[e] (value vals[e], or
+    pattern-only).  No duplicates are possible, so this is a stable sort plus a count - no `unique`, and no host
+    synchronisation unless the record list is built."""
+    idx = index.to(torch.int64)
+    e = idx.numel()
+    order = torch.argsort(idx, stable=True)                      # edge ids grouped by row, ascending inside a row
+    counts = torch.zeros(n_rows, dtype=torch.int64, device=idx.device).index_add_(
+        0, idx, torch.ones(e, dtype=torch.int64, device=idx.device))
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=idx.device)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    v = None if vals is None else vals.to(torch.float32)[order]
+    if records is None:
+        records = e >= RECORDS_MIN_NNZ
+    return CSRGraph(rowptr, order, v, n_rows, e, split=split, records=records)
+
+
 def incidence_from_index(index, n_rows, split=DEFAULT_SPLIT):
     """N x E incidence with a single 1.0 per column at row index[e] (Mtgt of GAT/utils.py:194-197),
     built directly from the index vector."""
-    e = index.numel()
-    return from_coo(index.to(torch.int64), torch.arange(e, device=index.device), None, n_rows, e, split=split)
+    return csr_from_assignment(index, n_rows, None, split=split)

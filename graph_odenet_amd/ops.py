@@ -274,7 +274,7 @@ def _edge_csr(eg, width):
     gs.rowptr = mt.rowptr.data_ptr()
     gs.col = None if eg.canonical else mt.col.data_ptr()
     gs.val = mt.val.data_ptr() if mt.val is not None else None
-    gs.items, gs.n_items = mt.items.data_ptr(), mt.n_items
+    gs.items, gs.n_items = (mt.items.data_ptr() if mt.items is not None else None), mt.n_items
     gs.long_rows = mt.long_rows.data_ptr() if mt.long_rows is not None else None
     gs.n_long = mt.n_long
     part = mt.partial(width)

@@ -18,30 +18,47 @@ from torch.nn.modules.module import Module
 from torch.nn.parameter import Parameter
 
 from . import ops
-from .graph import as_graph, incidence_from_index
+from .graph import as_graph, csr_from_assignment, incidence_from_index
 
 _cache = {}
 
 
 class _EdgeSet:
+    """(Esrc, Etgt) of one mini-batch, converted once per tensor pair.  In training every step brings a new batch, so
+    the conversion sits on the step's critical path: for the reference's dense Etgt (one entry per edge column) it is
+    a column-wise argmax, two stable sorts and two counts, with a single host synchronisation (the validity check)."""
+
     def __init__(self, Esrc, Etgt):
-        self.Mt = as_graph(Etgt)                          # N x E CSR with values
         self.E = Esrc.numel()
-        self.n = self.Mt.n_rows
-        if self.Mt.n_cols != self.E:
-            raise ValueError("Etgt must be N x E with E = len(Esrc)")
         self.src = Esrc.to(torch.int32).contiguous()
+        if torch.is_tensor(Etgt) and Etgt.layout == torch.strided and Etgt.dim() == 2:
+            self.n = Etgt.shape[0]
+            if Etgt.shape[1] != self.E:
+                raise ValueError("Etgt must be N x E with E = len(Esrc)")
+            nz = Etgt != 0
+            per_col = nz.sum(0)
+            if self.E and int(per_col.max().item()) > 1:
+                raise NotImplementedError("Etgt with more than one entry per edge column is not supported")
+            tgt = nz.to(torch.uint8).argmax(0)                                   # the entry's row (0 for an empty column)
+            val = Etgt.gather(0, tgt.unsqueeze(0)).squeeze(0).to(torch.float32)    # its value (0 for an empty column)
+            self.Mt = csr_from_assignment(tgt, self.n, val)                      # N x E CSR with values
+            self.edge_row = torch.where(per_col > 0, tgt, torch.full_like(tgt, -1)).to(torch.int32)
+            self.edge_val = val.contiguous()
+        else:                                                                    # sparse / CSRGraph input: general path
+            self.Mt = as_graph(Etgt)
+            self.n = self.Mt.n_rows
+            if self.Mt.n_cols != self.E:
+                raise ValueError("Etgt must be N x E with E = len(Esrc)")
+            rp = self.Mt.rowptr.to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(self.n, device=rp.device), rp[1:] - rp[:-1])
+            cols = self.Mt.col.to(torch.int64)
+            if cols.numel() and torch.bincount(cols, minlength=self.E).max().item() > 1:
+                raise NotImplementedError("Etgt with more than one entry per edge column is not supported")
+            self.edge_row = torch.full((self.E,), -1, dtype=torch.int32, device=rp.device)
+            self.edge_row[cols] = rows.to(torch.int32)
+            self.edge_val = torch.zeros(self.E, dtype=torch.float32, device=rp.device)
+            self.edge_val[cols] = self.Mt.val if self.Mt.val is not None else 1.0
         self.Ms_inc = incidence_from_index(self.src, self.n)
-        # per-edge target row / value for the backward kernel (-1: edge not attached to any node)
-        rp = self.Mt.rowptr.to(torch.int64)
-        rows = torch.repeat_interleave(torch.arange(self.n, device=rp.device), rp[1:] - rp[:-1])
-        cols = self.Mt.col.to(torch.int64)
-        if cols.numel() and torch.bincount(cols, minlength=self.E).max().item() > 1:
-            raise NotImplementedError("Etgt with more than one entry per edge column is not supported")
-        self.edge_row = torch.full((self.E,), -1, dtype=torch.int32, device=rp.device)
-        self.edge_row[cols] = rows.to(torch.int32)
-        self.edge_val = torch.zeros(self.E, dtype=torch.float32, device=rp.device)
-        self.edge_val[cols] = self.Mt.val if self.Mt.val is not None else 1.0
 
 
 def _edges(Esrc, Etgt):
