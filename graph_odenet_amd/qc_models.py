@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .functional import GroupNorm
-from .graph import incidence_from_index
+from .graph import RECORDS_MIN_NNZ, CSRGraph, incidence_from_index
 from .qc_layers import EdgeGraphConvolution, MPNN_enn_edge
 
 
@@ -89,21 +89,32 @@ class _Segments:
 
     def __init__(self, batch):
         b64 = batch.to(torch.int64)
-        self.nb = int(b64.max().item()) + 1 if b64.numel() else 0
-        counts = torch.bincount(b64, minlength=self.nb)
+        n = b64.numel()
+        if n:
+            # one host synchronisation for both facts the layout depends on: number of graphs, sortedness
+            unsorted = (b64[1:] < b64[:-1]).any().to(torch.int64) if n > 1 else torch.zeros((), dtype=torch.int64, device=b64.device)
+            mx, uns = torch.stack([b64.max(), unsorted]).tolist()
+            self.nb = int(mx) + 1
+        else:
+            self.nb, uns = 0, 0
+        counts = torch.zeros(self.nb, dtype=torch.int64, device=batch.device).index_add_(
+            0, b64, torch.ones(n, dtype=torch.int64, device=batch.device))
         segptr = torch.zeros(self.nb + 1, dtype=torch.int64, device=batch.device)
         segptr[1:] = torch.cumsum(counts, 0)
         self.segptr = segptr.to(torch.int32)
-        if b64.numel() > 1 and bool((b64[1:] < b64[:-1]).any().item()):
-            self.perm = torch.argsort(b64, stable=True).to(torch.int32)
-        else:
-            self.perm = None
+        self.perm = torch.argsort(b64, stable=True).to(torch.int32) if uns else None
         self.index = b64
         self.incidence = None
 
     def sum_matrix(self):
+        """nb x N membership matrix (pattern-only CSR) for the per-graph sum."""
         if self.incidence is None:
-            self.incidence = incidence_from_index(self.index, self.nb)
+            if self.perm is None:            # sorted batch vector: the rows are the segments themselves
+                n = self.index.numel()
+                self.incidence = CSRGraph(self.segptr, torch.arange(n, device=self.index.device), None, self.nb, n,
+                                          records=n >= RECORDS_MIN_NNZ)
+            else:
+                self.incidence = incidence_from_index(self.index, self.nb)
         return self.incidence
 
 
