@@ -842,7 +842,8 @@ extern "C" int gode_gat_agg_f32_fwd(const gode_graph_t* mt, const int32_t* src, 
     const int64_t n_rows = mt->n_rows;
     if (n_rows < 0 || o <= 0) return GODE_E_SHAPE;
     if (n_rows == 0) return 0;
-    if (!proj || !mt->rowptr || !src || !tgt || !a || !amax || !out || !w_out || !den_out) return GODE_E_NULLPTR;
+    if (!proj || !mt->rowptr || !amax || !out || !den_out) return GODE_E_NULLPTR;
+    if (mt->nnz > 0 && (!src || !tgt || !a || !w_out)) return GODE_E_NULLPTR;        // an edgeless graph has no edge arrays
     if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
     const Proj pv = proj_of(proj);
     int rc = check_proj(pv, o); if (rc) return rc;
@@ -878,7 +879,8 @@ extern "C" int gode_gat_agg_f32_bwd(const gode_graph_t* mt, const int32_t* src, 
     if (did_target_sums) *did_target_sums = 0;
     if (n_rows < 0 || o <= 0) return GODE_E_SHAPE;
     if (n_rows == 0) return 0;
-    if (!proj || !mt->rowptr || !src || !tgt || !w || !den || !out || !dz || !da) return GODE_E_NULLPTR;
+    if (!proj || !mt->rowptr || !den || !out) return GODE_E_NULLPTR;
+    if (mt->nnz > 0 && (!src || !tgt || !w || !dz || !da)) return GODE_E_NULLPTR;
     if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
     const bool use_cot = cot && cot->n > 0;
     if (use_cot) { int rc = check_lincomb(cot, true); if (rc) return rc; }
@@ -949,7 +951,8 @@ extern "C" int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* ei
                                     int64_t ld_a, void* stream) {
     if (n_rows < 0 || o <= 0 || ld_s < o || ld_t < o || ld_a < 1) return GODE_E_SHAPE;
     if (n_rows == 0) return 0;
-    if (!rowptr_src || !eid_src || !rowptr_tgt || !eid_tgt || !dz || !da || !dps || !dpt || !das || !dat) return GODE_E_NULLPTR;
+    // eid_* / dz / da may be NULL for an edgeless graph (every row is empty and nothing is dereferenced)
+    if (!rowptr_src || !rowptr_tgt || !dps || !dpt || !das || !dat) return GODE_E_NULLPTR;
     if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
     const int G = pow2_group((int)o);
     const int maxc = (int)((o + G - 1) / G);

@@ -553,3 +553,19 @@ def test_edge_matvec_large_batch_path_matches_fused_path():
     close(big, ref, 1e-5, "per-edge + SpMM path")
     close(fused, ref, 1e-5, "fused path")
     close(big, fused, 2e-6, "paths agree")
+
+
+def test_gat_ode_block_on_edgeless_graph():
+    """No edges: every aggregation is 0 / eps = 0, so f = 0 and the block is the identity; all gradients are defined."""
+    from graph_odenet_amd import gat_models
+    n, d = 50, 16
+    src = torch.zeros(0, dtype=torch.int64, device=dev())
+    tgt = torch.zeros(0, dtype=torch.int64, device=dev())
+    Mtgt = torch.sparse_coo_tensor(torch.zeros(2, 0, dtype=torch.int64, device=dev()), torch.zeros(0, device=dev()), (n, 0))
+    blk = gat_models.ODEBlock(gat_models.ODEfunc(d), method="rk4", step_size=0.5).to(dev())
+    x = torch.randn(n, d, device=dev(), requires_grad=True)
+    out = blk(x, src, tgt, Mtgt)
+    assert torch.equal(out, x.detach())
+    out.sum().backward()
+    close(x.grad, torch.ones(n, d), 0.0, "identity gradient")
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) == 0.0 for p in blk.parameters())
