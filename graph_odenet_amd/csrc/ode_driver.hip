@@ -198,8 +198,7 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
                                            f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr, stream));   // Gb(g)
         GODE_TRY(gode_colsum_f32(kt + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, stream));
         if (f->groups > 0) {
-            GODE_TRY(gode_reduce_parts_f32(kt + nW + d, ws->gpart, gparts, d, 1.f, 0, stream));
-            GODE_TRY(gode_reduce_parts_f32(kt + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
+            GODE_TRY(gode_reduce_parts2_f32(kt + nW + d, ws->gpart, kt + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
         } else {
             GODE_HIP(hipMemsetAsync(kt + nW + d, 0, (size_t)2 * d * sizeof(float), hs));
         }
@@ -287,8 +286,7 @@ int dp_eval_adjoint(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws,
     GODE_TRY(gode_colsum_f32(kth + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, stream));
     if (f->groups > 0) {
         const int64_t gparts = gode_gemm_bwd_parts(n);
-        GODE_TRY(gode_reduce_parts_f32(kth + nW + d, ws->gpart, gparts, d, 1.f, 0, stream));
-        GODE_TRY(gode_reduce_parts_f32(kth + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
+        GODE_TRY(gode_reduce_parts2_f32(kth + nW + d, ws->gpart, kth + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
     } else {
         GODE_HIP(hipMemsetAsync(kth + nW + d, 0, (size_t)2 * d * sizeof(float), (hipStream_t)stream));
     }

@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256) void final_sum_kernel(double* out, const doubl
 // out[j] (+)= scale * sum_p part[p][j].  Block = 32 outputs x 8 part-groups; group q adds parts
 // q, q+8, ... (coalesced 128-B reads), the 8 group sums are added in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_parts_kernel(float* out, const float* part, int64_t n_part,
-                                                           int64_t len, float scale, int accumulate) {
+                                                           int64_t len, float scale, int accumulate,
+                                                           float* out_b, const float* part_b) {
     __shared__ float sm[8][33];
+    if (blockIdx.y == 1) { out = out_b; part = part_b; }      // second (out, part) pair of the same shape
     const int jj = threadIdx.x & 31, q = threadIdx.x >> 5;
     const int64_t j = (int64_t)blockIdx.x * 32 + jj;
     float s = 0.f;
@@ -267,7 +269,18 @@ extern "C" int gode_reduce_parts_f32(float* out, const float* part, int64_t n_pa
     if (len == 0) return 0;
     if (!out || (n_part > 0 && !part)) return GODE_E_NULLPTR;
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
-                       out, part, n_part, len, scale, accumulate);
+                       out, part, n_part, len, scale, accumulate, (float*)nullptr, (const float*)nullptr);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_reduce_parts2_f32(float* out_a, const float* part_a, float* out_b, const float* part_b,
+                                      int64_t n_part, int64_t len, float scale, int accumulate, void* stream) {
+    if (n_part < 0 || len < 0) return GODE_E_SHAPE;
+    if (len == 0) return 0;
+    if (!out_a || !out_b || (n_part > 0 && (!part_a || !part_b))) return GODE_E_NULLPTR;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((len + 31) / 32), 2), dim3(256), 0, (hipStream_t)stream,
+                       out_a, part_a, n_part, len, scale, accumulate, out_b, part_b);
     GODE_LAUNCH_CHECK();
     return 0;
 }

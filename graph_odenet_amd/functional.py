@@ -38,8 +38,7 @@ class _GnTimeLinearFn(torch.autograd.Function):
         if ctx.has_affine and dgp is not None:
             gg = torch.empty_like(gamma)
             gb = torch.empty_like(beta)
-            ops.reduce_parts_(gg, dgp)
-            ops.reduce_parts_(gb, dbp)
+            ops.reduce_parts2_(gg, dgp, gb, dbp)
         return dx, None, gW, gg, gb, None, None, None
 
 
@@ -90,8 +89,7 @@ class _GroupNorm2dFn(torch.autograd.Function):
         if gamma is not None:
             gg = torch.empty_like(gamma)
             gb = torch.empty_like(gamma)
-            ops.reduce_parts_(gg, dgp)
-            ops.reduce_parts_(gb, dbp)
+            ops.reduce_parts2_(gg, dgp, gb, dbp)
         return dx, gg, gb, None, None
 
 

@@ -164,8 +164,7 @@ class GatOdeAdjointField(GatOdeField):
                                  pre_terms=[(1.0, out[1])] if j else None,
                                  parts=(w.gp[j * nb:(j + 1) * nb], w.bp[j * nb:(j + 1) * nb]) if affine else None)
         if affine:
-            ops.reduce_parts_(g["gamma"], w.gp)
-            ops.reduce_parts_(g["beta"], w.bp)
+            ops.reduce_parts2_(g["gamma"], w.gp, g["beta"], w.bp)
         else:
             g["gamma"].zero_(); g["beta"].zero_()
         for j, (name, Wj, dPj) in enumerate((("Wsrc", s.Wsrc, w.dPs), ("Wtgt", s.Wtgt, w.dPt), ("Wlog", s.Wlog, w.dA2))):

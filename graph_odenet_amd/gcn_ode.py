@@ -280,8 +280,7 @@ class GcnOdeAdjointField(Field):
         out[3][0].mul_(t)                                               # dW[0,:] = t * colsum(dS)
         ops.colsum_(out[4], dZ)
         if dgp is not None:
-            ops.reduce_parts_(out[5], dgp)
-            ops.reduce_parts_(out[6], dbp)
+            ops.reduce_parts2_(out[5], dgp, out[6], dbp)
         else:
             out[5].zero_(); out[6].zero_()
 
@@ -316,8 +315,7 @@ class _OdeFuncFn(torch.autograd.Function):
         gg = torch.zeros_like(gamma)
         gbe = torch.zeros_like(beta)
         if dgp is not None:
-            ops.reduce_parts_(gg, dgp)
-            ops.reduce_parts_(gbe, dbp)
+            ops.reduce_parts2_(gg, dgp, gbe, dbp)
         return None, None, dx, gW, gb, gg, gbe
 
 

@@ -232,6 +232,18 @@ def reduce_parts_(out, part, scale=1.0, accumulate=False):
     return out
 
 
+def reduce_parts2_(out_a, part_a, out_b, part_b):
+    """Two reductions of equal shape in one launch: out_a = part_a.sum(0), out_b = part_b.sum(0)."""
+    lib = _lib.load()
+    for t, nm in ((out_a, "out_a"), (part_a, "part_a"), (out_b, "out_b"), (part_b, "part_b")):
+        _need(t, nm)
+    n_part = part_a.shape[0]
+    if part_b.shape != part_a.shape or out_b.numel() != out_a.numel() or part_a.numel() != n_part * out_a.numel():
+        raise ValueError("reduce_parts2: size mismatch")
+    check(lib.gode_reduce_parts2_f32(ptr(out_a), ptr(part_a), ptr(out_b), ptr(part_b), n_part, out_a.numel(), 1.0, 0,
+                                     stream_ptr()), "gode_reduce_parts2_f32")
+
+
 def colsum_(out, X, scale=1.0, accumulate=False):
     """out (+)= scale * X.sum(0)."""
     lib = _lib.load()

@@ -168,6 +168,9 @@ int gode_wgrad_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t
 /* out[j] (+)= scale * sum_p part[p*len + j]   (accumulate != 0 adds to out) */
 int gode_reduce_parts_f32(float* out, const float* part, int64_t n_part, int64_t len,
                           float scale, int accumulate, void* stream);
+/* the same for two (out, part) pairs of equal shape in one launch (e.g. dgamma and dbeta) */
+int gode_reduce_parts2_f32(float* out_a, const float* part_a, float* out_b, const float* part_b,
+                           int64_t n_part, int64_t len, float scale, int accumulate, void* stream);
 
 /* column sums: out[c] (+)= scale * sum_i X[i,c]  (bias gradient) */
 int gode_colsum_f32(float* out, const float* X, int64_t n_rows, int64_t d, float scale,
