@@ -220,6 +220,7 @@ def main():
                 "kernel": "spmm_vec4_kernel<%d>" % (args.hidden // 4), "launches_timed": len(sel),
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(tot_bytes / len(sel)),
                 "algorithmic_bytes_plain_product": b_alg, "compulsory_bytes_plain_product": b_min,
+                "frac_plain_product": round(b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "epilogue_operand_arrays_per_launch": round(sum(xx[i] for i in sel) / len(sel), 3)}
 
     extras = None
