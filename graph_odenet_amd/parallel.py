@@ -26,36 +26,40 @@ def broadcast_parameters(module, src=0):
 
 
 class GradBucket:
-    """Persistent flat buffer so that the all-reduce is a single collective per step."""
+    """Persistent flat buffer so that the all-reduce is a single collective per step.  The parameters' `.grad`
+    tensors are made VIEWS of the buffer (autograd accumulates into an existing `.grad` in place), so no gradient is
+    copied in or out around the collective as long as the optimiser keeps them (`zero_grad(set_to_none=False)`);
+    a gradient that was dropped or replaced in the meantime is copied in and re-attached."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = []
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            v = self.flat[o:o + k].view_as(p)
+            if p.grad is not None:
+                v.copy_(p.grad)
+            p.grad = v
+            self.views.append(v)
+            o += k
 
     def allreduce_mean(self):
         """grad <- mean over ranks.  Parameters without a gradient on this rank count as zero."""
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return
-        o = 0
-        for p in self.params:
-            n = p.numel()
+        for p, v in zip(self.params, self.views):
             if p.grad is None:
-                self.flat[o:o + n].zero_()
-            else:
-                self.flat[o:o + n].copy_(p.grad.reshape(-1))
-            o += n
+                v.zero_()
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+                p.grad = v
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())
-        o = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[o:o + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[o:o + n].view_as(p))
-            o += n
 
 
 def shard_range(n_items, rank, world):

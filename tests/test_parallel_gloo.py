@@ -28,10 +28,11 @@ def _worker(rank, world, port, q):
     y = torch.randn(16, 3, generator=torch.Generator().manual_seed(50 + rank))
     bucket = GradBucket(m)
     opt = torch.optim.Adam(m.parameters(), lr=0.01)
-    for _ in range(3):
-        opt.zero_grad()
+    for it in range(3):
+        opt.zero_grad(set_to_none=(it == 1))            # step 1 drops the gradients: the bucket re-attaches its views
         ((m(x) - y) ** 2).mean().backward()
         bucket.allreduce_mean()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
         opt.step()
     q.put((rank, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).tolist()))
     dist.destroy_process_group()
