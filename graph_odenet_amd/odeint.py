@@ -9,6 +9,8 @@ GCN/models.py:5,192, GAT/models.py:5,192 in the reference):
 and stage inputs are never materialised; any other module runs through autograd with the
 RK arithmetic still in the HIP kernels.
 """
+import weakref
+
 import torch
 
 from . import ops
@@ -145,6 +147,18 @@ class _Plan:
         self.no_capture = False          # set when a capture attempt failed: the plan stays on the eager path
 
 
+_PLANS = weakref.WeakKeyDictionary()      # func module -> {key: _Plan}; kept off the module so that deepcopy / pickling
+                                          # of a model never meets a HIP graph
+
+
+def plans_of(func):
+    """The captured-solve plans of an ODE function module (created on first use)."""
+    plans = _PLANS.get(func)
+    if plans is None:
+        plans = _PLANS[func] = {}
+    return plans
+
+
 def _try_capture(plan, field, comps, t0, t1):
     """A captured solve, or None (and the plan switched to the eager path for good) when the capture fails."""
     try:
@@ -170,7 +184,7 @@ def _plan_for(func, y0, tl, method, options, params):
         return None, _fields(func, y0)
     n = uniform_grid(tl[0], tl[1], (options or {}).get("step_size"))
     key = (tuple(y0.shape), y0.device.index, tl[0], tl[1], n, token, tuple(p.data_ptr() for p in params), NATIVE_RK4)
-    plans = func.__dict__.setdefault("_gode_plans", {})
+    plans = plans_of(func)
     plan = plans.get(key)
     if plan is None:
         fields = _fields(func, y0)

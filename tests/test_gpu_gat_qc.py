@@ -408,7 +408,7 @@ def test_gat_hip_graph_captured_solves_match_eager(golden):
                 opt.step()
             res[capture] = (log, blk.nfe)
             if capture:
-                plans = list(blk.odefunc.__dict__["_gode_plans"].values())
+                plans = list(OI.plans_of(blk.odefunc).values())
                 assert len(plans) == 1 and plans[0].gf is not None and plans[0].gb is not None
         finally:
             OI.GRAPH_CAPTURE_MAX_ELEMS = old

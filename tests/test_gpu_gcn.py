@@ -426,7 +426,7 @@ def test_hip_graph_captured_solves_match_eager(native, d):
                 opt.step()
             res[capture] = (log, blk.nfe)
             if capture:
-                plans = list(blk.odefunc.__dict__["_gode_plans"].values())
+                plans = list(OI.plans_of(blk.odefunc).values())
                 assert len(plans) == 1 and plans[0].gf is not None and plans[0].gb is not None
         finally:
             OI.NATIVE_RK4 = True
@@ -487,7 +487,7 @@ def test_failed_graph_capture_falls_back_to_eager(monkeypatch):
     with pytest.warns(UserWarning, match="capture of a fixed-grid solve failed"):
         out = blk(x, adj)
     assert torch.equal(out, ref)
-    plan = list(blk.odefunc.__dict__["_gode_plans"].values())[0]
+    plan = list(OI.plans_of(blk.odefunc).values())[0]
     assert plan.no_capture and plan.gf is None
     assert torch.equal(blk(x, adj), ref)                     # and no further attempts
 
@@ -550,3 +550,22 @@ def test_square_graph_convolution_on_mfma_kernels(d):
     close(xd.grad, x.grad, 2e-5, "gx")
     close(lay.weight.grad, W.grad, 2e-5, "gW")
     close(lay.bias.grad, b.grad, 2e-5, "gb")
+
+
+def test_model_with_captured_solves_can_be_deep_copied_and_pickled():
+    import copy
+    import io
+    from graph_odenet_amd import models
+    n, d = 300, 16
+    adj = (torch.rand(n, n) < 0.03).float() + torch.eye(n)
+    adj = (adj / adj.sum(1, keepdim=True)).to(dev())
+    x = torch.randn(n, d, device=dev())
+    blk = models.ODEBlock(models.ODEfunc(d), method="rk4", step_size=0.5).to(dev())
+    ref = [blk(x, adj).detach().clone() for _ in range(3)][-1]        # third call replays a captured graph
+    twin = copy.deepcopy(blk)
+    assert torch.equal(twin(x, adj), ref)
+    buf = io.BytesIO()
+    torch.save(blk, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    assert torch.equal(again(x, adj), ref)
