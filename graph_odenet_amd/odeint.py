@@ -183,7 +183,10 @@ def _plan_for(func, y0, tl, method, options, params):
     if token is None:
         return None, _fields(func, y0)
     n = uniform_grid(tl[0], tl[1], (options or {}).get("step_size"))
-    key = (tuple(y0.shape), y0.device.index, tl[0], tl[1], n, token, tuple(p.data_ptr() for p in params), NATIVE_RK4)
+    # the hook's identity is part of the key: a func whose gode_fields was swapped (e.g. to force the autograd path)
+    # must not be served the fused fields of an earlier plan
+    key = (tuple(y0.shape), y0.device.index, tl[0], tl[1], n, token, tuple(p.data_ptr() for p in params), NATIVE_RK4,
+           id(getattr(func, "gode_fields", None).__func__) if hasattr(getattr(func, "gode_fields", None), "__func__") else None)
     plans = plans_of(func)
     plan = plans.get(key)
     if plan is None:
