@@ -56,6 +56,22 @@ class Rk4Workspace(ctypes.Structure):
                 ("colsum_scratch", ctypes.c_void_p), ("X", ctypes.c_void_p * 2)]
 
 
+class GatOdeFunc(ctypes.Structure):
+    """Mirror of gode_gat_odefunc_t."""
+    _fields_ = [("mt", Graph), ("ms_inc", Graph), ("mt_inc", Graph), ("src", ctypes.c_void_p), ("tgt", ctypes.c_void_p),
+                ("n_edges", ctypes.c_int64), ("n", ctypes.c_int64), ("d", ctypes.c_int64), ("groups", ctypes.c_int32),
+                ("eps_gn", ctypes.c_float), ("eps", ctypes.c_float), ("Wsrc", ctypes.c_void_p), ("Wtgt", ctypes.c_void_p),
+                ("Wlog", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("bw", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
+                ("beta", ctypes.c_void_p)]
+
+
+class GatWorkspace(ctypes.Structure):
+    """Mirror of gode_gat_workspace_t."""
+    _fields_ = [(k, ctypes.c_void_p) for k in ("X", "Ps", "Pt", "A2", "a", "amax", "wgt", "den", "logits_scratch", "dz", "da",
+                                               "dPs", "dPt", "dA2", "pair", "gp", "bp")] + \
+               [("wp", ctypes.c_void_p * 3), ("maxpath_scratch", ctypes.c_void_p), ("colsum_scratch", ctypes.c_void_p)]
+
+
 c_i64 = ctypes.c_int64
 c_p = ctypes.c_void_p
 c_f = ctypes.c_float
@@ -119,6 +135,14 @@ SIGNATURES = {
                                                ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_p,
                                                ctypes.POINTER(Rk4Workspace), ctypes.c_double, ctypes.c_double, c_f, c_f,
                                                c_p, c_p, c_p]),
+    "gode_gat_ode_theta_len": (c_i64, [c_i64]),
+    "gode_gat_ode_dopri5_step_forward": (c_i, [ctypes.POINTER(GatOdeFunc), c_p, ctypes.POINTER(c_p), c_p,
+                                               ctypes.POINTER(GatWorkspace), ctypes.c_double, ctypes.c_double, c_f, c_f,
+                                               c_p, c_p, c_p]),
+    "gode_gat_ode_dopri5_step_adjoint": (c_i, [ctypes.POINTER(GatOdeFunc), c_p, c_p, c_p, c_p, ctypes.POINTER(c_p),
+                                               ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_p,
+                                               c_p, ctypes.POINTER(GatWorkspace), ctypes.c_double, ctypes.c_double, c_f,
+                                               c_f, c_p, c_p, c_p]),
     "gode_prof_create": (c_p, [c_i]),
     "gode_prof_destroy": (None, [c_p]),
     "gode_prof_enable": (None, [c_p]),

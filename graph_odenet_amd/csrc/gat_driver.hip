@@ -1,0 +1,179 @@
+// gat_driver.hip — one Dormand-Prince 5(4) step of the GAT ODE function per C-ABI call.
+//
+// f(t, x) = relu(EdgeAttention([t | GroupNorm(x)]))  (reference: GAT/models.py:172-179 -> GAT/layers.py:95-122).
+// The adaptive controller (step-size choice, accept / reject, interpolation) stays with the caller, as for the GCN
+// function in ode_driver.hip; this file only sequences the launches of six stage evaluations, the solution combine
+// and the error-ratio sums, so that an adaptive step on a citation-size graph is one call instead of ~200.
+// The launch sequence of one evaluation is graph_odenet_amd/gat_ode.py (GatOdeField / GatOdeAdjointField).
+#include "common.h"
+
+namespace {
+
+#define GODE_TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+#define GODE_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+const double DPC[7] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+const double DPA[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
+};
+const double DPB[7] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84, 0};
+const double DPE[7] = {35.0 / 384 - 1951.0 / 21600, 0, 500.0 / 1113 - 22642.0 / 50085, 125.0 / 192 - 451.0 / 720,
+                       -2187.0 / 6784 - -12231.0 / 42400, 11.0 / 84 - 649.0 / 6300, -1.0 / 60.0};
+
+gode_lincomb_t dp_terms(const float* y, float* const* k, const double* coef, int count, double h, bool with_y, int64_t off = 0) {
+    gode_lincomb_t lc;
+    lc.n = 0;
+    if (with_y) { lc.coef[0] = 1.f; lc.ptr[0] = y + off; lc.n = 1; }
+    for (int j = 0; j < count; ++j)
+        if (coef[j] != 0.0) { lc.coef[lc.n] = (float)(h * coef[j]); lc.ptr[lc.n] = k[j] + off; ++lc.n; }
+    return lc;
+}
+
+gode_gat_proj_t proj_of(const gode_gat_workspace_t* w, int64_t d) {
+    gode_gat_proj_t p;
+    p.ps = w->Ps; p.ld_s = d; p.pt = w->Pt; p.ld_t = d; p.as = w->A2; p.at = w->A2 + 1; p.ld_a = 2;
+    return p;
+}
+
+// Ps, Pt, A2 of the stage input; a multi-term input is combined once (x_out) and read back as one array afterwards
+int project(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lincomb_t* yin, float t, void* stream) {
+    const int64_t n = f->n, d = f->d;
+    float* xo = yin->n > 1 ? w->X : nullptr;
+    GODE_TRY(gode_gn_time_gemm_xout_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, d, 1, t, w->Ps, xo, stream));
+    if (xo) { yin->n = 1; yin->coef[0] = 1.f; yin->ptr[0] = xo; }
+    GODE_TRY(gode_gn_time_gemm_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wtgt, d, 1, t, w->Pt, stream));
+    return gode_gn_time_gemm_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wlog, 2, 1, t, w->A2, stream);
+}
+
+int eval_forward(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lincomb_t* yin, float t, float* ky,
+                 void* stream) {
+    GODE_TRY(project(f, w, yin, t, stream));
+    const gode_gat_proj_t pr = proj_of(w, f->d);
+    GODE_TRY(gode_gat_logits_f32(&pr, f->bw, f->src, f->tgt, f->n_edges, w->a, w->amax, (float*)w->logits_scratch, stream));
+    return gode_gat_agg_f32_fwd(&f->mt, f->src, f->tgt, &pr, f->d, f->bf, w->a, w->amax, f->eps, ky, w->wgt, w->den, stream);
+}
+
+// theta-k layout: [Wsrc ((d+1)*d) | Wtgt ((d+1)*d) | Wlog ((d+1)*2) | bf (d) | bw (1) | gamma (d) | beta (d)]
+int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lincomb_t yin, const gode_lincomb_t& ain,
+                 float t, float* ky, float* ka, float* kat, float* kth, void* stream) {
+    const int64_t n = f->n, d = f->d, nW = (d + 1) * d, nL = (d + 1) * 2;
+    GODE_TRY(eval_forward(f, w, &yin, t, ky, stream));                  // yin now names the combined input
+    const gode_gat_proj_t pr = proj_of(w, d);
+    int32_t did = 0;
+    GODE_TRY(gode_gat_agg_f32_bwd(&f->mt, f->src, f->tgt, &pr, d, f->bf, w->wgt, w->den, ky, nullptr, &ain, -1.f, w->dz,
+                                  w->da, w->dPt, d, w->dA2 + 1, 2, &did, stream));
+    if (f->n_edges > 0)
+        GODE_TRY(gode_gat_maxpath_f32(w->a, w->amax, w->da, f->n_edges, did ? f->tgt : nullptr, did ? w->dA2 + 1 : nullptr, 2,
+                                      w->maxpath_scratch, stream));
+    if (did) {
+        GODE_TRY(gode_spmm_csr_f32(f->ms_inc.rowptr, f->ms_inc.col, nullptr, f->ms_inc.items, f->ms_inc.n_items,
+                                   f->ms_inc.long_rows, f->ms_inc.n_long, f->ms_inc.partial, w->dz, d, w->dPs, d, n, d,
+                                   nullptr, stream));
+        GODE_TRY(gode_spmm_csr_f32(f->ms_inc.rowptr, f->ms_inc.col, nullptr, f->ms_inc.items, f->ms_inc.n_items,
+                                   f->ms_inc.long_rows, f->ms_inc.n_long, f->ms_inc.partial, w->da, 1, w->dA2, 2, n, 1,
+                                   nullptr, stream));
+    } else {
+        GODE_TRY(gode_gat_scatter_f32(f->ms_inc.rowptr, f->ms_inc.col, f->mt_inc.rowptr, f->mt_inc.col, w->dz, w->da, d, n,
+                                      w->dPs, d, w->dPt, d, w->dA2, w->dA2 + 1, 2, stream));
+    }
+    float* g_src = kth; float* g_tgt = kth + nW; float* g_log = kth + 2 * nW;
+    float* g_bf = g_log + nL; float* g_bw = g_bf + d; float* g_gamma = g_bw + 1; float* g_beta = g_gamma + d;
+    // bias gradients from the per-target node sums (every edge has exactly one target)
+    GODE_TRY(gode_colsum_f32(g_bf, w->dPt, n, d, 1.f, 0, (float*)w->colsum_scratch, stream));
+    GODE_TRY(gode_colsum_f32(w->pair, w->dA2, n, 2, 1.f, 0, (float*)w->colsum_scratch, stream));
+    { gode_lincomb_t one; one.n = 1; one.coef[0] = 1.f; one.ptr[0] = w->pair + 1; GODE_TRY(gode_lincomb_f32(g_bw, &one, 1, stream)); }
+    const int64_t nb = gode_gemm_bwd_parts(n);
+    const bool affine = f->groups > 0;
+    const float* Wj[3] = {f->Wsrc, f->Wtgt, f->Wlog};
+    const float* dPj[3] = {w->dPs, w->dPt, w->dA2};
+    const int64_t dout[3] = {d, d, 2};
+    gode_lincomb_t acc; acc.n = 1; acc.coef[0] = 1.f; acc.ptr[0] = ka;
+    for (int j = 0; j < 3; ++j)
+        GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, Wj[j], dout[j], 1, dPj[j], 1.f,
+                                           j ? &acc : nullptr, ka, affine ? w->gp + j * nb * d : nullptr,
+                                           affine ? w->bp + j * nb * d : nullptr, stream));
+    if (affine) GODE_TRY(gode_reduce_parts2_f32(g_gamma, w->gp, g_beta, w->bp, 3 * nb, d, 1.f, 0, stream));
+    else GODE_HIP(hipMemsetAsync(g_gamma, 0, (size_t)2 * d * sizeof(float), (hipStream_t)stream));
+    float* gW[3] = {g_src, g_tgt, g_log};
+    const int64_t lenW[3] = {nW, nW, nL};
+    const int64_t npw = gode_wgrad_parts(n);
+    for (int j = 0; j < 3; ++j) {
+        GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, dPj[j], dout[j], 1, w->wp[j], stream));
+        GODE_TRY(gode_reduce_parts_f32(gW[j], w->wp[j], npw, lenW[j], 1.f, 0, stream));
+        GODE_TRY(gode_time_row_fixup_f32(gW[j], Wj[j], dout[j], t, kat, j > 0, stream));     // a_t' = -a^T df/dt ; row 0 *= t
+    }
+    return 0;
+}
+
+int check_common(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, bool adjoint) {
+    if (!f || !w) return GODE_E_NULLPTR;
+    if (f->n <= 0 || f->d <= 0 || f->n_edges < 0) return GODE_E_SHAPE;
+    if (!f->Wsrc || !f->Wtgt || !f->Wlog || !f->bf || !f->bw || !f->mt.rowptr) return GODE_E_NULLPTR;
+    if (!w->X || !w->Ps || !w->Pt || !w->A2 || !w->amax || !w->den || !w->logits_scratch) return GODE_E_NULLPTR;
+    if (f->n_edges > 0 && (!f->src || !f->tgt || !w->a || !w->wgt)) return GODE_E_NULLPTR;
+    if (adjoint) {
+        if (!w->dPs || !w->dPt || !w->dA2 || !w->pair || !w->colsum_scratch || !w->maxpath_scratch || !w->wp[0] || !w->wp[1] ||
+            !w->wp[2] || !f->ms_inc.rowptr || !f->mt_inc.rowptr) return GODE_E_NULLPTR;
+        if (f->n_edges > 0 && (!w->dz || !w->da)) return GODE_E_NULLPTR;
+        if (f->groups > 0 && (!w->gp || !w->bp)) return GODE_E_NULLPTR;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t gode_gat_ode_theta_len(int64_t d) { return 2 * (d + 1) * d + (d + 1) * 2 + d + 1 + 2 * d; }
+
+extern "C" int gode_gat_ode_dopri5_step_forward(const gode_gat_odefunc_t* f, const float* y, float* const* k, float* y1,
+                                                const gode_gat_workspace_t* w, double t, double h, float rtol, float atol,
+                                                double* sums, void* err_scratch, void* stream)
+{
+    int rc = check_common(f, w, false); if (rc) return rc;
+    if (!y || !k || !y1 || !sums || !err_scratch) return GODE_E_NULLPTR;
+    for (int s = 0; s < 7; ++s) if (!k[s]) return GODE_E_NULLPTR;
+    const int64_t nd = f->n * f->d;
+    for (int s = 1; s < 7; ++s) {
+        gode_lincomb_t yin = dp_terms(y, k, DPA[s], s, h, true);
+        GODE_TRY(eval_forward(f, w, &yin, (float)(t + DPC[s] * h), k[s], stream));
+    }
+    gode_lincomb_t sol = dp_terms(y, k, DPB, 7, h, true);
+    GODE_TRY(gode_lincomb_f32(y1, &sol, nd, stream));
+    gode_lincomb_t err = dp_terms(nullptr, k, DPE, 7, h, false);
+    return gode_rk_errnorm_f32(sums, y, y1, &err, rtol, atol, nd, err_scratch, stream);
+}
+
+extern "C" int gode_gat_ode_dopri5_step_adjoint(const gode_gat_odefunc_t* f, const float* y, const float* a,
+                                                const float* a_t, const float* theta, float* const* ky, float* const* ka,
+                                                float* const* kat, float* const* kth, float* y1, float* a1, float* a_t1,
+                                                float* theta1, const gode_gat_workspace_t* w, double t, double h,
+                                                float rtol, float atol, double* sums /* 4 */, void* err_scratch,
+                                                void* stream)
+{
+    int rc = check_common(f, w, true); if (rc) return rc;
+    if (!y || !a || !a_t || !theta || !ky || !ka || !kat || !kth || !y1 || !a1 || !a_t1 || !theta1 || !sums || !err_scratch)
+        return GODE_E_NULLPTR;
+    for (int s = 0; s < 7; ++s) if (!ky[s] || !ka[s] || !kat[s] || !kth[s]) return GODE_E_NULLPTR;
+    const int64_t nd = f->n * f->d, P = gode_gat_ode_theta_len(f->d);
+    for (int s = 1; s < 7; ++s) {
+        gode_lincomb_t yin = dp_terms(y, ky, DPA[s], s, h, true);
+        gode_lincomb_t ain = dp_terms(a, ka, DPA[s], s, h, true);
+        GODE_TRY(eval_adjoint(f, w, yin, ain, (float)(t + DPC[s] * h), ky[s], ka[s], kat[s], kth[s], stream));
+    }
+    struct Part { const float* y0; float* const* k; float* y1; int64_t len; };
+    const Part parts[4] = {{y, ky, y1, nd}, {a, ka, a1, nd}, {a_t, kat, a_t1, 1}, {theta, kth, theta1, P}};
+    for (int c = 0; c < 4; ++c) {
+        gode_lincomb_t sol = dp_terms(parts[c].y0, parts[c].k, DPB, 7, h, true);
+        GODE_TRY(gode_lincomb_f32(parts[c].y1, &sol, parts[c].len, stream));
+    }
+    for (int c = 0; c < 4; ++c) {
+        gode_lincomb_t err = dp_terms(nullptr, parts[c].k, DPE, 7, h, false);
+        GODE_TRY(gode_rk_errnorm_f32(sums + c, parts[c].y0, parts[c].y1, &err, rtol, atol, parts[c].len, err_scratch, stream));
+    }
+    return 0;
+}

@@ -19,6 +19,8 @@ The adjoint integrates [y, a, a_t, theta] with theta = [Wsrc | Wtgt | Wlog | bf 
 buffer (one RK combine launch for all parameters); the gradient is converted back to the parameters' layout once,
 at the end of the solve.
 """
+import ctypes
+
 import torch
 
 from . import _lib, ops
@@ -87,6 +89,12 @@ class _Work:
         self.gp, self.bp = torch.empty(3 * self.np_b, o, **f), torch.empty(3 * self.np_b, o, **f)
         npw = lib.gode_wgrad_parts(n)
         self.wp = [torch.empty(npw, spec.i * o, **f), torch.empty(npw, spec.i * o, **f), torch.empty(npw, spec.i * 2, **f)]
+        # extras of the C-level dopri5 step (csrc/gat_driver.hip)
+        self.pair = torch.empty(2, **f)
+        u8 = dict(dtype=torch.uint8, device=device)
+        self.logits_scratch = torch.empty(max(lib.gode_gat_logits_scratch_bytes(E), 16), **u8)
+        self.colsum_scratch = torch.empty(max(lib.gode_colsum_scratch_bytes(n, o), 16), **u8)
+        self.err_scratch = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), **u8)
 
 
 class GatOdeField(Field):
@@ -99,6 +107,48 @@ class GatOdeField(Field):
 
     def prepare(self):
         self.s.refresh()
+
+    # ---- one adaptive step per C call (csrc/gat_driver.hip) -------------------------------------------------------
+    def _structs(self, adjoint):
+        s, w, eg = self.s, self.w, self.s.eg
+        fs = _lib.GatOdeFunc()
+        fs.mt = ops._edge_csr(eg, s.d + 4)
+        for name, gph in (("ms_inc", eg.Ms_inc), ("mt_inc", eg.Mt_inc)):
+            gs = _lib.Graph()
+            gs.rowptr, gs.col, gs.val = gph.rowptr.data_ptr(), gph.col.data_ptr(), None
+            gs.items, gs.n_items = (gph.items.data_ptr() if gph.items is not None else None), gph.n_items
+            gs.long_rows = gph.long_rows.data_ptr() if gph.long_rows is not None else None
+            gs.n_long = gph.n_long
+            part = gph.partial(s.d) if adjoint else None
+            gs.partial = part.data_ptr() if part is not None else None
+            gs.n_rows, gs.nnz = gph.n_rows, gph.nnz
+            setattr(fs, name, gs)
+        p = lambda t: (t.data_ptr() or None) if t is not None else None      # noqa: E731  (struct fields take ints)
+        fs.src, fs.tgt, fs.n_edges = p(eg.src), p(eg.tgt), eg.E
+        fs.n, fs.d, fs.groups, fs.eps_gn, fs.eps = s.n, s.d, s.groups, s.eps_gn, s.eps
+        fs.Wsrc, fs.Wtgt, fs.Wlog = s.Wsrc.data_ptr(), s.Wtgt.data_ptr(), s.Wlog.data_ptr()
+        fs.bf, fs.bw, fs.gamma, fs.beta = s.bf.data_ptr(), s.bw.data_ptr(), s.gamma.data_ptr(), s.beta.data_ptr()
+        ws = _lib.GatWorkspace()
+        for k in ("X", "Ps", "Pt", "A2", "a", "amax", "wgt", "den", "logits_scratch"):
+            setattr(ws, k, p(getattr(w, k)))
+        if adjoint:
+            for k in ("dz", "da", "dPs", "dPt", "dA2", "pair", "gp", "bp", "colsum_scratch"):
+                setattr(ws, k, p(getattr(w, k)))
+            for j in range(3):
+                ws.wp[j] = w.wp[j].data_ptr()
+            ws.maxpath_scratch = p(eg.maxpath_scratch())
+        return fs, ws
+
+    def dopri5_step_native(self, y, kk, y1, t, h, rtol, atol):
+        lib = _lib.load()
+        fs, ws = self._structs(False)
+        kptr = (ctypes.c_void_p * 7)(*[kk[i][0].data_ptr() for i in range(7)])
+        sums = torch.empty(1, dtype=torch.float64, device=y[0].device)
+        _lib.check(lib.gode_gat_ode_dopri5_step_forward(ctypes.byref(fs), _lib.ptr(y[0]), kptr, _lib.ptr(y1[0]), ctypes.byref(ws),
+                                                        float(t), float(h), float(rtol), float(atol), _lib.ptr(sums),
+                                                        _lib.ptr(self.w.err_scratch), _lib.stream_ptr()),
+                   "gode_gat_ode_dopri5_step_forward")
+        return sums
 
     def _project(self, t, y_terms):
         """Ps, Pt, A2 of the stage input; returns the term list later launches of the stage should read."""
@@ -144,6 +194,18 @@ class GatOdeAdjointField(GatOdeField):
         m = {"gamma": v["gamma"].clone(), "beta": v["beta"].clone(), "Wf": gWf, "bf": v["bf"].clone(),
              "ww": gww, "bw": v["bw"].clone()}
         return [m[k] for k in self.order]
+
+    def dopri5_step_native(self, y, kk, y1, t, h, rtol, atol):
+        lib = _lib.load()
+        fs, ws = self._structs(True)
+        arr = lambda c: (ctypes.c_void_p * 7)(*[kk[i][c].data_ptr() for i in range(7)])      # noqa: E731
+        sums = torch.empty(4, dtype=torch.float64, device=y[0].device)
+        _lib.check(lib.gode_gat_ode_dopri5_step_adjoint(
+            ctypes.byref(fs), _lib.ptr(y[0]), _lib.ptr(y[1]), _lib.ptr(y[2]), _lib.ptr(y[3]), arr(0), arr(1), arr(2), arr(3),
+            _lib.ptr(y1[0]), _lib.ptr(y1[1]), _lib.ptr(y1[2]), _lib.ptr(y1[3]), ctypes.byref(ws), float(t), float(h),
+            float(rtol), float(atol), _lib.ptr(sums), _lib.ptr(self.w.err_scratch), _lib.stream_ptr()),
+            "gode_gat_ode_dopri5_step_adjoint")
+        return sums
 
     def eval(self, t, terms, out):
         s, w = self.s, self.w

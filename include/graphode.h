@@ -325,6 +325,41 @@ int gode_gcn_ode_dopri5_step_adjoint(const gode_gcn_odefunc_t* f, const float* y
                                      double t, double h, float rtol, float atol, double* sums /* 4 */,
                                      void* err_scratch, void* stream);
 
+/* The same for the GAT ODE function  f(t, x) = relu(EdgeAttention([t | GroupNorm(x)]))  (GAT/models.py:172-179 ->
+ * GAT/layers.py:95-122), with the two Linear layers packed by role: Wsrc, Wtgt ((d+1) x d: message parts by source /
+ * target, time row first) and Wlog ((d+1) x 2: the two logit columns).  Adjoint state: (y, a, a_t, theta) with
+ * theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta]  (gode_gat_ode_theta_len floats). */
+typedef struct gode_gat_odefunc {
+    gode_graph_t mt;                    /* CSR of Mtgt (col NULL: target-sorted edge list), + record list on large graphs */
+    gode_graph_t ms_inc, mt_inc;        /* incidence CSR by source / by target (pattern only; adjoint) */
+    const int32_t* src; const int32_t* tgt; int64_t n_edges;
+    int64_t n, d; int32_t groups; float eps_gn; float eps;
+    const float* Wsrc; const float* Wtgt; const float* Wlog;
+    const float* bf; const float* bw; const float* gamma; const float* beta;
+} gode_gat_odefunc_t;
+
+typedef struct gode_gat_workspace {
+    float* X; float* Ps; float* Pt; float* A2;          /* n x d, n x d, n x d, n x 2 */
+    float* a; float* amax; float* wgt; float* den;      /* E, 1, E, n */
+    void* logits_scratch;                               /* gode_gat_logits_scratch_bytes(E) */
+    /* adjoint only */
+    float* dz; float* da;                               /* E x d, E */
+    float* dPs; float* dPt; float* dA2; float* pair;    /* n x d, n x d, n x 2, 2 floats */
+    float* gp; float* bp;                               /* 3 * gode_gemm_bwd_parts(n) * d floats each */
+    float* wp[3];                                       /* gode_wgrad_parts(n) * (d+1)*d, same, * (d+1)*2 */
+    void* maxpath_scratch; void* colsum_scratch;        /* gode_gat_maxpath_scratch_bytes(E); gode_colsum_scratch_bytes(n, d) */
+} gode_gat_workspace_t;
+
+int64_t gode_gat_ode_theta_len(int64_t d);
+int gode_gat_ode_dopri5_step_forward(const gode_gat_odefunc_t* f, const float* y, float* const* k /* 7 */, float* y1,
+                                     const gode_gat_workspace_t* ws, double t, double h, float rtol, float atol,
+                                     double* sums, void* err_scratch, void* stream);
+int gode_gat_ode_dopri5_step_adjoint(const gode_gat_odefunc_t* f, const float* y, const float* a, const float* a_t,
+                                     const float* theta, float* const* ky, float* const* ka, float* const* ka_t,
+                                     float* const* ktheta, float* y1, float* a1, float* a_t1, float* theta1,
+                                     const gode_gat_workspace_t* ws, double t, double h, float rtol, float atol,
+                                     double* sums /* 4 */, void* err_scratch, void* stream);
+
 /* ---- measurement aid (bench.py): HIP-event brackets around the SpMM main kernel ----------
  * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 fast-path launch
  * records a start/stop event pair on its stream (up to `capacity` launches).

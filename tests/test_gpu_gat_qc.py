@@ -569,3 +569,32 @@ def test_gat_ode_block_on_edgeless_graph():
     out.sum().backward()
     close(x.grad, torch.ones(n, d), 0.0, "identity gradient")
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) == 0.0 for p in blk.parameters())
+
+
+@pytest.mark.parametrize("d", [16, 128])
+def test_gat_native_dopri5_step_matches_python_driver(golden, d):
+    """Adaptive steps of the fused GAT field as one C-ABI call (csrc/gat_driver.hip) against the per-stage Python driver
+    on Citeseer's edge list: same kernels in the same order, so the same accepted / rejected steps."""
+    from graph_odenet_amd import gat_models, solver as SV
+    ge = golden("citeseer_gat_edges.npz")
+    n, src, tgt, Mtgt = gat_inputs(ge)
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(d)).relu().to(dev())
+    res = {}
+    for native in (True, False):
+        SV.DOPRI5_NATIVE = native
+        try:
+            torch.manual_seed(1)
+            blk = gat_models.ODEBlock(gat_models.ODEfunc(d), tol=1e-4).to(dev())          # default method: dopri5
+            xi = x.clone().requires_grad_(True)
+            out = blk(xi, src, tgt, Mtgt)
+            nf = blk.nfe; blk.nfe = 0
+            out.square().mean().backward()
+            res[native] = (out.detach(), xi.grad, [p.grad.clone() for p in blk.parameters()], nf, blk.nfe)
+        finally:
+            SV.DOPRI5_NATIVE = True
+    assert res[True][3] == res[False][3] and res[True][4] == res[False][4] and res[True][3] >= 14
+    close(res[True][0], res[False][0], 1e-6, "state")
+    close(res[True][1], res[False][1], 1e-5, "gx")
+    tol = 1e-4 if d == 16 else 1e-5
+    for a, b in zip(res[True][2], res[False][2]):
+        close(a, b, tol, "param grad")
