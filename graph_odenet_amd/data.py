@@ -40,6 +40,57 @@ def load_captured(name):
     return _coo(g["rows"], g["cols"], g["vals"], n), feats, t("labels"), t("idx_train"), t("idx_val"), t("idx_test")
 
 
+def undirected_edge_list(graph):
+    """Each undirected edge of a {node: [neighbours]} dict ONCE, in the order the reference's GAT loader gets them from
+    networkx (GAT/utils.py:187-189: `nx.from_dict_of_lists(graph)` then `G.edges`): nodes in the dict's order, each
+    with its not-yet-finished neighbours in the order they were first attached.  (Messages therefore flow in one
+    direction per undirected edge - a property of the reference.)"""
+    adj = {}
+    for u in graph:
+        adj.setdefault(u, {})
+    seen = set()
+    for u, nbrs in graph.items():                 # from_dict_of_lists: an edge enters when its first endpoint comes up
+        for v in nbrs:
+            if v not in seen:
+                adj.setdefault(v, {})
+                adj[u][v] = True
+                adj[v][u] = True
+        seen.add(u)
+    done, edges = set(), []
+    for u, nbrs in adj.items():                   # Graph.edges: (u, v) for v in adj[u] unless v is already finished
+        for v in nbrs:
+            if v not in done:
+                edges.append((u, v))
+        done.add(u)
+    return np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+
+
+def _gat_tuple(edges, n, rest):
+    src, tgt = torch.from_numpy(edges[:, 0].copy()), torch.from_numpy(edges[:, 1].copy())
+    e = src.numel()
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(e)]), torch.ones(e), (n, e))
+    return (src, tgt, Mtgt) + tuple(rest)
+
+
+def load_captured_gat(name):
+    """(src, tgt, Mtgt, features, labels, idx_train, idx_val, idx_test) as GAT/utils.py:load_data_new returns them, from
+    the captured outputs (tests/golden/<name>_gat_edges.npz + <name>_graph.npz)."""
+    path = os.path.join(GOLDEN, "%s_gat_edges.npz" % name)
+    if not os.path.exists(path):
+        raise FileNotFoundError("no captured GAT edge list for %r (have: cora, citeseer)" % name)
+    g = np.load(path)
+    edges = np.stack([g["src"].astype(np.int64), g["tgt"].astype(np.int64)], 1)
+    return _gat_tuple(edges, int(g["n"]), load_captured(name)[1:])
+
+
+def load_planetoid_gat(name, data_dir):
+    """The same from the raw `ind.<name>.*` files (own reader + undirected_edge_list)."""
+    with open(os.path.join(data_dir, "ind.%s.graph" % name), "rb") as f:
+        graph = pickle.load(f, encoding="latin1")
+    rest = load_planetoid(name, data_dir)[1:]
+    return _gat_tuple(undirected_edge_list(graph), rest[0].shape[0], rest)
+
+
 def load_planetoid(name, data_dir, norm="row"):
     import scipy.sparse as sp
 

@@ -2,6 +2,7 @@
 (GCN/train_res.py:17-158), on the MI355X path.
 
     python -m graph_odenet_amd.train_res --model ode3 --dataset cora [--runs N] [--method rk4 --step_size 0.0625]
+    python -m graph_odenet_amd.train_res --variant gat --model ode3 --dataset citeseer        (GAT/train_res.py)
 
 Same flags, defaults, seeding rule (seed applied only when --runs 1), per-epoch line, `Run #i Test --`
 line and closing summary, so GCN/results/basic/{stats,make_table}.py parse its stdout unchanged.
@@ -18,13 +19,18 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import models
-from .data import load_captured, load_planetoid
+from . import gat_models, models
+from .data import load_captured, load_captured_gat, load_planetoid, load_planetoid_gat
 from .parallel import shard_range
 
-MODELS = {"gcn2": models.GCN, "gcn3": models.GCN3, "gcn3norm": models.GCN3, "res3": models.RGCN3,
-          "ode3": models.ODEGCN3, "res3norm": models.RGCN3norm, "res3fullnorm": models.RGCN3fullnorm,
-          "ode3norm": models.ODEGCN3fullnorm}     # "gcn3norm" -> GCN3 as in the reference's model_dict (Q2)
+def _model_dict(mod):
+    return {"gcn2": mod.GCN, "gcn3": mod.GCN3, "gcn3norm": mod.GCN3, "res3": mod.RGCN3,
+            "ode3": mod.ODEGCN3, "res3norm": mod.RGCN3norm, "res3fullnorm": mod.RGCN3fullnorm,
+            "ode3norm": mod.ODEGCN3fullnorm}      # "gcn3norm" -> GCN3 as in the reference's model_dict (Q2)
+
+
+MODELS = _model_dict(models)
+VARIANTS = {"gcn": MODELS, "gat": _model_dict(gat_models)}      # GCN/train_res.py and GAT/train_res.py (same CLI)
 
 
 def accuracy(output, labels):
@@ -49,13 +55,17 @@ def build_parser():
     p.add_argument('--tol', type=float, default=1e-5)
     p.add_argument('--data_dir', default=None)
     p.add_argument('--norm', choices=["row", "sym", "sum"], default="row")
+    p.add_argument('--variant', choices=sorted(VARIANTS), default="gcn",
+                   help="gcn: models over a normalised adjacency (GCN/train_res.py); gat: edge attention over "
+                        "(src, tgt, Mtgt) (GAT/train_res.py)")
     return p
 
 
 class Trainer:
     def __init__(self, args, data, device, verbose):
         self.args, self.verbose, self.device = args, verbose, device
-        self.adj, self.x, self.y, self.itr, self.iva, self.ite = (t.to(device) for t in data)
+        *graph, self.x, self.y, self.itr, self.iva, self.ite = (t.to(device) for t in data)
+        self.graph = tuple(graph)                  # (adj,) or (src, tgt, Mtgt)
         self.is_ode = "ode" in args.model
 
     def new_model(self):
@@ -63,7 +73,7 @@ class Trainer:
         kw = dict(nfeat=self.x.shape[1], nhid=a.hidden, nclass=int(self.y.max().item()) + 1, dropout=a.dropout)
         if self.is_ode:
             kw.update(method=a.method, step_size=a.step_size, tol=a.tol)
-        model = MODELS[a.model](**kw).to(self.device)
+        model = VARIANTS[a.variant][a.model](**kw).to(self.device)
         opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
         return model, opt
 
@@ -72,7 +82,7 @@ class Trainer:
         model.nfe = 0
         model.train()
         opt.zero_grad()
-        out = model(self.x, self.adj)
+        out = model(self.x, *self.graph)
         nfe_f = model.nfe
         model.nfe = 0
         loss = F.nll_loss(out[self.itr], self.y[self.itr])
@@ -84,7 +94,7 @@ class Trainer:
         if not self.args.fastmode:
             model.eval()
             with torch.no_grad():
-                out = model(self.x, self.adj)
+                out = model(self.x, *self.graph)
         lv = F.nll_loss(out[self.iva], self.y[self.iva])
         av = accuracy(out[self.iva], self.y[self.iva])
         if self.verbose:
@@ -98,7 +108,7 @@ class Trainer:
     def test(self, model):
         model.eval()
         with torch.no_grad():
-            out = model(self.x, self.adj)
+            out = model(self.x, *self.graph)
         lt = F.nll_loss(out[self.ite], self.y[self.ite]).item()
         at = accuracy(out[self.ite], self.y[self.ite]).item()
         if self.verbose:
@@ -123,7 +133,10 @@ def main(argv=None):
         np.random.seed(args.seed)
         torch.manual_seed(args.seed)
         torch.cuda.manual_seed(args.seed)
-    data = load_planetoid(args.dataset, args.data_dir, args.norm) if args.data_dir else load_captured(args.dataset)
+    if args.variant == "gat":
+        data = load_planetoid_gat(args.dataset, args.data_dir) if args.data_dir else load_captured_gat(args.dataset)
+    else:
+        data = load_planetoid(args.dataset, args.data_dir, args.norm) if args.data_dir else load_captured(args.dataset)
     tr = Trainer(args, data, device, verbose=(args.runs == 1 and rank == 0))
     lo, hi = shard_range(args.runs, rank, world)
     tot = torch.zeros(3, dtype=torch.float64, device=device)

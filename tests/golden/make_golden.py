@@ -15,6 +15,7 @@ What is captured (inputs AND expected outputs, fp32):
   pubmed_graph_sym.npz  Pubmed topology, D^-1/2 (A+I) D^-1/2                 (GCN-dense-paper/utils.py:70-110)
   gcn_depth_models.npz  depth-sweep model family (GCNK*, RESK*) eval outputs + one gradient (GCN/models.py:255-522)
   gcn_variants.npz   GCN-mlp-sum layer / ODEfunc / models and GCN-dense-paper models (their layers.py, models.py)
+  train_traj_cora.npz  ten training steps of the reference's GCN3 / RGCN3norm (GCN) and GCN3 (GAT) on Cora: loss trajectory
   gat_zoo.npz        non-ODE GAT model zoo eval outputs + one gradient (GAT/models.py)
   set2set.npz        the reference's Set2Set readout alone: q_star + gradients (QC/set2set.py:6-75)
   qc_models.npz      QC model zoo outputs + small gradients on a synthetic batch (QC/layer_models.py:27-232)
@@ -268,7 +269,7 @@ if __name__ == "__main__":
         sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
         sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
         pubmed_topology()
-    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth", "gat_zoo", "variants"):
+    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth", "gat_zoo", "variants", "gat_edges", "train_traj"):
         main()
         pubmed_topology()
         qc_models_golden()
@@ -440,6 +441,58 @@ def variants_golden():
     save("gcn_variants.npz", **res)
 
 
+def gat_edges_golden():
+    """Edge lists the GAT loader derives from the Planetoid graphs (GAT/utils.py:187-209), for both datasets present."""
+    import scipy.sparse.linalg as spla
+    alias = types.ModuleType("scipy.sparse.linalg.eigen.arpack")
+    alias.eigsh = spla.eigsh
+    sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
+    sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
+    cwd = os.getcwd()
+    os.chdir(REF)                                  # the loaders open "data/ind.*" relative to the checkout root
+    try:
+        (gatutils,) = ref_import("GAT", "utils")
+        for name in ("cora", "citeseer"):
+            src, tgt, Mtgt, feats, labels, itr, iva, ite = gatutils.load_data_new(name)
+            mi = Mtgt._indices()
+            save("%s_gat_edges.npz" % name, src=src.to(torch.int32), tgt=tgt.to(torch.int32),
+                 m_rows=mi[0].to(torch.int32), m_cols=mi[1].to(torch.int32), m_vals=Mtgt._values(), n=Mtgt.shape[0])
+    finally:
+        os.chdir(cwd)
+
+
+def train_traj_golden():
+    """Ten Adam steps (lr .01, wd 5e-4, dropout 0: no RNG involved) of the reference's own GCN3 / RGCN3norm (GCN) and
+    GCN3 (GAT) on Cora, from a saved initial state: training-loss trajectory and final eval logits of 64 test nodes."""
+    stub = types.ModuleType("torchdiffeq"); stub.odeint_adjoint = None; stub.odeint = None
+    sys.modules["torchdiffeq"] = stub
+    sys.path.insert(0, ROOT_REPO)
+    from graph_odenet_amd.data import load_captured, load_captured_gat
+    import torch.nn.functional as F
+    res = {}
+    for variant, names in (("GCN", ("GCN3", "RGCN3norm")), ("GAT", ("GCN3",))):
+        (mods,) = ref_import(variant, "models")
+        data = load_captured("cora") if variant == "GCN" else load_captured_gat("cora")
+        *graph, x, y, itr, iva, ite = data
+        for name in names:
+            torch.manual_seed(5)
+            m = getattr(mods, name)(nfeat=x.shape[1], nhid=16, nclass=7, dropout=0.0)
+            key = "%s_%s" % (variant, name)
+            for k, p in m.state_dict().items():
+                res[key + "__sd__" + k.replace(".", "__")] = p.clone()
+            opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=5e-4)
+            losses = []
+            for _ in range(10):
+                m.train(); opt.zero_grad()
+                loss = F.nll_loss(m(x, *graph)[itr], y[itr])
+                loss.backward(); opt.step()
+                losses.append(float(loss))
+            m.eval()
+            res[key + "__losses"] = torch.tensor(losses, dtype=torch.float64)
+            res[key + "__logits"] = m(x, *graph)[ite[:64]]
+    save("train_traj_cora.npz", **res)
+
+
 def set2set_golden():
     """The reference's Set2Set module (QC/set2set.py:6-75) alone: h=24, 4 processing steps, 6 graphs of
     uneven size; inputs, lstm parameters, q_star and the gradients of x and of the lstm parameters."""
@@ -467,6 +520,13 @@ def set2set_golden():
 
 
 ROOT_REPO = os.path.dirname(os.path.dirname(OUT))
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "train_traj":
+    sys.dont_write_bytecode = True
+    ROOT_REPO = os.path.dirname(os.path.dirname(OUT))
+    train_traj_golden()
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "gat_edges":
+    sys.dont_write_bytecode = True
+    gat_edges_golden()
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "variants":
     sys.dont_write_bytecode = True
     variants_golden()

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from graph_odenet_amd.data import load_captured, load_planetoid
+from graph_odenet_amd.data import load_captured, load_captured_gat, load_planetoid, load_planetoid_gat
 
 RAW = "/root/reference/data"
 
@@ -27,3 +27,17 @@ def test_captured_shapes():
     adj, x, y, itr, iva, ite = load_captured("cora")
     assert adj.shape == (2708, 2708) and adj._nnz() == 13264 and x.shape == (2708, 1433)
     assert itr.numel() == 140 and iva.numel() == 500 and ite.numel() == 1000 and int(y.max()) == 6
+
+
+@pytest.mark.parametrize("name,n_edges", [("cora", 5278), ("citeseer", 4676)])
+def test_own_gat_edge_list_matches_reference_loader(name, n_edges):
+    """undirected_edge_list restates networkx's edge order (GAT/utils.py:187-189); compared with the edge lists captured
+    from the reference's GAT loader."""
+    src, tgt, Mtgt, x, y, itr, iva, ite = load_captured_gat(name)
+    assert src.numel() == n_edges and Mtgt.shape == (x.shape[0], n_edges)
+    if not os.path.exists(os.path.join(RAW, "ind.%s.graph" % name)):
+        pytest.skip("raw Planetoid files not present on this machine")
+    s2, t2, M2, x2, y2, *_ = load_planetoid_gat(name, RAW)
+    assert torch.equal(s2, src) and torch.equal(t2, tgt)
+    assert torch.equal(M2.coalesce().indices(), Mtgt.coalesce().indices())
+    assert torch.allclose(x2, x, atol=1e-7) and torch.equal(y2, y)
