@@ -15,6 +15,7 @@ What is captured (inputs AND expected outputs, fp32):
   pubmed_graph_sym.npz  Pubmed topology, D^-1/2 (A+I) D^-1/2                 (GCN-dense-paper/utils.py:70-110)
   gcn_depth_models.npz  depth-sweep model family (GCNK*, RESK*) eval outputs + one gradient (GCN/models.py:255-522)
   gcn_variants.npz   GCN-mlp-sum layer / ODEfunc / models and GCN-dense-paper models (their layers.py, models.py)
+  train_traj_qc.npz  five training steps of the reference's EdgeGCN_K_Sum / MPNN_ENN_K_Set2Set on a synthetic batch
   train_traj_cora.npz  ten training steps of the reference's GCN3 / RGCN3norm (GCN) and GCN3 (GAT) on Cora: loss trajectory
   gat_zoo.npz        non-ODE GAT model zoo eval outputs + one gradient (GAT/models.py)
   set2set.npz        the reference's Set2Set readout alone: q_star + gradients (QC/set2set.py:6-75)
@@ -491,6 +492,35 @@ def train_traj_golden():
             res[key + "__losses"] = torch.tensor(losses, dtype=torch.float64)
             res[key + "__logits"] = m(x, *graph)[ite[:64]]
     save("train_traj_cora.npz", **res)
+    # QC: five Adam steps (lr 1e-3, QC/train_egcn.py:122) of two reference models on the 4-molecule synthetic batch
+    from graph_odenet_amd.synth import qm9_like_batch
+    for n in ("layers", "models", "mpnn", "set2set", "layer_models", "torch_scatter", "torch_geometric_utils"):
+        sys.modules.pop(n, None)
+    sys.path.insert(0, os.path.join(REF, "QC"))
+    try:
+        lm = importlib.import_module("layer_models")
+    finally:
+        sys.path.pop(0)
+    x, ef, Esrc, Etgt, batch = qm9_like_batch(4, seed=3)
+    torch.manual_seed(8)
+    tgt = torch.randn(4, 12)
+    res = dict(x=x, ef=ef, Esrc=Esrc, etgt=Etgt.argmax(0), batch=batch, n=x.shape[0], target=tgt)
+    for name in ("EdgeGCN_K_Sum", "MPNN_ENN_K_Set2Set"):
+        m = getattr(lm, name)(node_features=13, edge_features=5, target_features=12, hidden_features=16, num_layers=3,
+                              s2s_processing_steps=3, dropout=0.0)
+        for k, p in m.state_dict().items():
+            res[name + "__sd__" + k.replace(".", "__")] = p.clone()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        losses = []
+        m.train()
+        for _ in range(5):
+            opt.zero_grad()
+            loss = F.mse_loss(m(x, ef, Esrc, Etgt, batch), tgt)
+            loss.backward(); opt.step()
+            losses.append(float(loss))
+        res[name + "__losses"] = torch.tensor(losses, dtype=torch.float64)
+        res[name + "__out"] = m(x, ef, Esrc, Etgt, batch)
+    save("train_traj_qc.npz", **res)
 
 
 def set2set_golden():

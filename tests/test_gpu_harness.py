@@ -86,3 +86,38 @@ def test_training_trajectory_matches_reference(golden, variant, name):
     # hidden 16 -> one channel per GroupNorm group in the norm variant (noise-floor comparison)
     tol = 5e-4 if "norm" in name else 5e-5
     assert float((logits - torch.from_numpy(np.asarray(g["%s_%s__logits" % (variant, name)]))).abs().max()) < tol
+
+
+@pytest.mark.parametrize("name", ["EdgeGCN_K_Sum", "MPNN_ENN_K_Set2Set"])
+def test_qc_training_trajectory_matches_reference(golden, name):
+    """Five Adam steps (lr 1e-3, MSE, as QC/train_egcn.py) of the reference's QC model classes on a synthetic 4-molecule
+    batch vs ours from the same initial weights: loss sequence and final outputs (tests/golden/train_traj_qc.npz)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from graph_odenet_amd import qc_models
+    g = golden("train_traj_qc.npz")
+    dev = torch.device("cuda:0")
+    T = lambda k: torch.from_numpy(np.asarray(g[k]))          # noqa: E731
+    n = int(g["n"])
+    x, ef, tgt = T("x").to(dev), T("ef").to(dev), T("target").to(dev)
+    Esrc, batch = T("Esrc").long().to(dev), T("batch").long().to(dev)
+    E = Esrc.numel()
+    Etgt = torch.zeros(n, E)
+    Etgt[T("etgt").long(), torch.arange(E)] = 1.0
+    Etgt = Etgt.to(dev)
+    m = getattr(qc_models, name)(node_features=13, edge_features=5, target_features=12, hidden_features=16, num_layers=3,
+                                 s2s_processing_steps=3, dropout=0.0)
+    pre = name + "__sd__"
+    m.load_state_dict({k[len(pre):].replace("__", "."): torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(pre)})
+    m = m.to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = F.mse_loss(m(x, ef, Esrc, Etgt, batch), tgt)
+        loss.backward(); opt.step()
+        losses.append(float(loss.detach()))
+    ref = np.asarray(g[name + "__losses"])
+    assert np.abs(np.asarray(losses) - ref).max() < 5e-5 * max(1.0, float(ref.max())), (losses, ref)
+    out = m(x, ef, Esrc, Etgt, batch).detach().cpu()
+    assert float((out - T(name + "__out")).abs().max()) < 1e-4 * max(1.0, float(T(name + "__out").abs().max()))
