@@ -118,6 +118,7 @@ SIGNATURES = {
     "gode_gat_scatter_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64,
                                    c_p]),
     "gode_time_row_fixup_f32": (c_i, [c_p, c_p, c_i64, c_f, c_p, c_i, c_p]),
+    "gode_time_row_fixup3_f32": (c_i, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_p, c_i64, c_f, c_p, c_p]),
     "gode_edge_matvec_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
     "gode_edge_matvec_msg_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "gode_edge_matvec_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),

@@ -966,6 +966,39 @@ extern "C" int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* ei
     return 0;
 }
 
+// the same for three weight blocks in one launch: at = sum_b <g_b, w_b> (added in block order), every g_b *= t
+__global__ __launch_bounds__(256) void time_row_fixup3_kernel(float* g0, const float* w0, int l0, float* g1, const float* w1,
+                                                              int l1, float* g2, const float* w2, int l2, float t,
+                                                              float* __restrict__ at) {
+    __shared__ float sm[4];
+    float* gs[3] = {g0, g1, g2};
+    const float* ws[3] = {w0, w1, w2};
+    const int ls[3] = {l0, l1, l2};
+    float total = 0.f;
+    for (int b = 0; b < 3; ++b) {
+        float s = 0.f;
+        for (int c = threadIdx.x; c < ls[b]; c += 256) s += gs[b][c] * ws[b][c];
+        s = wave_sum(s);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+        __syncthreads();
+        total += (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        for (int c = threadIdx.x; c < ls[b]; c += 256) gs[b][c] *= t;
+    }
+    if (threadIdx.x == 0) at[0] = total;
+}
+
+extern "C" int gode_time_row_fixup3_f32(float* g0, const float* w0, int64_t l0, float* g1, const float* w1, int64_t l1,
+                                        float* g2, const float* w2, int64_t l2, float t, float* at, void* stream) {
+    if (l0 <= 0 || l1 <= 0 || l2 <= 0) return GODE_E_SHAPE;
+    if (!g0 || !w0 || !g1 || !w1 || !g2 || !w2 || !at) return GODE_E_NULLPTR;
+    if (l0 > INT32_MAX || l1 > INT32_MAX || l2 > INT32_MAX) return GODE_E_RANGE;
+    hipLaunchKernelGGL(time_row_fixup3_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g0, w0, (int)l0, g1, w1, (int)l1,
+                       g2, w2, (int)l2, t, at);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int gode_time_row_fixup_f32(float* g_row0, const float* w_row0, int64_t len, float t, float* at,
                                        int accumulate, void* stream) {
     if (len <= 0) return GODE_E_SHAPE;

@@ -103,12 +103,12 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
     float* gW[3] = {g_src, g_tgt, g_log};
     const int64_t lenW[3] = {nW, nW, nL};
     const int64_t npw = gode_wgrad_parts(n);
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 3; ++j)
         GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, dPj[j], dout[j], 1, w->wp[j], stream));
-        GODE_TRY(gode_reduce_parts_f32(gW[j], w->wp[j], npw, lenW[j], 1.f, 0, stream));
-        GODE_TRY(gode_time_row_fixup_f32(gW[j], Wj[j], dout[j], t, kat, j > 0, stream));     // a_t' = -a^T df/dt ; row 0 *= t
-    }
-    return 0;
+    GODE_TRY(gode_reduce_parts2_f32(gW[0], w->wp[0], gW[1], w->wp[1], npw, lenW[0], 1.f, 0, stream));
+    GODE_TRY(gode_reduce_parts_f32(gW[2], w->wp[2], npw, lenW[2], 1.f, 0, stream));
+    // a_t' = -a^T df/dt over the three time rows; each row 0 *= t
+    return gode_time_row_fixup3_f32(gW[0], Wj[0], dout[0], gW[1], Wj[1], dout[1], gW[2], Wj[2], dout[2], t, kat, stream);
 }
 
 int check_common(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, bool adjoint) {

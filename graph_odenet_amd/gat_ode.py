@@ -229,10 +229,12 @@ class GatOdeAdjointField(GatOdeField):
             ops.reduce_parts2_(g["gamma"], w.gp, g["beta"], w.bp)
         else:
             g["gamma"].zero_(); g["beta"].zero_()
-        for j, (name, Wj, dPj) in enumerate((("Wsrc", s.Wsrc, w.dPs), ("Wtgt", s.Wtgt, w.dPt), ("Wlog", s.Wlog, w.dA2))):
+        for j, dPj in enumerate((w.dPs, w.dPt, w.dA2)):
             ops.wgrad(xt, n, o, s.groups, s.eps_gn, s.gamma, s.beta, dPj, True, part=w.wp[j])
-            ops.reduce_parts_(g[name].view(-1), w.wp[j])
-            ops.time_row_fixup_(g[name][0], Wj[0], t, out[2], accumulate=j > 0)     # a_t' = -a^T df/dt ; row 0 *= t
+        ops.reduce_parts2_(g["Wsrc"].view(-1), w.wp[0], g["Wtgt"].view(-1), w.wp[1])
+        ops.reduce_parts_(g["Wlog"].view(-1), w.wp[2])
+        # a_t' = -a^T df/dt over the three time rows; each row 0 *= t
+        ops.time_row_fixup3_([g["Wsrc"][0], g["Wtgt"][0], g["Wlog"][0]], [s.Wsrc[0], s.Wtgt[0], s.Wlog[0]], t, out[2])
 
 
 def gat_fields(odefunc, y0):

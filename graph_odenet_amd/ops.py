@@ -363,6 +363,18 @@ def time_row_fixup_(g_row0, w_row0, t, at, accumulate):
                                       1 if accumulate else 0, stream_ptr()), "gode_time_row_fixup_f32")
 
 
+def time_row_fixup3_(rows, w_rows, t, at):
+    """at = sum_b <rows[b], w_rows[b]>; rows[b] *= t   (three weight blocks, one launch)."""
+    lib = _lib.load()
+    for r, w in zip(rows, w_rows):
+        _need(r, "g_row0"); _need(w, "w_row0")
+    _need(at, "at")
+    a = []
+    for r, w in zip(rows, w_rows):
+        a += [ptr(r), ptr(w), r.numel()]
+    check(lib.gode_time_row_fixup3_f32(*a, float(t), ptr(at), stream_ptr()), "gode_time_row_fixup3_f32")
+
+
 # ---- QC edge-conditioned messages ---------------------------------------------------------------
 EDGE_MSG_MIN_EDGES = 4096      # from this many edges on, the message step runs as per-edge matvec + SpMM
 

@@ -239,6 +239,9 @@ int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* eid_src, cons
 /* time row of a weight gradient inside the adjoint: at (+)= <g_row0, w_row0>;  g_row0 *= t  (len floats) */
 int gode_time_row_fixup_f32(float* g_row0, const float* w_row0, int64_t len, float t, float* at, int accumulate,
                             void* stream);
+/* three weight blocks in one launch: at = <g0,w0> + <g1,w1> + <g2,w2>;  every g_b *= t */
+int gode_time_row_fixup3_f32(float* g0, const float* w0, int64_t l0, float* g1, const float* w1, int64_t l1,
+                             float* g2, const float* w2, int64_t l2, float t, float* at, void* stream);
 
 /* ---- QC edge-conditioned messages (QC/mpnn.py:27-29, QC/layers.py:143-145) ----------------
  * out[v,:] = sum_k val[k] * A[e_k] (h x h, row-major) * X[src[e_k], :]   over row v of Etgt (CSR).
