@@ -93,6 +93,8 @@ SIGNATURES = {
                                     c_p, c_i64, c_i, c_f, c_p, c_p]),
     "gode_gn_time_gemm_xout_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
                                          c_p, c_i64, c_i, c_f, c_p, c_p, c_p]),
+    "gode_gn_time_gemm_pair_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p,
+                                         c_i, c_f, c_p, c_p, c_p, c_p]),
     "gode_gemm_bwd_parts": (c_i64, [c_i64]),
     "gode_gn_time_gemm_bwd_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p,
                                         c_p, c_i64, c_i, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p]),

@@ -45,9 +45,9 @@ gode_gat_proj_t proj_of(const gode_gat_workspace_t* w, int64_t d) {
 int project(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lincomb_t* yin, float t, void* stream) {
     const int64_t n = f->n, d = f->d;
     float* xo = yin->n > 1 ? w->X : nullptr;
-    GODE_TRY(gode_gn_time_gemm_xout_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, d, 1, t, w->Ps, xo, stream));
+    GODE_TRY(gode_gn_time_gemm_pair_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, f->Wtgt, 1, t, w->Ps, w->Pt,
+                                        xo, stream));
     if (xo) { yin->n = 1; yin->coef[0] = 1.f; yin->ptr[0] = xo; }
-    GODE_TRY(gode_gn_time_gemm_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wtgt, d, 1, t, w->Pt, stream));
     return gode_gn_time_gemm_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wlog, 2, 1, t, w->A2, stream);
 }
 

@@ -294,11 +294,13 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ W, int has_time, float t,
-                                                             float* __restrict__ S, float* __restrict__ xout)
+                                                             float* __restrict__ S, float* __restrict__ xout,
+                                                             const float* __restrict__ W2, float* __restrict__ S2)
 {
     constexpr int D = 16 * NJ;
     constexpr int LDW = D + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.y == 1) { W = W2; S = S2; xout = nullptr; }      // second (W, S) pair over the same input (grid.y = 2)
     float* Ws = smem;
     float* Gs = smem + D * LDW;          // gamma | beta | t * W[0,:]
     float* Bs = Gs + D;
@@ -1259,7 +1261,8 @@ extern "C" int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin, int64_t n_r
 #define GODE_FWD(NJV, CGV)                                                                          \
         { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
           hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
-                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S, x_out);          \
+                             lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S, x_out,           \
+                             (const float*)nullptr, (float*)nullptr);                               \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_FWD)
 #undef GODE_FWD
@@ -1285,6 +1288,39 @@ extern "C" int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin, int64_t n_r
                        (int)groups, eps, gamma, beta, W, (int)d_out, has_time, t, S);
     GODE_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gode_gn_time_gemm_pair_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                                          const float* gamma, const float* beta, const float* Wa, const float* Wb,
+                                          int has_time, float t, float* Sa, float* Sb, float* x_out, void* stream)
+{
+    // two square products over the same normalised input in one launch (grid.y selects the pair); shapes outside the
+    // MFMA path run as two calls
+    int rc = check_common(xin, n_rows, d, groups, d); if (rc) return rc;
+    if (n_rows == 0) return 0;
+    if (!Wa || !Wb || !Sa || !Sb) return GODE_E_NULLPTR;
+    has_time = has_time ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    LinComb lc = make_lincomb(xin);
+    const int cg = fast_cg(d, d, groups);
+    const bool al = lincomb_aligned16(xin) && !((((uintptr_t)Sa) | ((uintptr_t)Sb) | ((uintptr_t)Wa) | ((uintptr_t)Wb)) & 15) &&
+                    (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15)) &&
+                    (!x_out || !(((uintptr_t)x_out) & 15));
+    if (cg >= 0 && al) {
+        const int nj = (int)(d / 16);
+        const size_t lds = ((size_t)d * (d + 4) + 3 * d) * sizeof(float);
+        const int64_t blocks = fwd_blocks(n_rows);
+#define GODE_FWDP(NJV, CGV)                                                                         \
+        { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
+          hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV>), dim3((unsigned)blocks, 2), dim3(256), lds, s, \
+                             lc, (int)n_rows, eps, gamma, beta, Wa, has_time, t, Sa, x_out, Wb, Sb);  \
+          GODE_LAUNCH_CHECK(); return 0; }
+        GODE_DISPATCH_ALL(GODE_FWDP)
+#undef GODE_FWDP
+    }
+    rc = gode_gn_time_gemm_xout_f32(xin, n_rows, d, groups, eps, gamma, beta, Wa, d, has_time, t, Sa, x_out, stream);
+    if (rc) return rc;
+    return gode_gn_time_gemm_f32(xin, n_rows, d, groups, eps, gamma, beta, Wb, d, has_time, t, Sb, stream);
 }
 
 extern "C" int64_t gode_gemm_bwd_parts(int64_t n_rows) {

@@ -154,9 +154,9 @@ class GatOdeField(Field):
         """Ps, Pt, A2 of the stage input; returns the term list later launches of the stage should read."""
         s, w = self.s, self.w
         x_out = w.X if len(y_terms) > 1 else None
-        ops.gn_time_gemm(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, True, t, out=w.Ps, x_out=x_out)
+        ops.gn_time_gemm_pair(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, True, t, w.Ps, w.Pt,
+                              x_out=x_out)
         terms = [(1.0, w.X)] if x_out is not None else y_terms
-        ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wtgt, True, t, out=w.Pt)
         ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog, True, t, out=w.A2)
         return terms
 

@@ -164,6 +164,22 @@ def gn_time_gemm(x_terms, n_rows, d_in, groups, eps, gamma, beta, W, has_time, t
     return out
 
 
+def gn_time_gemm_pair(x_terms, n_rows, d, groups, eps, gamma, beta, Wa, Wb, has_time, t, out_a, out_b, x_out=None):
+    """out_a = [t | GN(x)] @ Wa, out_b = [t | GN(x)] @ Wb for two square weight matrices, in one launch."""
+    lib = _lib.load()
+    for tns, nm in ((Wa, "Wa"), (Wb, "Wb"), (gamma, "gamma"), (beta, "beta"), (out_a, "out_a"), (out_b, "out_b"), (x_out, "x_out")):
+        _need(tns, nm)
+    if _need_terms(x_terms, "x") != n_rows * d:
+        raise ValueError("gn_time_gemm_pair: x terms have wrong size")
+    k = d + (1 if has_time else 0)
+    if tuple(Wa.shape) != (k, d) or tuple(Wb.shape) != (k, d) or out_a.numel() != n_rows * d or out_b.numel() != n_rows * d:
+        raise ValueError("gn_time_gemm_pair: weights must be (%d, %d) and outputs n x d" % (k, d))
+    lc = lincomb(x_terms)
+    check(lib.gode_gn_time_gemm_pair_f32(ctypes.byref(lc), n_rows, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(Wa), ptr(Wb),
+                                         1 if has_time else 0, float(t), ptr(out_a), ptr(out_b), ptr(x_out), stream_ptr()),
+          "gode_gn_time_gemm_pair_f32")
+
+
 def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS, out_scale=1.0, out=None,
                      want_affine_grads=True, pre_terms=None, parts=None):
     """Returns (dx, dgamma_part, dbeta_part); parts are [n_part, d_in] block partials (or None).

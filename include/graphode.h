@@ -130,6 +130,12 @@ int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin /* host */, int64_t n_r
                                const float* W, int64_t d_out, int has_time, float t,
                                float* S, float* x_out, void* stream);
 
+/* Two square products (d_out = d_in = d) over the same input in one launch: Sa = [t | xn] Wa, Sb = [t | xn] Wb
+ * (the two message projections of the GAT ODE function); x_out as above. */
+int gode_gn_time_gemm_pair_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                               const float* gamma, const float* beta, const float* Wa, const float* Wb,
+                               int has_time, float t, float* Sa, float* Sb, float* x_out, void* stream);
+
 /* VJP of the above w.r.t. x:  dxn = dS * W[has_time:,:]^T ; dx = GroupNorm'(x)^T dxn
  * out[i,:] = (sum_j pre.coef[j]*pre.ptr[j][i,:]) + out_scale * dx[i,:]
  *   (out_scale = 1, pre = NULL for a plain VJP; pre folds the RK combine of the adjoint state).
