@@ -118,6 +118,47 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(float* out, const flo
     }
 }
 
+// 16-byte form for long outputs (the weight-gradient reduction: 512 partials x 16 512 floats at d = 128): a block owns 64
+// outputs (16 lanes x float4, 256 contiguous bytes per partial row) and 16 part-groups stride the partials with four
+// loads in flight each; the groups are added in a fixed order.
+__global__ __launch_bounds__(256) void reduce_parts4_kernel(float* out, const float* part, int64_t n_part,
+                                                            int64_t len, float scale, int accumulate,
+                                                            float* out_b, const float* part_b) {
+    __shared__ float4 sm[16][17];
+    if (blockIdx.y == 1) { out = out_b; part = part_b; }
+    const int jj = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int64_t j = ((int64_t)blockIdx.x * 16 + jj) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < len) {
+        int64_t p = q;
+        for (; p + 48 < n_part; p += 64) {
+            const float4 a0 = *reinterpret_cast<const float4*>(part + p * len + j);
+            const float4 a1 = *reinterpret_cast<const float4*>(part + (p + 16) * len + j);
+            const float4 a2 = *reinterpret_cast<const float4*>(part + (p + 32) * len + j);
+            const float4 a3 = *reinterpret_cast<const float4*>(part + (p + 48) * len + j);
+            s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+            s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
+            s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
+            s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
+        }
+        for (; p < n_part; p += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(part + p * len + j);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
+    sm[q][jj] = s;
+    __syncthreads();
+    if (q == 0 && j < len) {
+        float4 t = sm[0][jj];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 a = sm[k][jj]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
+        t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
+        float4* o = reinterpret_cast<float4*>(out + j);
+        if (accumulate) { const float4 c = *o; t.x += c.x; t.y += c.y; t.z += c.z; t.w += c.w; }
+        *o = t;
+    }
+}
+
 // column sums with 16-B loads: thread owns 4 columns, TPR = d/4 threads cover a row.
 __global__ __launch_bounds__(256) void colsum4_kernel(float* part, const float* X, int64_t n_rows, int d, int64_t rpb) {
     const int tpr = d >> 2;
@@ -268,6 +309,12 @@ extern "C" int gode_reduce_parts_f32(float* out, const float* part, int64_t n_pa
     if (n_part < 0 || len < 0) return GODE_E_SHAPE;
     if (len == 0) return 0;
     if (!out || (n_part > 0 && !part)) return GODE_E_NULLPTR;
+    if (len >= 4096 && n_part >= 64 && len % 4 == 0 && !((((uintptr_t)out) | ((uintptr_t)part)) & 15)) {
+        hipLaunchKernelGGL(reduce_parts4_kernel, dim3((unsigned)((len / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                           out, part, n_part, len, scale, accumulate, (float*)nullptr, (const float*)nullptr);
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
                        out, part, n_part, len, scale, accumulate, (float*)nullptr, (const float*)nullptr);
     GODE_LAUNCH_CHECK();
