@@ -172,6 +172,18 @@ class GcnOdeField(Field):
         return sums
 
 
+class GcnOdePartField(GcnOdeField):
+    """The same field on a row-partitioned graph (partition.py): ops.spmm gathers the operand rows between the two
+    launches of an f-eval, so the whole-solve C drivers are not offered and the solver takes the per-stage path."""
+    rk4_native = None
+    dopri5_step_native = None
+    fixed_grid_only = True
+
+    def __init__(self, spec, shared):
+        GcnOdeField.__init__(self, spec, shared)
+        self.token = None
+
+
 class GcnOdeAdjointField(Field):
     """Components: [y, a, a_t, W, b, gamma, beta] (b may be absent -> never, FixedGC always has bias here)."""
     fused = True
@@ -283,6 +295,15 @@ class GcnOdeAdjointField(Field):
             ops.reduce_parts2_(out[5], dgp, out[6], dbp)
         else:
             out[5].zero_(); out[6].zero_()
+
+
+class GcnOdePartAdjointField(GcnOdeAdjointField):
+    """Adjoint on a row-partitioned graph: y and a are this rank's rows; the small components (a_t and the parameter
+    gradients) are PARTIAL sums over the local rows, summed over the ranks once per step by the caller
+    (GradBucket.allreduce_sum) - the adjoint ODE is linear in them, so the sum commutes with the integration."""
+    rk4_native = None
+    dopri5_step_native = None
+    fixed_grid_only = True
 
 
 class _OdeFuncFn(torch.autograd.Function):

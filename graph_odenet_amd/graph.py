@@ -152,8 +152,8 @@ def _evict(key):
 
 def as_graph(adj, split=DEFAULT_SPLIT):
     """Normalise `adj` (sparse COO / dense / CSRGraph); cached per tensor object."""
-    if isinstance(adj, CSRGraph):
-        return adj
+    if isinstance(adj, CSRGraph) or getattr(adj, "is_partitioned", False):
+        return adj                              # partition.PartitionedGraph: this rank's rows of A and A^T
     if not torch.is_tensor(adj):
         raise TypeError("adjacency must be a torch tensor (sparse COO or dense) or CSRGraph")
     key = id(adj)

@@ -24,7 +24,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .functional import GroupNorm, gn_time_linear, graph_aggregate
-from .gcn_ode import GcnOdeAdjointField, GcnOdeField, GcnOdeSpec, _Shared, odefunc_apply
+from .gcn_ode import (GcnOdeAdjointField, GcnOdeField, GcnOdePartAdjointField, GcnOdePartField, GcnOdeSpec, _Shared,
+                      odefunc_apply)
 from .graph import as_graph
 from .layers import FixedGraphConvolution, GraphConvolution
 from .odeint import odeint_adjoint as odeint
@@ -120,6 +121,8 @@ class ODEfunc(nn.Module):
         """Identity of the graph behind this ODE function (odeint keys its captured solves on it)."""
         if self.gc1.bias is None or y0.dim() != 2 or self.gc1.adj is None:
             return None
+        if getattr(self.gc1.adj, "is_partitioned", False):
+            return None                         # a collective per f-eval: no captured solve
         return ("gcn", id(as_graph(self.gc1.adj)))
 
     def gode_fields(self, y0):
@@ -136,6 +139,8 @@ class ODEfunc(nn.Module):
         names = {id(self.norm1.weight): "gamma", id(self.norm1.bias): "beta",
                  id(self.gc1.weight): "W", id(self.gc1.bias): "b"}
         order = [names[id(p)] for p in plist]
+        if getattr(spec.graph, "is_partitioned", False):
+            return GcnOdePartField(spec, sh), (lambda: GcnOdePartAdjointField(spec, sh, order)), tuple(plist)
         return GcnOdeField(spec, sh), (lambda: GcnOdeAdjointField(spec, sh, order)), tuple(plist)
 
 

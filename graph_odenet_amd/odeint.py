@@ -98,6 +98,9 @@ def _integrate(field, comps, t0, t1, rtol, atol, method, options, stats):
     if method == "rk4":
         stats.nfe += _run_rk4(field, comps, t0, t1, uniform_grid(t0, t1, (options or {}).get("step_size")))
     else:
+        if getattr(field, "fixed_grid_only", False):
+            raise NotImplementedError("odeint: a row-partitioned graph supports the fixed-grid method only "
+                                      "(method='rk4'); see graph_odenet_amd/partition.py")
         prep = getattr(field, "prepare", None)
         if prep is not None:
             prep()

@@ -39,6 +39,11 @@ def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None, p
     lib = _lib.load()
     _need(X, "X")
     _need(bias, "bias")
+    if getattr(graph, "is_partitioned", False):
+        # one graph over several GPUs (partition.py): all-gather the operand rows, then the local row block
+        if X.dim() != 2 or X.shape[0] != graph.n_cols:
+            raise ValueError("spmm: X has shape %s, this rank owns %d rows" % (tuple(X.shape), graph.n_cols))
+        X, graph = graph.gather(X), graph.local
     if X.dim() != 2 or X.shape[0] != graph.n_cols:
         raise ValueError("spmm: X has shape %s, graph is %d x %d" % (tuple(X.shape), graph.n_rows, graph.n_cols))
     d = X.shape[1]

@@ -17,7 +17,12 @@ def broadcast_parameters(module, src=0):
     if not ps:
         return
     flat = torch.cat([p.reshape(-1).float() for p in ps])
-    dist.broadcast(flat, src)
+    if dist.get_backend() == "gloo" and flat.is_cuda:               # one-box rehearsal: staged through the host
+        host = flat.cpu()
+        dist.broadcast(host, src)
+        flat = host.to(flat.device)
+    else:
+        dist.broadcast(flat, src)
     o = 0
     for p in ps:
         n = p.numel()
@@ -49,6 +54,13 @@ class GradBucket:
 
     def allreduce_mean(self):
         """grad <- mean over ranks.  Parameters without a gradient on this rank count as zero."""
+        self._allreduce(True)
+
+    def allreduce_sum(self):
+        """grad <- sum over ranks: the ranks hold partial sums of ONE model's gradient (partition.py)."""
+        self._allreduce(False)
+
+    def _allreduce(self, mean):
         if not dist.is_initialized() or dist.get_world_size() == 1:
             return
         for p, v in zip(self.params, self.views):
@@ -58,8 +70,14 @@ class GradBucket:
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
                 p.grad = v
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(dist.get_world_size())
+        if dist.get_backend() == "gloo" and self.flat.is_cuda:      # one-box rehearsal: staged through the host
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if mean:
+            self.flat.div_(dist.get_world_size())
 
 
 def shard_range(n_items, rank, world):

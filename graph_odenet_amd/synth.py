@@ -21,6 +21,19 @@ def rmat_edges(scale, n_edges, seed=0, abcd=(0.57, 0.19, 0.19, 0.05), device="cp
     return src, dst
 
 
+def rmat_coo(scale, n_edges, seed=0, device="cpu", self_loops=True, normalize=True):
+    """The matrix of rmat_graph as sorted COO triplets (rows, cols, values or None, n)."""
+    n = 1 << scale
+    src, dst = rmat_edges(scale, n_edges, seed, device=device)
+    if self_loops:
+        ar = torch.arange(n, device=device)
+        src = torch.cat([src, ar]); dst = torch.cat([dst, ar])
+    key = torch.unique(src * n + dst)
+    r, c = key // n, key % n
+    v = 1.0 / torch.bincount(r, minlength=n).to(torch.float32)[r] if normalize else None
+    return r, c, v, n
+
+
 def rmat_graph(scale, n_edges, seed=0, device="cpu", self_loops=True, normalize=True, split=None):
     """C5 of SURVEY.md §8(d): R-MAT, duplicates removed, self-loops added, row-normalised fp32."""
     n = 1 << scale

@@ -9,6 +9,15 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Multi-rank GPU tests (test_gpu_partition.py) fork their ranks from a helper process that is started HERE, before
+# anything in this process can have touched the GPU: a process that has initialised HIP must not fork+exec (the GPU
+# boxes refuse it), while children forked from the clean helper initialise the GPU themselves.
+try:
+    import multiprocessing.forkserver as _forkserver
+    _forkserver.ensure_running()
+except Exception:                                      # no forkserver on this platform: those tests skip
+    _forkserver = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
