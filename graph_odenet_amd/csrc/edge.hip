@@ -735,6 +735,92 @@ __global__ __launch_bounds__(256) void edge_matvec_bwd_kernel(const int* __restr
     }
 }
 
+// ---- H independent attention heads on one graph ------------------------------------------------------------------
+// The heads run as ONE head on the H-fold graph: virtual node v*H + h carries head h of node v (an N x H*o projection
+// matrix IS the (N*H) x o matrix of the virtual nodes), edge (s -> t) becomes the H edges (s*H+h -> t*H+h), and every
+// aggregation kernel above runs unchanged.  What does not carry over is the GLOBAL maximum of GAT/layers.py:47, which
+// is per head: the logits are shifted by their head's maximum here (so each head's maximum is exactly 0 and the
+// aggregation kernels are given amax = 0), and the gradient path through the maximum is applied per head.
+// Head of an edge = tgt % H.  Deterministic: maxima are order-free, sums run in a fixed order.
+constexpr int kMaxHeads = 64;
+constexpr int kHeadBlocks = 512;
+
+__device__ __forceinline__ int float_key(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float key_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+
+__global__ __launch_bounds__(256) void gat_logits_heads_part_kernel(Proj pv, const int* __restrict__ src,
+                                                                    const int* __restrict__ tgt, int n_edges, int H,
+                                                                    float* __restrict__ a, float* __restrict__ pmax) {
+    __shared__ int hm[kMaxHeads];
+    if (threadIdx.x < H) hm[threadIdx.x] = float_key(-INFINITY);
+    __syncthreads();
+    const int per = (n_edges + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n_edges, lo + per);
+    for (int e = lo + threadIdx.x; e < hi; e += 256) {
+        const int t = tgt[e];
+        const float v = pv.as[(int64_t)src[e] * pv.lda] + pv.at[(int64_t)t * pv.lda];
+        a[e] = v;
+        atomicMax(&hm[t % H], float_key(v));
+    }
+    __syncthreads();
+    if (threadIdx.x < H) pmax[blockIdx.x * H + threadIdx.x] = key_float(hm[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void gat_logits_heads_shift_kernel(const int* __restrict__ tgt, int n_edges, int H,
+                                                                     int n_part, const float* __restrict__ pmax,
+                                                                     float* __restrict__ a, float* __restrict__ hmax) {
+    __shared__ float hm[kMaxHeads];
+    if (threadIdx.x < H) {
+        float m = -INFINITY;
+        for (int b = 0; b < n_part; ++b) m = fmaxf(m, pmax[b * H + threadIdx.x]);
+        hm[threadIdx.x] = m;
+        if (blockIdx.x == 0 && hmax) hmax[threadIdx.x] = m;
+    }
+    __syncthreads();
+    const int per = (n_edges + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n_edges, lo + per);
+    for (int e = lo + threadIdx.x; e < hi; e += 256) a[e] -= hm[tgt[e] % H];
+}
+
+// per block and head: sum of da and first edge whose shifted logit is 0 (the head's arg-max)
+__global__ __launch_bounds__(256) void gat_maxpath_heads_part_kernel(const float* __restrict__ a, const float* __restrict__ da,
+                                                                     const int* __restrict__ tgt, int n_edges, int H,
+                                                                     float* __restrict__ psum, int* __restrict__ pidx) {
+    extern __shared__ float col[];                    // [H][256]: thread t accumulates its own column
+    __shared__ int hidx[kMaxHeads];
+    for (int h = 0; h < H; ++h) col[h * 256 + threadIdx.x] = 0.f;
+    if (threadIdx.x < H) hidx[threadIdx.x] = INT32_MAX;
+    __syncthreads();
+    const int per = (n_edges + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n_edges, lo + per);
+    for (int e = lo + threadIdx.x; e < hi; e += 256) {
+        const int h = tgt[e] % H;
+        col[h * 256 + threadIdx.x] += da[e];
+        if (a[e] == 0.f) atomicMin(&hidx[h], e);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int h = w; h < H; h += 4) {
+        const float* c = col + h * 256;
+        const float v = wave_sum((c[lane] + c[lane + 64]) + (c[lane + 128] + c[lane + 192]));
+        if (lane == 0) { psum[blockIdx.x * H + h] = v; pidx[blockIdx.x * H + h] = hidx[h]; }
+    }
+}
+
+__global__ __launch_bounds__(64) void gat_maxpath_heads_final_kernel(const float* __restrict__ psum, const int* __restrict__ pidx,
+                                                                     int n_part, int H, float* __restrict__ da, int n_edges,
+                                                                     const int* __restrict__ tgt, float* __restrict__ dat,
+                                                                     int64_t ld_dat) {
+    const int h = threadIdx.x;
+    if (h >= H) return;
+    float t = 0.f; int f = INT32_MAX;
+    for (int b = 0; b < n_part; ++b) { t += psum[b * H + h]; f = min(f, pidx[b * H + h]); }
+    if (f < n_edges) {
+        da[f] -= t;
+        if (dat) dat[(int64_t)tgt[f] * ld_dat] -= t;
+    }
+}
+
 int pow2_group(int o) { int G = 1; while (G < o && G < 64) G <<= 1; return G; }
 
 }  // namespace
@@ -941,6 +1027,67 @@ extern "C" int gode_gat_maxpath_f32(const float* a, const float* amax, float* da
     GODE_LAUNCH_CHECK();
     hipLaunchKernelGGL(gat_maxpath_final_kernel, dim3(1), dim3(64), 0, s, (const float*)psum, (const int*)pidx, (int)nb, da,
                        (int)n_edges, tgt, dat, ld_dat);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+int head_blocks(int64_t n_edges) {
+    int64_t b = (n_edges + 1023) / 1024; if (b > kHeadBlocks) b = kHeadBlocks; if (b < 1) b = 1;
+    return (int)b;
+}
+}  // namespace
+
+extern "C" int64_t gode_gat_heads_scratch_bytes(int64_t n_edges, int64_t heads) {
+    (void)n_edges;
+    if (heads < 1) heads = 1;
+    return (int64_t)kHeadBlocks * heads * (int64_t)(sizeof(float) + sizeof(int));
+}
+
+extern "C" int gode_gat_logits_heads_f32(const gode_gat_proj_t* proj, const int32_t* src, const int32_t* tgt,
+                                         int64_t n_edges, int64_t heads, float* a, float* hmax, void* scratch,
+                                         void* stream) {
+    if (!proj) return GODE_E_NULLPTR;
+    if (n_edges < 0 || heads < 1) return GODE_E_SHAPE;
+    if (heads > kMaxHeads) return GODE_E_UNSUPPORTED;
+    if (n_edges > INT32_MAX) return GODE_E_RANGE;
+    if (n_edges == 0) return 0;
+    const Proj pv = proj_of(proj);
+    if (!pv.as || !pv.at || !src || !tgt || !a || !scratch) return GODE_E_NULLPTR;
+    if (pv.lda < 1) return GODE_E_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = head_blocks(n_edges);
+    float* pmax = (float*)scratch;
+    hipLaunchKernelGGL(gat_logits_heads_part_kernel, dim3(nb), dim3(256), 0, s, pv, src, tgt, (int)n_edges, (int)heads, a, pmax);
+    GODE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_logits_heads_shift_kernel, dim3(nb), dim3(256), 0, s, tgt, (int)n_edges, (int)heads, nb,
+                       (const float*)pmax, a, hmax);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_gat_maxpath_heads_f32(const float* a, float* da, int64_t n_edges, int64_t heads, const int32_t* tgt,
+                                          float* dat, int64_t ld_dat, void* scratch, void* stream) {
+    if (n_edges < 0 || heads < 1) return GODE_E_SHAPE;
+    if (heads > kMaxHeads) return GODE_E_UNSUPPORTED;
+    if (n_edges > INT32_MAX) return GODE_E_RANGE;
+    if (n_edges == 0) return 0;
+    if (!a || !da || !tgt || !scratch) return GODE_E_NULLPTR;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = head_blocks(n_edges);
+    float* psum = (float*)scratch;
+    int* pidx = (int*)(psum + (int64_t)kHeadBlocks * heads);
+    static int lds_set = 0;
+    if (!lds_set) {
+        (void)hipFuncSetAttribute((const void*)gat_maxpath_heads_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kMaxHeads * 256 * (int)sizeof(float));
+        lds_set = 1;
+    }
+    hipLaunchKernelGGL(gat_maxpath_heads_part_kernel, dim3(nb), dim3(256), (size_t)heads * 256 * sizeof(float), s, a,
+                       (const float*)da, tgt, (int)n_edges, (int)heads, psum, pidx);
+    GODE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_maxpath_heads_final_kernel, dim3(1), dim3(64), 0, s, (const float*)psum, (const int*)pidx, nb,
+                       (int)heads, da, (int)n_edges, tgt, dat, ld_dat);
     GODE_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,368 @@
+"""H-head edge attention (BASELINE.json configs[2]: "Citeseer GAT 8-head ODEBlock rk4"; SURVEY.md §8(d) C3: "8
+independent reference-style heads batched").  The reference's layer (GAT/layers.py:11-63) has one head; an H-head
+layer here is H of those layers on the same graph with their outputs concatenated,
+
+    out = [ head_0(x) | head_1(x) | ... | head_{H-1}(x) ]          head_h : in_features -> out_features / H,
+
+each head with its own f / w Linear layers, its own global logit maximum (:47) and its own eps-regularised
+per-target normalisation (:53) - the parameters are literally H reference layers (`heads.<h>.f.weight`, ...).
+
+Execution: the H heads run as ONE head on the H-fold graph.  Virtual node v*H + h carries head h of node v, so the
+N x (H*o) projection matrices of all heads - produced by ONE dense product with the heads' weights side by side,
+square (d+1) x d inside an ODE function where H*o = d - ARE the (N*H) x o matrices of the virtual nodes, and the
+(N*H) x o result is the N x (H*o) concatenation: no copy in either direction.  Edge s -> t becomes the H edges
+s*H+h -> t*H+h.  Every aggregation / VJP / scatter kernel of the one-head path runs unchanged on that graph; the
+per-head maximum is handled by gode_gat_logits_heads_f32 (logits shifted by their head's maximum, the aggregation then
+runs with amax = 0) and gode_gat_maxpath_heads_f32 (gradient path through each head's maximum).  The per-head biases
+are folded into the target-side projections (z_e = Ps[src] + (Pt[tgt] + bf_h), a_e = As[src] + (At[tgt] + bw_h)).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.modules.module import Module
+
+from . import _lib, ops
+from . import models as _gcn_models
+from .gat_layers import EdgeGraph, GraphConvolution, edge_graph
+from .gat_ode import GatOdeAdjointField, GatOdeField
+from .models import _gn
+
+
+def heads_graph(eg, heads):
+    """The H-fold EdgeGraph of `eg` (cached on it)."""
+    cache = eg.__dict__.setdefault("_heads", {})
+    hit = cache.get(heads)
+    if hit is not None:
+        return hit
+    if not eg.canonical:
+        raise NotImplementedError("multi-head attention needs an Mtgt whose rows agree with tgt")
+    dev = eg.src.device
+    h = torch.arange(heads, device=dev)
+    src_v = (eg.src.to(torch.int64)[:, None] * heads + h).reshape(-1)
+    tgt_v = (eg.tgt.to(torch.int64)[:, None] * heads + h).reshape(-1)
+    ev = eg.E * heads
+    val = eg.Mt.val.repeat_interleave(heads) if eg.Mt.val is not None else torch.ones(ev, device=dev)
+    M = torch.sparse_coo_tensor(torch.stack([tgt_v, torch.arange(ev, device=dev)]), val, (eg.n * heads, ev))
+    egv = EdgeGraph(src_v, tgt_v, M)
+    if not egv.canonical:
+        raise RuntimeError("H-fold graph lost its target order")
+    egv.base, egv.heads = eg, heads
+    cache[heads] = egv
+    return egv
+
+
+class _EdgeAttentionHeadsFn(torch.autograd.Function):
+    """Concatenated outputs of H heads from Ps, Pt (N x H*o, biases folded into Pt) and A2 (N x 2H: per head the
+    logit part by source and by target, bias folded into the latter)."""
+
+    @staticmethod
+    def forward(ctx, egv, heads, Ps, Pt, A2, eps):
+        Ps, Pt, A2 = Ps.contiguous(), Pt.contiguous(), A2.contiguous()
+        n, d = Ps.shape
+        o, nv = d // heads, n * heads
+        f = dict(dtype=torch.float32, device=Ps.device)
+        a, zero = torch.empty(egv.E, **f), torch.zeros(1, **f)
+        out, w, den = torch.empty(n, d, **f), torch.empty(egv.E, **f), torch.empty(nv, **f)
+        proj = ops.gat_proj(Ps.view(nv, o), Pt.view(nv, o), A2.view(nv, 2))
+        ops.gat_logits_heads(proj, egv.src, egv.tgt, heads, a)
+        ops.gat_agg_fwd(egv, proj, o, torch.zeros(o, **f), a, zero, eps, out.view(nv, o), w, den)
+        ctx.egv, ctx.heads = egv, heads
+        ctx.save_for_backward(Ps, Pt, A2, a, w, den, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Ps, Pt, A2, a, w, den, out = ctx.saved_tensors
+        egv, heads = ctx.egv, ctx.heads
+        n, d = Ps.shape
+        o, nv = d // heads, n * heads
+        f = dict(dtype=torch.float32, device=Ps.device)
+        dz, da = torch.empty(egv.E, o, **f), torch.empty(egv.E, **f)
+        dPs, dPt, dA2 = torch.empty(n, d, **f), torch.empty(n, d, **f), torch.empty(n, 2 * heads, **f)
+        proj = ops.gat_proj(Ps.view(nv, o), Pt.view(nv, o), A2.view(nv, 2))
+        ops.gat_vjp(egv, proj, o, torch.zeros(o, **f), a, torch.zeros(1, **f), w, den, out.view(nv, o), dz, da,
+                    dPs.view(nv, o), dPt.view(nv, o), dA2.view(nv, 2), dout=dout.contiguous().view(nv, o), heads=heads)
+        return None, None, dPs, dPt, dA2, None
+
+
+class MultiHeadGraphConvolution(Module):
+    """`heads` reference layers (GAT/layers.py:11-63) on one graph, outputs concatenated."""
+
+    def __init__(self, in_features, out_features, heads=8, bias=True, act=F.relu, eps=1e-6):
+        super(MultiHeadGraphConvolution, self).__init__()
+        if heads < 1 or out_features % heads:
+            raise ValueError("MultiHeadGraphConvolution: %d heads do not divide %d output features" % (heads, out_features))
+        if heads > 64:
+            raise ValueError("MultiHeadGraphConvolution: at most 64 heads")
+        self.in_features, self.out_features, self.n_heads = in_features, out_features, heads
+        self.eps, self.act = eps, act
+        self.heads = nn.ModuleList([GraphConvolution(in_features, out_features // heads, bias, act, eps)
+                                    for _ in range(heads)])
+
+    def packed(self):
+        """(Wsrc, Wtgt: i x H*o;  Wlog: i x 2H;  bf: H*o;  ba: 2H = [0, bw_0, 0, bw_1, ...]) as differentiable
+        functions of the heads' parameters."""
+        i = self.in_features
+        Wsrc = torch.cat([hd.f.weight[:, :i].t() for hd in self.heads], 1)
+        Wtgt = torch.cat([hd.f.weight[:, i:].t() for hd in self.heads], 1)
+        Wlog = torch.cat([torch.stack([hd.w.weight[0, :i], hd.w.weight[0, i:]], 1) for hd in self.heads], 1)
+        bf = torch.cat([hd.f.bias for hd in self.heads])
+        ba = torch.cat([torch.cat([torch.zeros_like(hd.w.bias), hd.w.bias]) for hd in self.heads])
+        return Wsrc, Wtgt, Wlog, bf, ba
+
+    def forward(self, x, src, tgt, Mtgt):
+        return _heads_forward(self, x, src, tgt, Mtgt)
+
+    def __repr__(self):
+        return "%s (%d -> %d, %d heads)" % (self.__class__.__name__, self.in_features, self.out_features, self.n_heads)
+
+
+def _heads_forward(layer, x, src, tgt, Mtgt):
+    if layer.act is not F.relu:
+        raise NotImplementedError("graph_odenet_amd GAT layer: only act=F.relu (the reference default) is fused")
+    eg = edge_graph(src, tgt, Mtgt)
+    Wsrc, Wtgt, Wlog, bf, ba = layer.packed()
+    Ps, Pt, A2 = torch.mm(x, Wsrc), torch.mm(x, Wtgt) + bf, torch.mm(x, Wlog) + ba
+    if eg.E == 0:
+        return torch.zeros(x.shape[0], layer.out_features, dtype=x.dtype, device=x.device) + 0.0 * (Ps.sum() + Pt.sum() + A2.sum())
+    return _EdgeAttentionHeadsFn.apply(heads_graph(eg, layer.n_heads), layer.n_heads, Ps, Pt, A2, layer.eps)
+
+
+class FixedMultiHeadGraphConvolution(MultiHeadGraphConvolution):
+    """The same layer with (src, tgt, Mtgt) held as attributes (the role of GAT/layers.py:67-127)."""
+
+    def __init__(self, in_features, out_features, heads=8, bias=True, act=F.relu, eps=1e-6):
+        super(FixedMultiHeadGraphConvolution, self).__init__(in_features, out_features, heads, bias, act, eps)
+        self.src = self.tgt = self.Mtgt = torch.Tensor([[1]])
+
+    def set_adj(self, src, tgt, Mtgt):
+        self.src, self.tgt, self.Mtgt = src, tgt, Mtgt
+
+    def forward(self, x):
+        return _heads_forward(self, x, self.src, self.tgt, self.Mtgt)
+
+
+# ---- fused ODE function -------------------------------------------------------------------------------------------
+class GatHeadsSpec:
+    """Packed description of ODEfunc(dim, heads): theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta] with
+    Wsrc, Wtgt (d+1) x d (head h in columns h*o..), Wlog (d+1) x 2H, bf d, bw H."""
+
+    def __init__(self, egv, layer, norm):
+        self.eg, self.layer, self.norm = egv, layer, norm           # eg: the H-fold graph (what the kernels see)
+        self.heads = layer.n_heads
+        self.d, self.i = layer.out_features, layer.in_features
+        if self.i != self.d + 1:
+            raise ValueError("GatHeadsSpec: the ODE layer maps d+1 -> d features")
+        self.o = self.d // self.heads
+        self.groups, self.eps_gn, self.eps = int(norm.num_groups), float(norm.eps), float(layer.eps)
+        dev = norm.weight.device
+        f = dict(dtype=torch.float32, device=dev)
+        i, d, H = self.i, self.d, self.heads
+        self.Wsrc, self.Wtgt, self.Wlog = torch.empty(i, d, **f), torch.empty(i, d, **f), torch.empty(i, 2 * H, **f)
+        self.bf, self.ba = torch.empty(d, **f), torch.zeros(2 * H, **f)
+        self.refresh()
+        self.gamma, self.beta = norm.weight.detach(), norm.bias.detach()
+        self.n = egv.base.n
+        self.off, p = {}, 0
+        for name, ln in (("Wsrc", i * d), ("Wtgt", i * d), ("Wlog", i * 2 * H), ("bf", d), ("bw", H), ("gamma", d), ("beta", d)):
+            self.off[name] = (p, p + ln)
+            p += ln
+        self.n_theta = p
+
+    def refresh(self):
+        with torch.no_grad():
+            Wsrc, Wtgt, Wlog, bf, ba = self.layer.packed()
+            self.Wsrc.copy_(Wsrc); self.Wtgt.copy_(Wtgt); self.Wlog.copy_(Wlog); self.bf.copy_(bf); self.ba.copy_(ba)
+
+    def views(self, theta):
+        v = {k: theta[a:b] for k, (a, b) in self.off.items()}
+        v["Wsrc"], v["Wtgt"] = v["Wsrc"].view(self.i, self.d), v["Wtgt"].view(self.i, self.d)
+        v["Wlog"] = v["Wlog"].view(self.i, 2 * self.heads)
+        return v
+
+
+class _HeadsWork:
+    def __init__(self, spec, device):
+        n, d, o, H, E = spec.n, spec.d, spec.o, spec.heads, spec.eg.E
+        nv = n * H
+        lib = _lib.load()
+        f = dict(dtype=torch.float32, device=device)
+        self.X = torch.empty(n, d, **f)
+        self.Ps, self.Pt, self.A2 = torch.empty(n, d, **f), torch.empty(n, d, **f), torch.empty(n, 2 * H, **f)
+        self.dPs, self.dPt, self.dA2 = torch.empty(n, d, **f), torch.empty(n, d, **f), torch.empty(n, 2 * H, **f)
+        self.a, self.zero, self.bf0 = torch.empty(max(E, 1), **f)[:E], torch.zeros(1, **f), torch.zeros(o, **f)
+        self.wgt, self.den = torch.zeros(max(E, 1), **f)[:E], torch.empty(nv, **f)
+        self.dz, self.da = torch.zeros(max(E, 1), o, **f)[:E], torch.zeros(max(E, 1), **f)[:E]
+        self.proj = ops.gat_proj(self.Ps.view(nv, o), self.Pt.view(nv, o), self.A2.view(nv, 2))
+        self.np_b = lib.gode_gemm_bwd_parts(n)
+        self.gp, self.bp = torch.empty(3 * self.np_b, d, **f), torch.empty(3 * self.np_b, d, **f)
+        npw = lib.gode_wgrad_parts(n)
+        self.wp = [torch.empty(npw, spec.i * d, **f), torch.empty(npw, spec.i * d, **f), torch.empty(npw, spec.i * 2 * H, **f)]
+        self.ba_grad = torch.empty(2 * H, **f)
+
+
+class GatHeadsField(GatOdeField):
+    """f(t, x) = relu(heads([t | GroupNorm(x)])) as a kernel sequence (the one-head sequence of gat_ode.py on the
+    H-fold graph).  The C-level dopri5 step is not offered: the adaptive solver takes the per-stage path."""
+    dopri5_step_native = None
+
+    def __init__(self, spec, work):
+        self.s, self.w = spec, work
+        self.token = ("gat-heads", id(spec.eg))
+
+    def _project(self, t, y_terms):
+        s, w = self.s, self.w
+        x_out = w.X if len(y_terms) > 1 else None
+        ops.gn_time_gemm_pair(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, True, t, w.Ps, w.Pt,
+                              x_out=x_out)
+        terms = [(1.0, w.X)] if x_out is not None else y_terms
+        ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog, True, t, out=w.A2)
+        w.Pt.add_(s.bf)                                  # per-head biases, folded into the target-side parts
+        w.A2.add_(s.ba)
+        return terms
+
+    def _forward(self, t, y_terms, out):
+        s, w, eg = self.s, self.w, self.s.eg
+        terms = self._project(t, y_terms)
+        ops.gat_logits_heads(w.proj, eg.src, eg.tgt, s.heads, w.a)
+        ops.gat_agg_fwd(eg, w.proj, s.o, w.bf0, w.a, w.zero, s.eps, out.view(s.n * s.heads, s.o), w.wgt, w.den)
+        return terms
+
+
+class GatHeadsAdjointField(GatHeadsField):
+    """Components [y, a, a_t, theta], theta laid out as GatHeadsSpec.off."""
+
+    def __init__(self, spec, work, order):
+        GatHeadsField.__init__(self, spec, work)
+        self.order = order
+        self.n_components = 4
+        self.ratio_groups = [[0], [1], [2], [3]]
+
+    new_state = GatOdeAdjointField.new_state
+
+    def param_grads(self, comps):
+        s = self.s
+        i, o = s.i, s.o
+        v = s.views(comps[3])
+        m = {"gamma": v["gamma"].clone(), "beta": v["beta"].clone()}
+        for h in range(s.heads):
+            c = slice(h * o, (h + 1) * o)
+            m["Wf%d" % h] = torch.cat([v["Wsrc"][:, c].t(), v["Wtgt"][:, c].t()], 1).contiguous()        # o x 2i
+            m["bf%d" % h] = v["bf"][c].clone()
+            m["ww%d" % h] = torch.cat([v["Wlog"][:, 2 * h], v["Wlog"][:, 2 * h + 1]]).view(1, 2 * i).contiguous()
+            m["bw%d" % h] = v["bw"][h:h + 1].clone()
+        return [m[k] for k in self.order]
+
+    def eval(self, t, terms, out):
+        s, w = self.s, self.w
+        eg, n, d, H = s.eg, s.n, s.d, s.heads
+        nv, o = n * H, s.o
+        xt = self._forward(t, terms[0], out[0])
+        g = s.views(out[3])
+        ops.gat_vjp(eg, w.proj, o, w.bf0, w.a, w.zero, w.wgt, w.den, out[0].view(nv, o), w.dz, w.da, w.dPs.view(nv, o),
+                    w.dPt.view(nv, o), w.dA2.view(nv, 2), cot_terms=terms[1], cot_scale=-1.0, heads=H)
+        ops.colsum_(g["bf"], w.dPt)                      # biases sit on the target side: column sums of its gradient
+        ops.colsum_(w.ba_grad, w.dA2)
+        g["bw"].copy_(w.ba_grad[1::2])
+        nb = w.np_b
+        affine = s.groups > 0
+        for j, (Wj, dPj) in enumerate(((s.Wsrc, w.dPs), (s.Wtgt, w.dPt), (s.Wlog, w.dA2))):
+            ops.gn_time_gemm_bwd(xt, n, d, s.groups, s.eps_gn, s.gamma, Wj, True, dPj, out=out[1],
+                                 pre_terms=[(1.0, out[1])] if j else None,
+                                 parts=(w.gp[j * nb:(j + 1) * nb], w.bp[j * nb:(j + 1) * nb]) if affine else None)
+        if affine:
+            ops.reduce_parts2_(g["gamma"], w.gp, g["beta"], w.bp)
+        else:
+            g["gamma"].zero_(); g["beta"].zero_()
+        for j, dPj in enumerate((w.dPs, w.dPt, w.dA2)):
+            ops.wgrad(xt, n, d, s.groups, s.eps_gn, s.gamma, s.beta, dPj, True, part=w.wp[j])
+        ops.reduce_parts2_(g["Wsrc"].view(-1), w.wp[0], g["Wtgt"].view(-1), w.wp[1])
+        ops.reduce_parts_(g["Wlog"].view(-1), w.wp[2])
+        ops.time_row_fixup3_([g["Wsrc"][0], g["Wtgt"][0], g["Wlog"][0]], [s.Wsrc[0], s.Wtgt[0], s.Wlog[0]], t, out[2])
+
+
+class ODEfunc(nn.Module):
+    """relu(gc1([t | norm1(x)])) with an H-head layer: GAT/models.py:161-179 with `heads` reference layers side by
+    side (dim must be a multiple of heads)."""
+
+    _gode_counts_nfe = True
+
+    def __init__(self, dim, heads=8):
+        super(ODEfunc, self).__init__()
+        self.norm1 = _gn(dim)
+        self.gc1 = FixedMultiHeadGraphConvolution(dim + 1, dim, heads)
+        self.nfe = 0
+
+    def set_adj(self, src, tgt, Mtgt):
+        self.gc1.set_adj(src, tgt, Mtgt)
+
+    def forward(self, t, x):
+        self.nfe += 1
+        xn = self.norm1(x)
+        return F.relu(self.gc1(torch.cat([torch.ones_like(xn[:, :1]) * t, xn], 1)))
+
+    def _egv(self):
+        layer = self.gc1
+        if not torch.is_tensor(layer.src) or layer.src.dim() != 1:
+            return None
+        eg = edge_graph(layer.src, layer.tgt, layer.Mtgt)
+        return heads_graph(eg, layer.n_heads) if eg.canonical and eg.E > 0 else None
+
+    def gode_plan_token(self, y0):
+        egv = self._egv()
+        return None if egv is None else ("gat-heads", id(egv))
+
+    def gode_fields(self, y0):
+        layer, norm = self.gc1, self.norm1
+        egv = self._egv()
+        if egv is None or layer.act is not F.relu or y0.dim() != 2 or egv.base.n != y0.shape[0]:
+            return None
+        plist = [p for p in self.parameters() if p.requires_grad]
+        names = {id(norm.weight): "gamma", id(norm.bias): "beta"}
+        for h, hd in enumerate(layer.heads):
+            names.update({id(hd.f.weight): "Wf%d" % h, id(hd.f.bias): "bf%d" % h, id(hd.w.weight): "ww%d" % h,
+                          id(hd.w.bias): "bw%d" % h})
+        if len(plist) != len(names) or any(id(p) not in names for p in plist):
+            return None
+        key = ("heads", layer.out_features, y0.device)
+        spec = GatHeadsSpec(egv, layer, norm)
+        work = egv.__dict__.setdefault("_ode_work", {}).get(key)
+        if work is None:
+            work = egv.__dict__["_ode_work"][key] = _HeadsWork(spec, y0.device)
+        order = [names[id(p)] for p in plist]
+        return GatHeadsField(spec, work), (lambda: GatHeadsAdjointField(spec, work, order)), tuple(plist)
+
+
+# ---- model zoo ----------------------------------------------------------------------------------------------------
+_zoos = {}
+
+
+def zoo(heads=8):
+    """The 23 model classes of the GAT variant with H-head layers wherever `heads` divides the layer's output width
+    (the hidden layers and the ODE block; a class-count output layer that it does not divide keeps one head, as in
+    the usual GAT output layer).  Returns a namespace object with the classes as attributes."""
+    hit = _zoos.get(heads)
+    if hit is not None:
+        return hit
+
+    def layer(in_features, out_features, *args, **kw):
+        if out_features % heads == 0:
+            return MultiHeadGraphConvolution(in_features, out_features, heads, *args, **kw)
+        return GraphConvolution(in_features, out_features, *args, **kw)
+
+    def odefunc(dim):
+        return ODEfunc(dim, heads)
+
+    def odefunc2(dim, dropout):
+        raise NotImplementedError("the two-layer ODE function (ODEK2) has no multi-head form here")
+
+    kit = type("GatHeadsKit%d" % heads, (), {"GraphConvolution": staticmethod(layer), "ODEfunc": staticmethod(odefunc),
+                                             "ODEfunc2": staticmethod(odefunc2), "input_dropout": False})
+
+    def _forward(self, x, src, tgt, Mtgt):
+        return self._body(self._input(x), (src, tgt, Mtgt))
+
+    ns = {}
+    _gcn_models.rebind_zoo(ns, __name__, kit, forward=_forward, what="%d-head GAT" % heads)
+    out = _zoos[heads] = type("GatHeadsZoo%d" % heads, (), ns)
+    return out

@@ -324,10 +324,22 @@ def gat_agg_fwd(eg, proj, o, bf, a, amax, eps, out, w, den):
                                    ptr(amax), float(eps), ptr(out), ptr(w), ptr(den), stream_ptr()), "gode_gat_agg_f32_fwd")
 
 
-def gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=None, cot_terms=None, cot_scale=1.0):
+def gat_logits_heads(proj, src, tgt, heads, a, hmax=None):
+    """Logits of the H-fold graph (gat_heads.py), shifted by the maximum of their head (tgt % heads)."""
+    lib = _lib.load()
+    _need(a, "a"); _need(hmax, "hmax")
+    E = src.numel()
+    sc = _scratch(a.device, lib.gode_gat_heads_scratch_bytes(E, heads))
+    check(lib.gode_gat_logits_heads_f32(ctypes.byref(proj), ptr(src), ptr(tgt), E, int(heads), ptr(a), ptr(hmax), ptr(sc),
+                                        stream_ptr()), "gode_gat_logits_heads_f32")
+
+
+def gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=None, cot_terms=None, cot_scale=1.0,
+            heads=1):
     """Vector-Jacobian product of the edge-attention aggregation w.r.t. the projections: fills dz[E, o], da[E] (with the
     path through the global maximum folded in), dPs, dPt (N x o) and dA2 (N x 2).  The cotangent is `dout`, or
-    cot_scale * (sum cot_terms) masked by out > 0."""
+    cot_scale * (sum cot_terms) masked by out > 0.  heads > 1: `eg` is the H-fold graph, `a` holds logits shifted
+    per head and the path through the maximum is applied per head."""
     lib = _lib.load()
     for t, nm in ((out, "out"), (dz, "dz"), (da, "da"), (dout, "dout"), (dPs, "dPs"), (dPt, "dPt"), (dA2, "dA2")):
         _need(t, nm)
@@ -345,7 +357,12 @@ def gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=N
                                    ptr(den), ptr(out), ptr(dout), ctypes.byref(lc) if lc is not None else None,
                                    float(cot_scale), ptr(dz), ptr(da), ptr(dPt), o, at_ptr, 2, ctypes.byref(did),
                                    stream_ptr()), "gode_gat_agg_f32_bwd")
-    if eg.E > 0:                                                   # path through the global max (GAT/layers.py:47)
+    if eg.E > 0 and heads > 1:
+        big = bool(did.value)
+        sc = _scratch(a.device, lib.gode_gat_heads_scratch_bytes(eg.E, heads))
+        check(lib.gode_gat_maxpath_heads_f32(ptr(a), ptr(da), eg.E, int(heads), ptr(eg.tgt), at_ptr if big else None, 2,
+                                             ptr(sc), stream_ptr()), "gode_gat_maxpath_heads_f32")
+    elif eg.E > 0:                                                 # path through the global max (GAT/layers.py:47)
         big = bool(did.value)
         check(lib.gode_gat_maxpath_f32(ptr(a), ptr(amax), ptr(da), eg.E, ptr(eg.tgt) if big else None,
                                        at_ptr if big else None, 2, ptr(eg.maxpath_scratch()), stream_ptr()),

@@ -270,7 +270,7 @@ if __name__ == "__main__":
         sys.modules.setdefault("scipy.sparse.linalg.eigen", types.ModuleType("scipy.sparse.linalg.eigen"))
         sys.modules["scipy.sparse.linalg.eigen.arpack"] = alias
         pubmed_topology()
-    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth", "gat_zoo", "variants", "gat_edges", "train_traj"):
+    elif os.environ.get("GOLDEN_ONLY") not in ("qc_models", "set2set", "depth", "gat_zoo", "gat_heads", "variants", "gat_edges", "train_traj"):
         main()
         pubmed_topology()
         qc_models_golden()
@@ -393,6 +393,34 @@ def gat_zoo_golden():
         for k, p in mdl.state_dict().items():
             res[name + "__sd__" + k.replace(".", "__")] = p
     save("gat_zoo.npz", **res)
+
+
+def gat_heads_golden():
+    """H = 4 instances of the reference's GAT layer (GAT/layers.py GraphConvolution) on one 50-node / 220-edge random
+    multigraph, outputs concatenated: forward, and the gradients of a random cotangent w.r.t. the input and every
+    head's parameters.  The last nodes receive no edge; head 2 gets a large logit bias so that the heads' maxima differ
+    by far more than eps resolves."""
+    (glayers,) = ref_import("GAT", "layers")
+    n, E, nin, H, o = 50, 220, 12, 4, 5
+    gen = torch.Generator().manual_seed(31)
+    src = torch.randint(0, n, (E,), generator=gen)
+    tgt = torch.randint(0, n - 3, (E,), generator=gen)
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+    x = torch.randn(n, nin, generator=gen).requires_grad_(True)
+    gout = torch.randn(n, H * o, generator=gen)
+    torch.manual_seed(32)
+    layers = [glayers.GraphConvolution(nin, o) for _ in range(H)]
+    with torch.no_grad():
+        layers[2].w.bias.add_(7.5)
+        layers[1].w.weight.mul_(4.0)
+    out = torch.cat([l(x, src, tgt, Mtgt) for l in layers], 1)
+    out.backward(gout)
+    res = dict(src=src, tgt=tgt, n=n, x=x, gout=gout, out=out, gx=x.grad)
+    for h, l in enumerate(layers):
+        for k, p in l.named_parameters():
+            res["h%d__%s" % (h, k.replace(".", "__"))] = p
+            res["h%d__grad__%s" % (h, k.replace(".", "__"))] = p.grad
+    save("gat_heads.npz", **res)
 
 
 def variants_golden():
@@ -560,6 +588,9 @@ if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "gat_edges":
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "variants":
     sys.dont_write_bytecode = True
     variants_golden()
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "gat_heads":
+    gat_heads_golden()
+
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "gat_zoo":
     sys.dont_write_bytecode = True
     gat_zoo_golden()

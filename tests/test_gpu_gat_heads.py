@@ -1,0 +1,210 @@
+"""H-head edge attention (graph_odenet_amd/gat_heads.py; BASELINE.json configs[2] "Citeseer GAT 8-head ODEBlock rk4"):
+the product path through the C ABI against H instances of the reference's layer (golden), and against the oracle
+solver driving the oracle H-head ODE function on Citeseer's real edge list."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, tol, what=""):
+    a, b = a.detach().cpu().double(), (b.detach().cpu() if torch.is_tensor(b) else T(b)).double()
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), "%s: max abs err %.3e" % (what, err)
+
+
+def _load_heads(layer, g, H):
+    for h in range(H):
+        hd = layer.heads[h]
+        hd.f.weight.data.copy_(T(g["h%d__f__weight" % h])); hd.f.bias.data.copy_(T(g["h%d__f__bias" % h]))
+        hd.w.weight.data.copy_(T(g["h%d__w__weight" % h])); hd.w.bias.data.copy_(T(g["h%d__w__bias" % h]))
+
+
+def test_multihead_layer_vs_reference_golden(golden):
+    from graph_odenet_amd.gat_heads import MultiHeadGraphConvolution
+    g = golden("gat_heads.npz")
+    n, H = int(g["n"]), 4
+    src, tgt = T(g["src"]).long(), T(g["tgt"]).long()
+    E = src.numel()
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+    layer = MultiHeadGraphConvolution(12, 20, heads=H)
+    _load_heads(layer, g, H)
+    layer = layer.to(dev())
+    x = T(g["x"]).to(dev()).requires_grad_(True)
+    out = layer(x, src.to(dev()), tgt.to(dev()), Mtgt.to(dev()))
+    close(out, g["out"], 1e-5, "out")
+    out.backward(T(g["gout"]).to(dev()))
+    close(x.grad, g["gx"], 1e-5, "gx")
+    for h in range(H):
+        hd = layer.heads[h]
+        for p, k in ((hd.f.weight, "f__weight"), (hd.f.bias, "f__bias"), (hd.w.weight, "w__weight"), (hd.w.bias, "w__bias")):
+            close(p.grad, g["h%d__grad__%s" % (h, k)], 1e-5, "head %d %s" % (h, k))
+
+
+def test_one_head_equals_the_single_head_layer(golden):
+    from graph_odenet_amd.gat_heads import MultiHeadGraphConvolution
+    from graph_odenet_amd.gat_layers import GraphConvolution
+    g = golden("gat_heads.npz")
+    n = int(g["n"])
+    src, tgt = T(g["src"]).long().to(dev()), T(g["tgt"]).long().to(dev())
+    E = src.numel()
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E, device=dev())]), torch.ones(E, device=dev()), (n, E))
+    torch.manual_seed(0)
+    one = GraphConvolution(12, 7).to(dev())
+    multi = MultiHeadGraphConvolution(12, 7, heads=1).to(dev())
+    multi.heads[0].load_state_dict(one.state_dict())
+    x = T(g["x"]).to(dev())
+    close(multi(x, src, tgt, Mtgt), one(x, src, tgt, Mtgt), 1e-6, "H=1")
+
+
+def _citeseer(golden):
+    ge = golden("citeseer_gat_edges.npz")
+    n = int(ge["n"])
+    src, tgt = T(ge["src"]).long(), T(ge["tgt"]).long()
+    Mtgt = torch.sparse_coo_tensor(torch.stack([T(ge["m_rows"]).long(), T(ge["m_cols"]).long()]), T(ge["m_vals"]),
+                                   (n, src.numel()))
+    return n, src, tgt, Mtgt
+
+
+@pytest.mark.parametrize("method,kw,small", [("rk4", dict(step_size=0.25), False), ("dopri5", {}, True)])
+def test_eight_head_ode_block_vs_oracle_on_citeseer_edges(golden, method, kw, small):
+    """configs[2]: Citeseer's edge list, 8 heads x 16 features, ODEBlock; forward and parameter gradients against
+    the oracle's adjoint solver driving the oracle heads (same algorithm end to end)."""
+    from graph_odenet_amd.gat_heads import ODEfunc
+    from graph_odenet_amd.models import ODEBlock
+    from oracle import layers_ref as R, solver_ref as S
+    if small:                 # the adaptive solver on the 50-node golden graph: the CPU oracle takes every step too
+        g = golden("gat_heads.npz")
+        n, src, tgt = int(g["n"]), T(g["src"]).long(), T(g["tgt"]).long()
+        Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(src.numel())]), torch.ones(src.numel()), (n, src.numel()))
+        d, H, tol = 32, 4, 1e-5
+    else:
+        n, src, tgt, Mtgt = _citeseer(golden)
+        d, H, tol = 128, 8, 1e-6
+    torch.manual_seed(5)
+    blk = ODEBlock(ODEfunc(d, H), method=method, tol=tol, **kw)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    x0 = torch.randn(n, d) * 0.5
+
+    class F(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gn = torch.nn.ParameterList([torch.nn.Parameter(sd["odefunc.norm1." + k].clone()) for k in ("weight", "bias")])
+            self.hp = torch.nn.ParameterList([torch.nn.Parameter(sd["odefunc.gc1.heads.%d.%s" % (h, k)].clone())
+                                              for h in range(H) for k in ("f.weight", "f.bias", "w.weight", "w.bias")])
+
+        def forward(self, t, x):
+            heads = [list(self.hp[4 * h:4 * h + 4]) for h in range(H)]
+            return R.gat_multihead_odefunc(t, x, src, tgt, Mtgt, self.gn[0], self.gn[1], heads)
+    f = F()
+    opts = dict(options={"step_size": 0.25}) if method == "rk4" else {}
+    ref = S.odeint_adjoint(f, x0, torch.tensor([0., 1.]), tol, tol, method, opts.get("options"))[1]
+    gout = torch.randn(n, d, generator=torch.Generator().manual_seed(6))
+    ref.backward(gout)
+    blk = blk.to(dev())
+    xg = x0.to(dev()).requires_grad_(True)
+    out = blk(xg, src.to(dev()), tgt.to(dev()), Mtgt.to(dev()))
+    close(out, ref, 2e-5, "8-head %s forward" % method)
+    out.backward(gout.to(dev()))
+    gtol = 2e-4 if method == "rk4" else 5e-3      # adaptive steps: accept / reject decisions in fp32 on both sides
+    close(blk.odefunc.norm1.weight.grad, f.gn[0].grad, gtol, "dgamma")
+    close(blk.odefunc.norm1.bias.grad, f.gn[1].grad, gtol, "dbeta")
+    for h in (0, H // 2, H - 1):
+        hd = blk.odefunc.gc1.heads[h]
+        for j, p in enumerate((hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias)):
+            close(p.grad, f.hp[4 * h + j].grad, gtol, "head %d param %d" % (h, j))
+    # a second and third call replay the captured solve (rk4): same numbers
+    if method == "rk4":
+        for _ in range(2):
+            out2 = blk(xg, src.to(dev()), tgt.to(dev()), Mtgt.to(dev()))
+        close(out2, out, 1e-6, "captured replay")
+
+
+def test_fused_fields_agree_with_autograd_through_the_layer(golden):
+    """The fused adjoint (kernel sequence on packed parameters) against autograd through ODEfunc.forward."""
+    from graph_odenet_amd.gat_heads import ODEfunc
+    from graph_odenet_amd.models import ODEBlock
+    n, src, tgt, Mtgt = _citeseer(golden)
+    src, tgt, Mtgt = src.to(dev()), tgt.to(dev()), Mtgt.to(dev())
+    d, H = 32, 4
+    torch.manual_seed(8)
+    blk = ODEBlock(ODEfunc(d, H), method="rk4", step_size=0.5).to(dev())
+    x = torch.randn(n, d, device=dev())
+    gout = torch.randn(n, d, device=dev())
+    out = blk(x.clone().requires_grad_(True), src, tgt, Mtgt)
+    out.backward(gout)
+    fused = [p.grad.clone() for p in blk.parameters()]
+    for p in blk.parameters():
+        p.grad = None
+    type(blk.odefunc).gode_fields_saved = type(blk.odefunc).gode_fields
+    try:
+        type(blk.odefunc).gode_fields = lambda self, y0: None        # generic autograd fields
+        out2 = blk(x.clone().requires_grad_(True), src, tgt, Mtgt)
+        out2.backward(gout)
+    finally:
+        type(blk.odefunc).gode_fields = type(blk.odefunc).gode_fields_saved
+        del type(blk.odefunc).gode_fields_saved
+    close(out2, out, 1e-5, "forward")
+    for (nm, p), gf in zip(blk.named_parameters(), fused):
+        close(p.grad, gf, 1e-4, nm)
+
+
+def test_eight_head_model_trains_on_citeseer_edges(golden):
+    from graph_odenet_amd import gat_heads
+    n, src, tgt, Mtgt = _citeseer(golden)
+    src, tgt, Mtgt = src.to(dev()), tgt.to(dev()), Mtgt.to(dev())
+    zoo = gat_heads.zoo(8)
+    torch.manual_seed(1)
+    m = zoo.ODEGCN3(nfeat=50, nhid=64, nclass=6, dropout=0.0, method="rk4", step_size=0.25).to(dev())
+    assert type(m.gc1).__name__ == "MultiHeadGraphConvolution" and type(m.gc3).__name__ == "GraphConvolution"
+    x = torch.randn(n, 50, device=dev())
+    y = torch.randint(0, 6, (n,), device=dev())
+    opt = torch.optim.Adam(m.parameters(), lr=0.01)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss = torch.nn.functional.nll_loss(m(x, src, tgt, Mtgt), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_heads_on_the_record_path():
+    """Above 65 536 virtual targets the aggregation runs on the nnz-balanced record kernels (target sums formed in
+    the kernel, per-head maximum correction applied to them): against the fp64 oracle."""
+    from graph_odenet_amd.gat_heads import MultiHeadGraphConvolution
+    from oracle import layers_ref as R
+    n, E, H, nin, o = 20000, 90000, 4, 16, 16
+    g = torch.Generator().manual_seed(2)
+    src = torch.randint(0, n, (E,), generator=g)
+    tgt = torch.cat([torch.randint(0, n, (E - 3000,), generator=g), torch.zeros(3000, dtype=torch.int64)])   # one hub
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+    torch.manual_seed(3)
+    layer = MultiHeadGraphConvolution(nin, H * o, heads=H)
+    x = torch.randn(n, nin, generator=g)
+    gout = torch.randn(n, H * o, generator=g)
+    xd = x.double().requires_grad_(True)
+    heads = [[p.detach().double().requires_grad_(True) for p in (hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias)]
+             for hd in layer.heads]
+    ref = R.gat_multihead_layer(xd, src, tgt, Mtgt.double(), heads)
+    ref.backward(gout.double())
+    layer = layer.to(dev())
+    xg = x.to(dev()).requires_grad_(True)
+    out = layer(xg, src.to(dev()), tgt.to(dev()), Mtgt.to(dev()))
+    close(out, ref, 1e-5, "out")
+    out.backward(gout.to(dev()))
+    close(xg.grad, xd.grad, 2e-5, "gx")
+    for h in range(H):
+        hd = layer.heads[h]
+        for p, q in zip((hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias), heads[h]):
+            close(p.grad, q.grad, 1e-4, "head %d" % h)

@@ -195,3 +195,21 @@ def test_depth_sweep_models_oracle_vs_reference_golden(golden, name, nl, res, no
              for k in range(nl - 2)] if norm else None
     out = R.depth_stack(T(g["x"]), adj, W, b, norms, res, norm)
     close(out, g[key + "__out"], 1e-5)
+
+
+def test_gat_multihead_layer(golden):
+    """Oracle H-head layer (H oracle heads concatenated) vs H instances of the reference's layer (gat_heads.npz)."""
+    g = golden("gat_heads.npz")
+    n = int(g["n"])
+    src, tgt = T(g["src"]).long(), T(g["tgt"]).long()
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(src.numel())]), torch.ones(src.numel()), (n, src.numel()))
+    x = T(g["x"]).requires_grad_(True)
+    heads = [[T(g["h%d__%s" % (h, k)]).requires_grad_(True) for k in ("f__weight", "f__bias", "w__weight", "w__bias")]
+             for h in range(4)]
+    out = R.gat_multihead_layer(x, src, tgt, Mtgt, heads)
+    close(out, g["out"])
+    out.backward(T(g["gout"]))
+    close(x.grad, g["gx"], 1e-5)
+    for h, ps in enumerate(heads):
+        for p, k in zip(ps, ("f__weight", "f__bias", "w__weight", "w__bias")):
+            close(p.grad, g["h%d__grad__%s" % (h, k)], 1e-5)
