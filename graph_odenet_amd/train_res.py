@@ -55,6 +55,9 @@ def build_parser():
     p.add_argument('--tol', type=float, default=1e-5)
     p.add_argument('--data_dir', default=None)
     p.add_argument('--norm', choices=["row", "sym", "sum"], default="row")
+    p.add_argument('--heads', type=int, default=1,
+                   help="gat variant: H reference attention heads side by side in every layer whose width H divides "
+                        "(gat_heads.py; --hidden must be a multiple of H)")
     p.add_argument('--variant', choices=sorted(VARIANTS), default="gcn",
                    help="gcn: models over a normalised adjacency (GCN/train_res.py); gat: edge attention over "
                         "(src, tgt, Mtgt) (GAT/train_res.py)")
@@ -73,7 +76,13 @@ class Trainer:
         kw = dict(nfeat=self.x.shape[1], nhid=a.hidden, nclass=int(self.y.max().item()) + 1, dropout=a.dropout)
         if self.is_ode:
             kw.update(method=a.method, step_size=a.step_size, tol=a.tol)
-        model = VARIANTS[a.variant][a.model](**kw).to(self.device)
+        table = VARIANTS[a.variant]
+        if a.heads > 1:
+            if a.variant != "gat":
+                raise SystemExit("--heads applies to --variant gat")
+            from . import gat_heads
+            table = _model_dict(gat_heads.zoo(a.heads))
+        model = table[a.model](**kw).to(self.device)
         opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
         return model, opt
 
