@@ -172,12 +172,43 @@ class GcnOdeField(Field):
         return sums
 
 
-class GcnOdePartField(GcnOdeField):
-    """The same field on a row-partitioned graph (partition.py): ops.spmm gathers the operand rows between the two
-    launches of an f-eval, so the whole-solve C drivers are not offered and the solver takes the per-stage path."""
+class _PartMixin:
+    """Row-partitioned state (partition.py): hooks the adaptive solver uses to see global error norms."""
     rk4_native = None
     dopri5_step_native = None
-    fixed_grid_only = True
+    adaptive = False                # set by odeint when the method is adaptive
+
+    def _part(self):
+        return self.s.graph.part
+
+    def global_numel(self, c, t):
+        # the big components are row slices (padding rows of a ragged partition count: they are integrated too)
+        return t.numel() * self._part().world if t.dim() == 2 and t.shape[0] == self.w.n else t.numel()
+
+    def reduce_error_sums(self, sums):
+        """Per-component sums of squares -> sums over the ranks for the row-sliced components; the small components
+        are already global in adaptive mode."""
+        from .partition import global_sum
+        p = self._part()
+        if p.world == 1:
+            return sums
+        big = self.big_components
+        t = torch.tensor([sums[c] for c in big], dtype=torch.float64, device=self.w.S.device)
+        t = global_sum(t, p.group).tolist()
+        out = list(sums)
+        for c, v in zip(big, t):
+            out[c] = v
+        return out
+
+    def reduce_small(self, t):
+        from .partition import global_sum
+        return global_sum(t, self._part().group)
+
+
+class GcnOdePartField(_PartMixin, GcnOdeField):
+    """The same field on a row-partitioned graph (partition.py): ops.spmm gathers the operand rows between the two
+    launches of an f-eval, so the whole-solve C drivers are not offered and the solver takes the per-stage path."""
+    big_components = (0,)
 
     def __init__(self, spec, shared):
         GcnOdeField.__init__(self, spec, shared)
@@ -297,13 +328,29 @@ class GcnOdeAdjointField(Field):
             out[5].zero_(); out[6].zero_()
 
 
-class GcnOdePartAdjointField(GcnOdeAdjointField):
-    """Adjoint on a row-partitioned graph: y and a are this rank's rows; the small components (a_t and the parameter
-    gradients) are PARTIAL sums over the local rows, summed over the ranks once per step by the caller
-    (GradBucket.allreduce_sum) - the adjoint ODE is linear in them, so the sum commutes with the integration."""
-    rk4_native = None
-    dopri5_step_native = None
-    fixed_grid_only = True
+class GcnOdePartAdjointField(_PartMixin, GcnOdeAdjointField):
+    """Adjoint on a row-partitioned graph: y and a are this rank's rows.  Fixed grid: the small components (a_t and the
+    parameter gradients) stay PARTIAL sums over the local rows and the caller sums them over the ranks once per step
+    (GradBucket.allreduce_sum) - the adjoint ODE is linear in them, so the sum commutes with the integration.
+    Adaptive method: the step-size controller looks at their error norms, so every stage's small derivatives are summed
+    over the ranks (one 66 KB all-reduce per stage at d = 128) and every rank integrates the GLOBAL small components;
+    param_grads then hands back 1/world of them, so that the caller's allreduce_sum is right in both modes."""
+    big_components = (0, 1)
+
+    def _stage(self, t, terms, out, pre, coef):
+        GcnOdeAdjointField._stage(self, t, terms, out, pre, coef)
+        if self.adaptive and self._part().world > 1:
+            packed = getattr(out[2], "_gode_packed", None)
+            if packed is not None:
+                self.reduce_small(packed)
+            else:
+                for c in range(2, 7):
+                    self.reduce_small(out[c])
+
+    def param_grads(self, comps):
+        gs = GcnOdeAdjointField.param_grads(self, comps)
+        w = self._part().world
+        return [g / w for g in gs] if self.adaptive and w > 1 else gs
 
 
 class _OdeFuncFn(torch.autograd.Function):

@@ -99,8 +99,9 @@ def _integrate(field, comps, t0, t1, rtol, atol, method, options, stats):
         stats.nfe += _run_rk4(field, comps, t0, t1, uniform_grid(t0, t1, (options or {}).get("step_size")))
     else:
         if getattr(field, "fixed_grid_only", False):
-            raise NotImplementedError("odeint: a row-partitioned graph supports the fixed-grid method only "
-                                      "(method='rk4'); see graph_odenet_amd/partition.py")
+            raise NotImplementedError("odeint: this field supports the fixed-grid method only (method='rk4')")
+        if hasattr(field, "adaptive"):
+            field.adaptive = True                  # row-partitioned fields: keep the small components global
         prep = getattr(field, "prepare", None)
         if prep is not None:
             prep()
@@ -314,6 +315,9 @@ class _OdeintAdjoint(torch.autograd.Function):
                     fwd.eval(tl[i], [[(1.0, ans[i])]], [ctx_tmp])
                     stats.nfe += 1
                     comps[2].sub_((ctx_tmp * grad_out[i]).sum().reshape(1))
+                    if getattr(adj, "adaptive", None) is not None:
+                        adj.adaptive = True
+                        adj.reduce_small(comps[2])      # row-partitioned: a_t is a sum over all rows
                 _integrate(adj, comps, tl[i], tl[i - 1], ctx.rtol, ctx.atol, ctx.method, ctx.options, stats)
                 comps[1].add_(grad_out[i - 1])
         _bump_nfe(func, stats.nfe if getattr(adj, "fused", False) else 0)

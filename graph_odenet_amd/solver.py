@@ -128,25 +128,35 @@ class Dopri5Stats:
         self.nfe = 0
 
 
-def _rms_scaled(terms_per_comp, y, rtol, atol):
+def _numel(field, y, c):
+    """Elements of component c in the WHOLE problem (a row-partitioned field holds a slice of the big components)."""
+    g = getattr(field, "global_numel", None)
+    return g(c, y[c]) if g is not None else y[c].numel()
+
+
+def _rms_scaled(terms_per_comp, y, rtol, atol, field=None):
     """sqrt( sum_c sum_i (v_ci / (atol + rtol*|y_ci|))^2 / sum_c numel_c )  -> python float (syncs)."""
     outs = [ops.rk_scaled_sumsq(terms_per_comp[c], y[c], rtol, atol) for c in range(len(y))]
-    tot = torch.cat(outs).sum().item()
-    n = sum(c.numel() for c in y)
+    red = getattr(field, "reduce_error_sums", None)
+    if red is not None:
+        tot = sum(red(torch.cat(outs).tolist()))
+    else:
+        tot = torch.cat(outs).sum().item()
+    n = sum(_numel(field, y, c) for c in range(len(y)))
     return math.sqrt(tot / n)
 
 
 def _initial_step(field, t0, y, f0, rtol, atol, sgn, scratch_y, scratch_f, stats):
     nc = len(y)
-    d0 = _rms_scaled([[(1.0, y[c])] for c in range(nc)], y, rtol, atol)
-    d1 = _rms_scaled([[(1.0, f0[c])] for c in range(nc)], y, rtol, atol)
+    d0 = _rms_scaled([[(1.0, y[c])] for c in range(nc)], y, rtol, atol, field)
+    d1 = _rms_scaled([[(1.0, f0[c])] for c in range(nc)], y, rtol, atol, field)
     if d0 < 1e-5 or d1 < 1e-5:
         h0 = 1e-6
     else:
         h0 = 0.01 * d0 / d1
     field.eval(t0 + sgn * h0, [[(1.0, y[c]), (sgn * h0, f0[c])] for c in range(nc)], scratch_f)
     stats.nfe += 1
-    d2 = _rms_scaled([[(1.0, scratch_f[c]), (-1.0, f0[c])] for c in range(nc)], y, rtol, atol) / h0
+    d2 = _rms_scaled([[(1.0, scratch_f[c]), (-1.0, f0[c])] for c in range(nc)], y, rtol, atol, field) / h0
     if d1 <= 1e-15 and d2 <= 1e-15:
         h1 = max(1e-6, h0 * 1e-3)
     else:
@@ -206,7 +216,10 @@ def integrate_dopri5(field, y, t0, t1, rtol, atol, stats=None, max_steps=100000)
             sums = [ops.rk_error_sumsq(y[c], y1[c], [(h * DP_E[s], kk[s][c]) for s in range(7) if DP_E[s] != 0.0],
                                        rtol, atol) for c in range(nc)]
             sums = torch.cat(sums).tolist()          # the one device->host sync of this step
-            ratios = [sum(sums[c] for c in grp) / sum(y[c].numel() for c in grp) for grp in groups]
+            red = getattr(field, "reduce_error_sums", None)
+            if red is not None:
+                sums = red(sums)                     # row-partitioned state: every rank sees the global sums
+            ratios = [sum(sums[c] for c in grp) / sum(_numel(field, y, c) for c in grp) for grp in groups]
         ratio = max(ratios)
         if all(r <= 1.0 for r in ratios):
             stats.accepted += 1

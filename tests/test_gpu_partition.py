@@ -31,11 +31,22 @@ def _problem():
     return A.to_sparse(), x, y, train
 
 
-def _model(name, dev):
+def _model(spec, dev):
+    """spec: class name, optionally ':dopri5' for the adaptive method (default: rk4, 4 steps)."""
     from graph_odenet_amd import models
+    name, _, method = spec.partition(":")
     torch.manual_seed(11)
-    kw = dict(method="rk4", step_size=0.25) if name.startswith("ODE") else {}
-    return getattr(models, name)(NFEAT, NHID, NCLASS, 0.0, **kw).to(dev)
+    kw = {}
+    if name.startswith("ODE"):
+        kw = dict(method="dopri5", tol=1e-4) if method == "dopri5" else dict(method="rk4", step_size=0.25)
+    m = getattr(models, name)(NFEAT, NHID, NCLASS, 0.0, **kw)
+    if method == "dopri5":
+        # a gentle vector field: with the default initialisation this ODE is so sensitive that two adaptive step
+        # sequences on the SAME graph differ by percents in the gradient (whole graph, tol 1e-4 vs 1e-6), which would
+        # say nothing about the partitioned path
+        with torch.no_grad():
+            m.gc2.odefunc.gc1.weight.mul_(0.1)
+    return m.to(dev)
 
 
 def _partition(A, balanced, world, rank):
@@ -85,12 +96,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name,balanced", [("ODEGCN3", False), ("ODEGCN3", True), ("GCN3", True)])
+@pytest.mark.parametrize("name,balanced", [("ODEGCN3", False), ("ODEGCN3", True), ("GCN3", True), ("ODEGCN3:dopri5", True)])
 def test_two_rank_row_partition_matches_whole_graph(name, balanced):
     from graph_odenet_amd import models
     from graph_odenet_amd.partition import RowPartition
-    if not hasattr(models, name):
-        pytest.skip("no model %s" % name)
+    adaptive = name.endswith(":dopri5")
     try:
         ctx = mp.get_context("forkserver")
     except ValueError:
@@ -142,32 +152,28 @@ def test_two_rank_row_partition_matches_whole_graph(name, balanced):
     out, grads, loss, m = whole(Ad.to_sparse(), xp, yp, new[train])
     real = torch.zeros(part.n_pad, dtype=torch.bool)
     real[new] = True
-    assert (gathered[real] - out[real]).abs().max() < 2e-5
-    assert abs(res[0][2] - loss) < 1e-5
-    assert (got_grads - grads).abs().max() < 2e-5 * max(1.0, float(grads.abs().max())), worst(grads, m)
+    # adaptive: the accept / reject decisions read all-reduced error sums, rounded differently from one long sum
+    tol = 2e-4 if adaptive else 2e-5
+    assert (gathered[real] - out[real]).abs().max() < tol
+    assert abs(res[0][2] - loss) < tol
+    assert (got_grads - grads).abs().max() < (2e-3 if adaptive else 2e-5) * max(1.0, float(grads.abs().max())), worst(grads, m)
 
     # (2) the graph as given.  Outputs agree to rounding; the ODE block's gradients only to ~1e-3 of their size: the
     # adjoint pass reconstructs y(t) backwards and masks the cotangent with relu'(z), so a sum taken in another order
     # (renumbered columns) flips masks of pre-activations next to zero - the whole-graph path shows the same
     # differences between two node orders on ONE GPU (tools/dev/part_debug.py).
     out, grads, loss, m = whole(A, x, y, train)
-    assert (part.scatter_back(gathered) - out).abs().max() < 2e-5
-    assert abs(res[0][2] - loss) < 1e-5
+    assert (part.scatter_back(gathered) - out).abs().max() < tol
+    assert abs(res[0][2] - loss) < tol
     assert (got_grads - grads).abs().max() < 5e-3 * float(grads.abs().max()), worst(grads, m)
 
 
-def test_adaptive_method_is_refused_on_a_partitioned_graph():
-    from graph_odenet_amd import models
+def test_single_rank_partition_is_the_per_stage_path_on_the_whole_graph():
     from graph_odenet_amd.partition import PartitionedGraph, RowPartition
     dev = torch.device("cuda:0")
     A, x, _, _ = _problem()
-    part = RowPartition(N, 1, 0)
-    pg = PartitionedGraph.from_adj(A.to(dev), part)
-    torch.manual_seed(0)
-    m = models.ODEGCN3(NFEAT, NHID, NCLASS, 0.0).to(dev)            # default method: dopri5
-    with pytest.raises(NotImplementedError):
-        m(x.to(dev), pg)
-    # a single-rank partition is the per-stage solver path on the whole graph
-    m = _model("ODEGCN3", dev)
-    ref = m(x.to(dev), A.to(dev))
-    assert (m(x.to(dev), pg) - ref).abs().max() < 2e-5
+    pg = PartitionedGraph.from_adj(A.to(dev), RowPartition(N, 1, 0))
+    for spec in ("ODEGCN3", "ODEGCN3:dopri5"):
+        m = _model(spec, dev)
+        ref = m(x.to(dev), A.to(dev))
+        assert (m(x.to(dev), pg) - ref).abs().max() < 2e-5
