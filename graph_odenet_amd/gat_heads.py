@@ -143,6 +143,9 @@ class FixedMultiHeadGraphConvolution(MultiHeadGraphConvolution):
 
 
 # ---- fused ODE function -------------------------------------------------------------------------------------------
+PAD_LOGITS_MIN_ROWS = 4096
+
+
 class GatHeadsSpec:
     """Packed description of ODEfunc(dim, heads): theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta] with
     Wsrc, Wtgt (d+1) x d (head h in columns h*o..), Wlog (d+1) x 2H, bf d, bw H."""
@@ -160,6 +163,11 @@ class GatHeadsSpec:
         i, d, H = self.i, self.d, self.heads
         self.Wsrc, self.Wtgt, self.Wlog = torch.empty(i, d, **f), torch.empty(i, d, **f), torch.empty(i, 2 * H, **f)
         self.bf, self.ba = torch.empty(d, **f), torch.zeros(2 * H, **f)
+        # Large graphs: the 2H logit columns ride the square MFMA kernels as a zero-padded (d+1) x d block (0.4-0.5 ms
+        # per product at 2^20 x 128 against 2.2 / 5.5 / 3.8 ms for the generic kernels on a (d+1) x 16 block); small
+        # graphs are launch-bound and keep the compact product.
+        self.pad_logits = (egv.base.n >= PAD_LOGITS_MIN_ROWS and d in (16, 32, 64, 128) and 4 < 2 * H <= d)
+        self.Wlog_pad = torch.zeros(i, d, **f) if self.pad_logits else None
         self.refresh()
         self.gamma, self.beta = norm.weight.detach(), norm.bias.detach()
         self.n = egv.base.n
@@ -173,6 +181,8 @@ class GatHeadsSpec:
         with torch.no_grad():
             Wsrc, Wtgt, Wlog, bf, ba = self.layer.packed()
             self.Wsrc.copy_(Wsrc); self.Wtgt.copy_(Wtgt); self.Wlog.copy_(Wlog); self.bf.copy_(bf); self.ba.copy_(ba)
+            if self.Wlog_pad is not None:
+                self.Wlog_pad[:, :2 * self.heads].copy_(Wlog)
 
     def views(self, theta):
         v = {k: theta[a:b] for k, (a, b) in self.off.items()}
@@ -199,6 +209,10 @@ class _HeadsWork:
         npw = lib.gode_wgrad_parts(n)
         self.wp = [torch.empty(npw, spec.i * d, **f), torch.empty(npw, spec.i * d, **f), torch.empty(npw, spec.i * 2 * H, **f)]
         self.ba_grad = torch.empty(2 * H, **f)
+        if spec.pad_logits:
+            self.A2pad, self.dA2pad = torch.empty(n, d, **f), torch.zeros(n, d, **f)     # columns >= 2H of dA2pad stay 0
+            self.wp[2] = torch.empty(npw, spec.i * d, **f)
+            self.gWlog_pad = torch.empty(spec.i, d, **f)
 
 
 class GatHeadsField(GatOdeField):
@@ -216,7 +230,11 @@ class GatHeadsField(GatOdeField):
         ops.gn_time_gemm_pair(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, True, t, w.Ps, w.Pt,
                               x_out=x_out)
         terms = [(1.0, w.X)] if x_out is not None else y_terms
-        ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog, True, t, out=w.A2)
+        if s.pad_logits:
+            ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog_pad, True, t, out=w.A2pad)
+            w.A2.copy_(w.A2pad[:, :2 * s.heads])
+        else:
+            ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog, True, t, out=w.A2)
         w.Pt.add_(s.bf)                                  # per-head biases, folded into the target-side parts
         w.A2.add_(s.ba)
         return terms
@@ -266,7 +284,11 @@ class GatHeadsAdjointField(GatHeadsField):
         g["bw"].copy_(w.ba_grad[1::2])
         nb = w.np_b
         affine = s.groups > 0
-        for j, (Wj, dPj) in enumerate(((s.Wsrc, w.dPs), (s.Wtgt, w.dPt), (s.Wlog, w.dA2))):
+        Wl, dAl = s.Wlog, w.dA2
+        if s.pad_logits:
+            w.dA2pad[:, :2 * H].copy_(w.dA2)
+            Wl, dAl = s.Wlog_pad, w.dA2pad
+        for j, (Wj, dPj) in enumerate(((s.Wsrc, w.dPs), (s.Wtgt, w.dPt), (Wl, dAl))):
             ops.gn_time_gemm_bwd(xt, n, d, s.groups, s.eps_gn, s.gamma, Wj, True, dPj, out=out[1],
                                  pre_terms=[(1.0, out[1])] if j else None,
                                  parts=(w.gp[j * nb:(j + 1) * nb], w.bp[j * nb:(j + 1) * nb]) if affine else None)
@@ -274,10 +296,14 @@ class GatHeadsAdjointField(GatHeadsField):
             ops.reduce_parts2_(g["gamma"], w.gp, g["beta"], w.bp)
         else:
             g["gamma"].zero_(); g["beta"].zero_()
-        for j, dPj in enumerate((w.dPs, w.dPt, w.dA2)):
+        for j, dPj in enumerate((w.dPs, w.dPt, dAl)):
             ops.wgrad(xt, n, d, s.groups, s.eps_gn, s.gamma, s.beta, dPj, True, part=w.wp[j])
         ops.reduce_parts2_(g["Wsrc"].view(-1), w.wp[0], g["Wtgt"].view(-1), w.wp[1])
-        ops.reduce_parts_(g["Wlog"].view(-1), w.wp[2])
+        if s.pad_logits:
+            ops.reduce_parts_(w.gWlog_pad.view(-1), w.wp[2])
+            g["Wlog"].copy_(w.gWlog_pad[:, :2 * H])
+        else:
+            ops.reduce_parts_(g["Wlog"].view(-1), w.wp[2])
         ops.time_row_fixup3_([g["Wsrc"][0], g["Wtgt"][0], g["Wlog"][0]], [s.Wsrc[0], s.Wtgt[0], s.Wlog[0]], t, out[2])
 
 
@@ -335,18 +361,19 @@ class ODEfunc(nn.Module):
 
 # ---- model zoo ----------------------------------------------------------------------------------------------------
 _zoos = {}
+MIN_HEAD_WIDTH = 4
 
 
 def zoo(heads=8):
     """The 23 model classes of the GAT variant with H-head layers wherever `heads` divides the layer's output width
-    (the hidden layers and the ODE block; a class-count output layer that it does not divide keeps one head, as in
-    the usual GAT output layer).  Returns a namespace object with the classes as attributes."""
+    into heads of at least MIN_HEAD_WIDTH features (the hidden layers and the ODE block; a class-count output layer
+    keeps one head, as in the usual GAT output layer).  Returns a namespace object with the classes as attributes."""
     hit = _zoos.get(heads)
     if hit is not None:
         return hit
 
     def layer(in_features, out_features, *args, **kw):
-        if out_features % heads == 0:
+        if out_features % heads == 0 and out_features // heads >= MIN_HEAD_WIDTH:
             return MultiHeadGraphConvolution(in_features, out_features, heads, *args, **kw)
         return GraphConvolution(in_features, out_features, *args, **kw)
 

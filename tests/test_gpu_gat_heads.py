@@ -129,13 +129,22 @@ def test_eight_head_ode_block_vs_oracle_on_citeseer_edges(golden, method, kw, sm
         close(out2, out, 1e-6, "captured replay")
 
 
-def test_fused_fields_agree_with_autograd_through_the_layer(golden):
-    """The fused adjoint (kernel sequence on packed parameters) against autograd through ODEfunc.forward."""
+@pytest.mark.parametrize("big", [False, True])
+def test_fused_fields_agree_with_autograd_through_the_layer(golden, big):
+    """The fused adjoint (kernel sequence on packed parameters) against autograd through ODEfunc.forward; `big`: from
+    4096 nodes on the 2H logit columns ride the square MFMA kernels as a zero-padded block."""
     from graph_odenet_amd.gat_heads import ODEfunc
     from graph_odenet_amd.models import ODEBlock
-    n, src, tgt, Mtgt = _citeseer(golden)
+    if big:
+        n, E = 5000, 24000
+        g = torch.Generator().manual_seed(12)
+        src, tgt = torch.randint(0, n, (E,), generator=g), torch.randint(0, n, (E,), generator=g)
+        Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+        d, H = 32, 8
+    else:
+        n, src, tgt, Mtgt = _citeseer(golden)
+        d, H = 32, 4
     src, tgt, Mtgt = src.to(dev()), tgt.to(dev()), Mtgt.to(dev())
-    d, H = 32, 4
     torch.manual_seed(8)
     blk = ODEBlock(ODEfunc(d, H), method="rk4", step_size=0.5).to(dev())
     x = torch.randn(n, d, device=dev())
@@ -143,6 +152,7 @@ def test_fused_fields_agree_with_autograd_through_the_layer(golden):
     out = blk(x.clone().requires_grad_(True), src, tgt, Mtgt)
     out.backward(gout)
     fused = [p.grad.clone() for p in blk.parameters()]
+    assert blk.odefunc.gode_fields(x)[0].s.pad_logits == big
     for p in blk.parameters():
         p.grad = None
     type(blk.odefunc).gode_fields_saved = type(blk.odefunc).gode_fields
