@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--ode-steps", type=int, default=16, help="rk4 steps on [0,1] (4 evals each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=4, help="f-evals in the CPU-baseline sample (median is used)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the step times of the other BASELINE.json configurations (Cora / Pubmed / Citeseer-GAT / QC)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the untimed-by-contract extras: per-f-eval times and the 256-eval reading")
     return ap.parse_args()
@@ -226,6 +228,14 @@ def main():
     extras = None
     if world == 1 and not args.no_secondary:
         extras = secondary(args, model, x, g, step, barrier)
+        if not args.no_configs:
+            # the other BASELINE.json configurations (parity-test cases), timed on this box: tools/config_bench.py
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import config_bench
+                extras["other_configs"] = config_bench.all_configs(dev)
+            except Exception as e:
+                extras["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         res = {
