@@ -118,7 +118,7 @@ SIGNATURES = {
     "gode_gat_maxpath_scratch_bytes": (c_i64, [c_i64]),
     "gode_gat_maxpath_f32": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_p]),
     "gode_gat_heads_scratch_bytes": (c_i64, [c_i64, c_i64]),
-    "gode_gat_logits_heads_f32": (c_i, [ctypes.POINTER(GatProj), c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "gode_gat_logits_heads_f32": (c_i, [ctypes.POINTER(GatProj), c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "gode_gat_maxpath_heads_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p]),
     "gode_gat_scatter_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64,
                                    c_p]),

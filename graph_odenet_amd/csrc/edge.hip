@@ -748,7 +748,8 @@ constexpr int kHeadBlocks = 512;
 __device__ __forceinline__ int float_key(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float key_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
-__global__ __launch_bounds__(256) void gat_logits_heads_part_kernel(Proj pv, const int* __restrict__ src,
+__global__ __launch_bounds__(256) void gat_logits_heads_part_kernel(Proj pv, const float* __restrict__ bw,
+                                                                    const int* __restrict__ src,
                                                                     const int* __restrict__ tgt, int n_edges, int H,
                                                                     float* __restrict__ a, float* __restrict__ pmax) {
     __shared__ int hm[kMaxHeads];
@@ -758,12 +759,59 @@ __global__ __launch_bounds__(256) void gat_logits_heads_part_kernel(Proj pv, con
     const int lo = blockIdx.x * per, hi = min(n_edges, lo + per);
     for (int e = lo + threadIdx.x; e < hi; e += 256) {
         const int t = tgt[e];
-        const float v = pv.as[(int64_t)src[e] * pv.lda] + pv.at[(int64_t)t * pv.lda];
+        const float v = pv.as[(int64_t)src[e] * pv.lda] + pv.at[(int64_t)t * pv.lda] + (bw ? bw[t % H] : 0.f);
         a[e] = v;
         atomicMax(&hm[t % H], float_key(v));
     }
     __syncthreads();
     if (threadIdx.x < H) pmax[blockIdx.x * H + threadIdx.x] = key_float(hm[threadIdx.x]);
+}
+
+// Both steps in one block (small edge lists): every thread revisits the entries it wrote.
+__global__ __launch_bounds__(1024) void gat_logits_heads_small_kernel(Proj pv, const float* __restrict__ bw,
+                                                                      const int* __restrict__ src,
+                                                                      const int* __restrict__ tgt, int n_edges, int H,
+                                                                      float* __restrict__ a, float* __restrict__ hmax) {
+    __shared__ int hm[kMaxHeads];
+    if (threadIdx.x < H) hm[threadIdx.x] = float_key(-INFINITY);
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_edges; e += 1024) {
+        const int t = tgt[e];
+        const float v = pv.as[(int64_t)src[e] * pv.lda] + pv.at[(int64_t)t * pv.lda] + (bw ? bw[t % H] : 0.f);
+        a[e] = v;
+        atomicMax(&hm[t % H], float_key(v));
+    }
+    __syncthreads();
+    if (threadIdx.x < H && hmax) hmax[threadIdx.x] = key_float(hm[threadIdx.x]);
+    for (int e = threadIdx.x; e < n_edges; e += 1024) a[e] -= key_float(hm[tgt[e] % H]);
+}
+
+// One block (small edge lists, H <= 8 at the call site): per-thread LDS columns per head, fixed-order sums, first arg-max per head.
+__global__ __launch_bounds__(1024) void gat_maxpath_heads_small_kernel(const float* __restrict__ a, float* __restrict__ da,
+                                                                       const int* __restrict__ tgt, int n_edges, int H) {
+    extern __shared__ float col[];                    // [H][1024]
+    __shared__ int hidx[16];
+    __shared__ float hsum[16];
+    for (int h = 0; h < H; ++h) col[h * 1024 + threadIdx.x] = 0.f;
+    if (threadIdx.x < H) hidx[threadIdx.x] = INT32_MAX;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_edges; e += 1024) {
+        const int h = tgt[e] % H;
+        col[h * 1024 + threadIdx.x] += da[e];
+        if (a[e] == 0.f) atomicMin(&hidx[h], e);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int h = w; h < H; h += 16) {
+        const float* c = col + h * 1024;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += c[lane + 64 * k];
+        v = wave_sum(v);
+        if (lane == 0) hsum[h] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < H && hidx[threadIdx.x] < n_edges) da[hidx[threadIdx.x]] -= hsum[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void gat_logits_heads_shift_kernel(const int* __restrict__ tgt, int n_edges, int H,
@@ -1032,6 +1080,7 @@ extern "C" int gode_gat_maxpath_f32(const float* a, const float* amax, float* da
 }
 
 namespace {
+constexpr int64_t kSmallHeadEdges = 8192;         // below this the per-head maximum steps are single-block launches
 int head_blocks(int64_t n_edges) {
     int64_t b = (n_edges + 1023) / 1024; if (b > kHeadBlocks) b = kHeadBlocks; if (b < 1) b = 1;
     return (int)b;
@@ -1044,9 +1093,9 @@ extern "C" int64_t gode_gat_heads_scratch_bytes(int64_t n_edges, int64_t heads) 
     return (int64_t)kHeadBlocks * heads * (int64_t)(sizeof(float) + sizeof(int));
 }
 
-extern "C" int gode_gat_logits_heads_f32(const gode_gat_proj_t* proj, const int32_t* src, const int32_t* tgt,
-                                         int64_t n_edges, int64_t heads, float* a, float* hmax, void* scratch,
-                                         void* stream) {
+extern "C" int gode_gat_logits_heads_f32(const gode_gat_proj_t* proj, const float* bw, const int32_t* src,
+                                         const int32_t* tgt, int64_t n_edges, int64_t heads, float* a, float* hmax,
+                                         void* scratch, void* stream) {
     if (!proj) return GODE_E_NULLPTR;
     if (n_edges < 0 || heads < 1) return GODE_E_SHAPE;
     if (heads > kMaxHeads) return GODE_E_UNSUPPORTED;
@@ -1056,9 +1105,15 @@ extern "C" int gode_gat_logits_heads_f32(const gode_gat_proj_t* proj, const int3
     if (!pv.as || !pv.at || !src || !tgt || !a || !scratch) return GODE_E_NULLPTR;
     if (pv.lda < 1) return GODE_E_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    if (n_edges <= kSmallHeadEdges) {
+        hipLaunchKernelGGL(gat_logits_heads_small_kernel, dim3(1), dim3(1024), 0, s, pv, bw, src, tgt, (int)n_edges,
+                           (int)heads, a, hmax);
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
     const int nb = head_blocks(n_edges);
     float* pmax = (float*)scratch;
-    hipLaunchKernelGGL(gat_logits_heads_part_kernel, dim3(nb), dim3(256), 0, s, pv, src, tgt, (int)n_edges, (int)heads, a, pmax);
+    hipLaunchKernelGGL(gat_logits_heads_part_kernel, dim3(nb), dim3(256), 0, s, pv, bw, src, tgt, (int)n_edges, (int)heads, a, pmax);
     GODE_LAUNCH_CHECK();
     hipLaunchKernelGGL(gat_logits_heads_shift_kernel, dim3(nb), dim3(256), 0, s, tgt, (int)n_edges, (int)heads, nb,
                        (const float*)pmax, a, hmax);
@@ -1074,6 +1129,12 @@ extern "C" int gode_gat_maxpath_heads_f32(const float* a, float* da, int64_t n_e
     if (n_edges == 0) return 0;
     if (!a || !da || !tgt || !scratch) return GODE_E_NULLPTR;
     hipStream_t s = (hipStream_t)stream;
+    if (n_edges <= kSmallHeadEdges && heads <= 8 && !dat) {          // 4 KB of LDS per head
+        hipLaunchKernelGGL(gat_maxpath_heads_small_kernel, dim3(1), dim3(1024), (size_t)heads * 1024 * sizeof(float), s, a,
+                           da, tgt, (int)n_edges, (int)heads);
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
     const int nb = head_blocks(n_edges);
     float* psum = (float*)scratch;
     int* pidx = (int*)(psum + (int64_t)kHeadBlocks * heads);

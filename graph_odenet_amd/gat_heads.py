@@ -13,8 +13,9 @@ square (d+1) x d inside an ODE function where H*o = d - ARE the (N*H) x o matric
 (N*H) x o result is the N x (H*o) concatenation: no copy in either direction.  Edge s -> t becomes the H edges
 s*H+h -> t*H+h.  Every aggregation / VJP / scatter kernel of the one-head path runs unchanged on that graph; the
 per-head maximum is handled by gode_gat_logits_heads_f32 (logits shifted by their head's maximum, the aggregation then
-runs with amax = 0) and gode_gat_maxpath_heads_f32 (gradient path through each head's maximum).  The per-head biases
-are folded into the target-side projections (z_e = Ps[src] + (Pt[tgt] + bf_h), a_e = As[src] + (At[tgt] + bw_h)).
+runs with amax = 0) and gode_gat_maxpath_heads_f32 (gradient path through each head's maximum).  The per-head message
+biases are folded into the target-side projection (z_e = Ps[src] + (Pt[tgt] + bf_h)); the logit biases are added by the
+logits kernel.
 """
 import torch
 import torch.nn as nn
@@ -162,7 +163,7 @@ class GatHeadsSpec:
         f = dict(dtype=torch.float32, device=dev)
         i, d, H = self.i, self.d, self.heads
         self.Wsrc, self.Wtgt, self.Wlog = torch.empty(i, d, **f), torch.empty(i, d, **f), torch.empty(i, 2 * H, **f)
-        self.bf, self.ba = torch.empty(d, **f), torch.zeros(2 * H, **f)
+        self.bf, self.bw = torch.empty(d, **f), torch.empty(H, **f)
         # Large graphs: the 2H logit columns ride the square MFMA kernels as a zero-padded (d+1) x d block (0.4-0.5 ms
         # per product at 2^20 x 128 against 2.2 / 5.5 / 3.8 ms for the generic kernels on a (d+1) x 16 block); small
         # graphs are launch-bound and keep the compact product.
@@ -180,7 +181,7 @@ class GatHeadsSpec:
     def refresh(self):
         with torch.no_grad():
             Wsrc, Wtgt, Wlog, bf, ba = self.layer.packed()
-            self.Wsrc.copy_(Wsrc); self.Wtgt.copy_(Wtgt); self.Wlog.copy_(Wlog); self.bf.copy_(bf); self.ba.copy_(ba)
+            self.Wsrc.copy_(Wsrc); self.Wtgt.copy_(Wtgt); self.Wlog.copy_(Wlog); self.bf.copy_(bf); self.bw.copy_(ba[1::2])
             if self.Wlog_pad is not None:
                 self.Wlog_pad[:, :2 * self.heads].copy_(Wlog)
 
@@ -235,14 +236,13 @@ class GatHeadsField(GatOdeField):
             w.A2.copy_(w.A2pad[:, :2 * s.heads])
         else:
             ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog, True, t, out=w.A2)
-        w.Pt.add_(s.bf)                                  # per-head biases, folded into the target-side parts
-        w.A2.add_(s.ba)
+        w.Pt.add_(s.bf)                                  # per-head message biases, folded into the target-side part
         return terms
 
     def _forward(self, t, y_terms, out):
         s, w, eg = self.s, self.w, self.s.eg
         terms = self._project(t, y_terms)
-        ops.gat_logits_heads(w.proj, eg.src, eg.tgt, s.heads, w.a)
+        ops.gat_logits_heads(w.proj, eg.src, eg.tgt, s.heads, w.a, bw=s.bw)
         ops.gat_agg_fwd(eg, w.proj, s.o, w.bf0, w.a, w.zero, s.eps, out.view(s.n * s.heads, s.o), w.wgt, w.den)
         return terms
 

@@ -324,13 +324,15 @@ def gat_agg_fwd(eg, proj, o, bf, a, amax, eps, out, w, den):
                                    ptr(amax), float(eps), ptr(out), ptr(w), ptr(den), stream_ptr()), "gode_gat_agg_f32_fwd")
 
 
-def gat_logits_heads(proj, src, tgt, heads, a, hmax=None):
-    """Logits of the H-fold graph (gat_heads.py), shifted by the maximum of their head (tgt % heads)."""
+def gat_logits_heads(proj, src, tgt, heads, a, hmax=None, bw=None):
+    """Logits of the H-fold graph (gat_heads.py) + bw[head], shifted by the maximum of their head (tgt % heads)."""
     lib = _lib.load()
-    _need(a, "a"); _need(hmax, "hmax")
+    _need(a, "a"); _need(hmax, "hmax"); _need(bw, "bw")
+    if bw is not None and bw.numel() != heads:
+        raise ValueError("gat_logits_heads: bw must hold one bias per head")
     E = src.numel()
     sc = _scratch(a.device, lib.gode_gat_heads_scratch_bytes(E, heads))
-    check(lib.gode_gat_logits_heads_f32(ctypes.byref(proj), ptr(src), ptr(tgt), E, int(heads), ptr(a), ptr(hmax), ptr(sc),
+    check(lib.gode_gat_logits_heads_f32(ctypes.byref(proj), ptr(bw), ptr(src), ptr(tgt), E, int(heads), ptr(a), ptr(hmax), ptr(sc),
                                         stream_ptr()), "gode_gat_logits_heads_f32")
 
 

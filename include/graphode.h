@@ -240,13 +240,14 @@ int gode_gat_maxpath_f32(const float* a, const float* amax, float* da, int64_t n
  * N x H*o projection matrix is the (N*H) x o matrix of the virtual nodes; edge e becomes the H edges
  * src*H+h -> tgt*H+h, target-sorted) through the entry points above with amax -> 0.f.  The reference's maximum
  * (GAT/layers.py:47) is per head, so the logits are computed and shifted by their head's maximum here
- * (a_e = as[src_e] + at[tgt_e] - max over the edges of head tgt_e % H; fold bw into `at`), hmax[heads] (nullable)
+ * (a_e = as[src_e] + at[tgt_e] + bw[h] - max over the edges of head h = tgt_e % H), hmax[heads] (nullable)
  * receives the maxima, and the gradient path through the maximum is per head: for every head da[e*] -= S_h with e* the
  * first edge of the head whose shifted logit is 0 (and dat[tgt[e*]*ld_dat] -= S_h when dat is given).
  * heads <= 64; scratch >= gode_gat_heads_scratch_bytes(n_edges, heads) bytes. */
 int64_t gode_gat_heads_scratch_bytes(int64_t n_edges, int64_t heads);
-int gode_gat_logits_heads_f32(const gode_gat_proj_t* proj, const int32_t* src, const int32_t* tgt, int64_t n_edges,
-                              int64_t heads, float* a, float* hmax, void* scratch, void* stream);
+int gode_gat_logits_heads_f32(const gode_gat_proj_t* proj, const float* bw /* nullable: heads logit biases */,
+                              const int32_t* src, const int32_t* tgt, int64_t n_edges, int64_t heads, float* a,
+                              float* hmax, void* scratch, void* stream);
 int gode_gat_maxpath_heads_f32(const float* a, float* da, int64_t n_edges, int64_t heads, const int32_t* tgt,
                                float* dat, int64_t ld_dat, void* scratch, void* stream);
 /* dps[v,:] = sum_{e: src_e = v} dz[e,:], dpt[v,:] = sum_{e: tgt_e = v} dz[e,:], das / dat likewise from da; the
