@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--ode-steps", type=int, default=16, help="rk4 steps on [0,1] (4 evals each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-evals", type=int, default=4, help="f-evals in the CPU-baseline sample (median is used)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise RCCL and run the collectives of the multi-GPU path with a single rank")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the step times of the other BASELINE.json configurations (Cora / Pubmed / Citeseer-GAT / QC)")
     ap.add_argument("--no-secondary", action="store_true",
@@ -130,12 +132,16 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from graph_odenet_amd import _lib, models, ops
+    from graph_odenet_amd import parallel
     from graph_odenet_amd.parallel import GradBucket, broadcast_parameters
+    parallel.FORCE_COLLECTIVES = bool(args.force_dist)
     from graph_odenet_amd.synth import rmat_graph
     lib = _lib.load()
 
@@ -167,7 +173,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -187,7 +193,7 @@ def main():
     nfe_per_step = model.nfe / max(args.steps, 1)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = tmax.item()
 
@@ -262,7 +268,7 @@ def main():
             gc = {"n": n, "r": rows, "c": g.col.to(torch.int64).cpu(), "v": g.val.cpu()}
             res["cpu_baseline"] = cpu_baseline(args, gc, sd_cpu, x.cpu())
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

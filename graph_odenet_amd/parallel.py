@@ -9,9 +9,16 @@ import torch
 import torch.distributed as dist
 
 
+FORCE_COLLECTIVES = False      # rehearsal (bench.py --force-dist): issue the collectives even with a single rank
+
+
+def _alone():
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_COLLECTIVES)
+
+
 def broadcast_parameters(module, src=0):
     """Make every rank start from rank `src`'s weights (one flat broadcast)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _alone():
         return
     ps = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     if not ps:
@@ -61,7 +68,7 @@ class GradBucket:
         self._allreduce(False)
 
     def _allreduce(self, mean):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if _alone():
             return
         for p, v in zip(self.params, self.views):
             if p.grad is None:
