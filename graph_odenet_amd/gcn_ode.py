@@ -183,7 +183,7 @@ class _PartMixin:
 
     def global_numel(self, c, t):
         # the big components are row slices (padding rows of a ragged partition count: they are integrated too)
-        return t.numel() * self._part().world if t.dim() == 2 and t.shape[0] == self.w.n else t.numel()
+        return t.numel() * self._part().world if c in self.big_components else t.numel()
 
     def reduce_error_sums(self, sums):
         """Per-component sums of squares -> sums over the ranks for the row-sliced components; the small components
