@@ -218,3 +218,37 @@ def test_heads_on_the_record_path():
         hd = layer.heads[h]
         for p, q in zip((hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias), heads[h]):
             close(p.grad, q.grad, 1e-4, "head %d" % h)
+
+
+@pytest.mark.parametrize("H,o,n,E,weighted", [(3, 4, 287, 2861, False), (8, 2, 163, 2934, True), (16, 16, 233, 1414, False),
+                                              (5, 3, 18, 202, True), (1, 1, 16, 1058, True), (16, 1, 13, 567, False)])
+def test_head_counts_and_widths_vs_fp64_oracle(H, o, n, E, weighted):
+    """Head counts that are not powers of two, one-feature heads, weighted Mtgt entries, nodes without edges; edge
+    lists on both sides of the single-block threshold (tools/dev/fuzz_heads.py runs many more)."""
+    from graph_odenet_amd.gat_heads import MultiHeadGraphConvolution
+    from oracle import layers_ref as R
+    g = torch.Generator().manual_seed(H * 1000 + o)
+    nin = 7
+    src, tgt = torch.randint(0, n, (E,), generator=g), torch.randint(0, max(1, n - 2), (E,), generator=g)
+    vals = torch.rand(E, generator=g) + 0.25 if weighted else torch.ones(E)
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), vals, (n, E))
+    torch.manual_seed(o)
+    layer = MultiHeadGraphConvolution(nin, H * o, heads=H)
+    with torch.no_grad():
+        for hd in layer.heads:
+            hd.w.bias.add_(torch.randn(1) * 3)
+    x, gout = torch.randn(n, nin, generator=g), torch.randn(n, H * o, generator=g)
+    xd = x.double().requires_grad_(True)
+    heads = [[p.detach().double().requires_grad_(True) for p in (hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias)]
+             for hd in layer.heads]
+    ref = R.gat_multihead_layer(xd, src, tgt, Mtgt.double(), heads)
+    ref.backward(gout.double())
+    layer = layer.to(dev())
+    xg = x.to(dev()).requires_grad_(True)
+    out = layer(xg, src.to(dev()), tgt.to(dev()), Mtgt.to(dev()))
+    out.backward(gout.to(dev()))
+    close(out, ref, 1e-5, "out")
+    close(xg.grad, xd.grad, 2e-5, "gx")
+    for hd, ps in zip(layer.heads, heads):
+        for p, q in zip((hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias), ps):
+            close(p.grad, q.grad, 2e-5, "param")
