@@ -217,7 +217,7 @@ def main():
         ach = tot_bytes / (tot_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and (args.scale, args.edges, args.hidden) == (20, 10_000_000, 128):   # measured on THIS workload only
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
