@@ -55,6 +55,11 @@ def build_parser():
     p.add_argument('--tol', type=float, default=1e-5)
     p.add_argument('--data_dir', default=None)
     p.add_argument('--norm', choices=["row", "sym", "sum"], default="row")
+    p.add_argument('--partition', action='store_true', default=False,
+                   help="under torch.distributed.run: ONE model on the graph split by rows over the ranks "
+                        "(partition.py) instead of sharding --runs over them")
+    p.add_argument('--dist_backend', choices=["nccl", "gloo"], default="nccl",
+                   help="gloo: rehearsal with several ranks sharing one GPU (exchange staged through the host)")
     p.add_argument('--heads', type=int, default=1,
                    help="gat variant: H reference attention heads side by side in every layer whose width H divides "
                         "(gat_heads.py; --hidden must be a multiple of H)")
@@ -86,6 +91,19 @@ class Trainer:
         opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
         return model, opt
 
+    # hooks of the row-partitioned trainer below
+    def loss(self, out, idx):
+        return F.nll_loss(out[idx], self.y[idx])
+
+    def acc(self, out, idx):
+        return accuracy(out[idx], self.y[idx])
+
+    def value(self, t):
+        return t.item()
+
+    def sync_grads(self, model):
+        pass
+
     def epoch(self, model, opt, ep):
         t0 = time.time()
         model.nfe = 0
@@ -94,9 +112,10 @@ class Trainer:
         out = model(self.x, *self.graph)
         nfe_f = model.nfe
         model.nfe = 0
-        loss = F.nll_loss(out[self.itr], self.y[self.itr])
-        acc = accuracy(out[self.itr], self.y[self.itr])
+        loss = self.loss(out, self.itr)
+        acc = self.acc(out, self.itr)
         loss.backward()
+        self.sync_grads(model)
         opt.step()
         nfe_b = model.nfe
         model.nfe = 0
@@ -104,8 +123,9 @@ class Trainer:
             model.eval()
             with torch.no_grad():
                 out = model(self.x, *self.graph)
-        lv = F.nll_loss(out[self.iva], self.y[self.iva])
-        av = accuracy(out[self.iva], self.y[self.iva])
+        lv = self.loss(out, self.iva)
+        av = self.acc(out, self.iva)
+        loss, acc, lv, av = (_Val(self.value(t)) for t in (loss, acc, lv, av))
         if self.verbose:
             print('Epoch: {:04d}'.format(ep + 1), 'loss_train: {:.4f}'.format(loss.item()),
                   'acc_train: {:.4f}'.format(acc.item()), 'loss_val: {:.4f}'.format(lv.item()),
@@ -118,11 +138,68 @@ class Trainer:
         model.eval()
         with torch.no_grad():
             out = model(self.x, *self.graph)
-        lt = F.nll_loss(out[self.ite], self.y[self.ite]).item()
-        at = accuracy(out[self.ite], self.y[self.ite]).item()
+        lt = self.value(self.loss(out, self.ite))
+        at = self.value(self.acc(out, self.ite))
         if self.verbose:
             print("Test set results:", "loss= {:.4f}".format(lt), "accuracy= {:.4f}".format(at))
         return lt, at
+
+
+class _Val(float):
+    """A python float that still answers .item() (the print block above is the reference's)."""
+
+    def item(self):
+        return float(self)
+
+
+class PartitionedTrainer(Trainer):
+    """--partition: ONE model on ONE graph split by rows over the ranks (graph_odenet_amd/partition.py).  Every rank
+    holds its rows of the features / labels and its row blocks of A and A^T; losses and accuracies are sums over the
+    local members of an index set divided by the set's global size (summed over the ranks for printing), and the
+    parameter gradients - partial sums - are added over the ranks before the optimiser step."""
+
+    def __init__(self, args, data, device, verbose):
+        from .parallel import GradBucket
+        from .partition import PartitionedGraph, RowPartition
+        if args.variant != "gcn":
+            raise SystemExit("--partition is built for the gcn variant")
+        self.args, self.verbose, self.device = args, verbose, device
+        adj, x, y, itr, iva, ite = data
+        adj = adj.coalesce() if adj.is_sparse else adj.to_sparse().coalesce()
+        n = adj.shape[0]
+        rows, cols = adj.indices()
+        self.part = RowPartition.balanced(n, rows, cols)
+        self.graph = (PartitionedGraph.from_coo(rows, cols, adj.values(), n, self.part, device=device),)
+        self.x, self.y = self.part.take(x).to(device), self.part.take(y).to(device)
+        self.n_class = int(y.max().item()) + 1
+        self.itr, self.iva, self.ite = ((self.part.local_positions(i).to(device), i.numel()) for i in (itr, iva, ite))
+        self.is_ode = "ode" in args.model
+        self._bucket_of, self._GradBucket = {}, GradBucket
+
+    def new_model(self):
+        a = self.args
+        kw = dict(nfeat=self.x.shape[1], nhid=a.hidden, nclass=self.n_class, dropout=a.dropout)
+        if self.is_ode:
+            kw.update(method=a.method, step_size=a.step_size, tol=a.tol)
+        model = VARIANTS[a.variant][a.model](**kw).to(self.device)       # same seed on every rank: same initial weights
+        opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
+        self._bucket_of = {id(model): self._GradBucket(model)}
+        return model, opt
+
+    def loss(self, out, idx):
+        pos, count = idx
+        return F.nll_loss(out[pos], self.y[pos], reduction="sum") / count
+
+    def acc(self, out, idx):
+        pos, count = idx
+        return (out[pos].max(1)[1] == self.y[pos]).double().sum() / count
+
+    def value(self, t):
+        from .partition import global_sum
+        return float(global_sum(t.detach().double().reshape(1).clone(), self.part.group))
+
+    def sync_grads(self, model):
+        self._bucket_of[id(model)].allreduce_sum()
 
 
 def main(argv=None):
@@ -132,13 +209,16 @@ def main(argv=None):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) if args.dist_backend == "nccl" else 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    if args.runs == 1:
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.runs == 1 or args.partition:
         np.random.seed(args.seed)
         torch.manual_seed(args.seed)
         torch.cuda.manual_seed(args.seed)
@@ -146,13 +226,18 @@ def main(argv=None):
         data = load_planetoid_gat(args.dataset, args.data_dir) if args.data_dir else load_captured_gat(args.dataset)
     else:
         data = load_planetoid(args.dataset, args.data_dir, args.norm) if args.data_dir else load_captured(args.dataset)
-    tr = Trainer(args, data, device, verbose=(args.runs == 1 and rank == 0))
-    lo, hi = shard_range(args.runs, rank, world)
+    if args.partition:
+        tr = PartitionedTrainer(args, data, device, verbose=(args.runs == 1 and rank == 0))
+        lo, hi = 0, args.runs                      # every rank takes part in every run
+    else:
+        tr = Trainer(args, data, device, verbose=(args.runs == 1 and rank == 0))
+        lo, hi = shard_range(args.runs, rank, world)
     tot = torch.zeros(3, dtype=torch.float64, device=device)
     model = None
     for run in range(lo, hi):
         if args.runs > 1:
             torch.manual_seed(args.seed + run)          # independent replicas: seed = base + run
+            torch.cuda.manual_seed(args.seed + run)
         model, opt = tr.new_model()
         t0 = time.time()
         for ep in range(args.epochs):
@@ -160,10 +245,10 @@ def main(argv=None):
         torch.cuda.synchronize()
         dt = time.time() - t0
         lt, at = tr.test(model)
-        if args.runs > 1:
+        if args.runs > 1 and (rank == 0 or not args.partition):
             print("Run #{run} Test -- time: {time}s acc: {acc:.2f}%".format(run=run, time=dt, acc=100 * at), flush=True)
         tot += torch.tensor([lt, at, dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if world > 1 and not args.partition:
         dist.all_reduce(tot)
     tot = (tot / max(args.runs, 1)).tolist()
     if rank == 0:

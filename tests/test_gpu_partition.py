@@ -177,3 +177,49 @@ def test_single_rank_partition_is_the_per_stage_path_on_the_whole_graph():
         m = _model(spec, dev)
         ref = m(x.to(dev), A.to(dev))
         assert (m(x.to(dev), pg) - ref).abs().max() < 2e-5
+
+
+def _harness_rank(rank, world, port, argv, q):
+    try:
+        import contextlib
+        import io
+        from graph_odenet_amd import train_res
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            train_res.main(argv)
+        q.put((rank, buf.getvalue(), None))
+    except BaseException as e:
+        import traceback
+        q.put((rank, None, "%r\n%s" % (e, traceback.format_exc())))
+
+
+def _final_loss(text):
+    line = [l for l in text.splitlines() if l.startswith("Test set results: avg loss=")][-1]
+    return float(line.split("avg loss=")[1].split()[0]), float(line.split("avg accuracy=")[1])
+
+
+@pytest.mark.parametrize("model,tol", [("gcn3", 2e-4), ("ode3", 3e-2)])
+def test_train_res_partition_matches_single_process(capsys, model, tol):
+    """`train_res --partition`: Cora split over two ranks trains the same model as one process (dropout 0, same seed):
+    plain GCN to rounding, the ODE model within the mask-flip sensitivity of its adjoint gradients."""
+    from graph_odenet_amd import train_res
+    argv = ["--model", model, "--dataset", "cora", "--epochs", "6", "--dropout", "0", "--method", "rk4", "--step_size", "0.25"]
+    ctx = mp.get_context("forkserver")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_harness_rank, args=(k, 2, port, argv + ["--partition", "--dist_backend", "gloo"], q))
+             for k in range(2)]
+    [p.start() for p in procs]
+    outs = {}
+    for _ in range(2):
+        k, text, err = q.get(timeout=300)
+        assert err is None, "rank %d failed: %s" % (k, err)
+        outs[k] = text
+    [p.join(60) for p in procs]
+    assert "Epoch: 0006" in outs[0] and "Epoch:" not in outs[1]            # rank 0 reports
+    capsys.readouterr()
+    train_res.main(argv)
+    ref = capsys.readouterr().out
+    (l2, a2), (l1, a1) = _final_loss(outs[0]), _final_loss(ref)
+    assert abs(l2 - l1) < tol * max(1.0, abs(l1)) and abs(a2 - a1) < max(tol, 0.011)
