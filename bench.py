@@ -118,6 +118,20 @@ def secondary(args, model, x, g, step, barrier):
         out["steps_per_s_at_256_evals"] = round(1.0 / (time.perf_counter() - t0), 4)
     finally:
         blk.step_size = old
+    # opt-in lead, NOT the default path and not the contract value: the forward dense product on the bf16 matrix pipe
+    # through an exact three-way operand split with fp32 accumulation
+    from graph_odenet_amd import _lib
+    lib = _lib.load()
+    if lib.gode_set_option(b"gemm_split", 1) == 0:
+        try:
+            step()
+            barrier()
+            t0 = time.perf_counter()
+            step()
+            barrier()
+            out["steps_per_s_with_optin_split_bf16_forward_product"] = round(1.0 / (time.perf_counter() - t0), 4)
+        finally:
+            lib.gode_set_option(b"gemm_split", 0)
     return out
 
 
