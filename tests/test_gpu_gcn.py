@@ -569,3 +569,51 @@ def test_model_with_captured_solves_can_be_deep_copied_and_pickled():
     buf.seek(0)
     again = torch.load(buf, weights_only=False)
     assert torch.equal(again(x, adj), ref)
+
+
+def _citation(golden, name):
+    """Citeseer: the reference loader's captured adjacency / features / labels; Pubmed: the real topology
+    (sym-normalised as GCN-dense-paper holds it) with synthetic features and labels (ind.pubmed.allx is absent)."""
+    if name == "citeseer":
+        gr = golden("citeseer_graph.npz")
+        n = int(gr["n"])
+        adj = torch.sparse_coo_tensor(torch.stack([T(gr["rows"].astype(np.int64)), T(gr["cols"].astype(np.int64))]),
+                                      T(gr["vals"]), (n, n))
+        feats = torch.zeros(n, int(gr["n_feat"]))
+        feats[T(gr["feat_rows"].astype(np.int64)), T(gr["feat_cols"].astype(np.int64))] = T(gr["feat_vals"])
+        return adj, feats, T(gr["labels"].astype(np.int64)), T(gr["idx_train"].astype(np.int64)), 6
+    gr = golden("pubmed_graph_sym.npz")
+    n = int(gr["n"])
+    adj = torch.sparse_coo_tensor(torch.stack([T(gr["rows"].astype(np.int64)), T(gr["cols"].astype(np.int64))]),
+                                  T(gr["vals"]), (n, n))
+    gen = torch.Generator().manual_seed(0)
+    feats = (torch.rand(n, 500, generator=gen) < 0.1).float()
+    feats = feats / feats.sum(1, keepdim=True).clamp_min(1)
+    return adj, feats, torch.randint(0, 3, (n,), generator=gen), torch.arange(60), 3
+
+
+@pytest.mark.parametrize("name", ["citeseer", "pubmed"])
+def test_odegcn3_rk4_forward_backward_vs_oracle_on_citeseer_and_pubmed(golden, name):
+    """The north-star step (64 f-evals forward, adjoint backward) on the other two citation graphs of north_star's
+    parity clause, product vs oracle: logits to 1e-5, gradients to the fp32 noise floor (as on Cora above)."""
+    from graph_odenet_amd import models
+    adj, feats, labels, idx, ncls = _citation(golden, name)
+    torch.manual_seed(7)
+    m = models.ODEGCN3(nfeat=feats.shape[1], nhid=128, nclass=ncls, dropout=0.0, method="rk4", step_size=1 / 16)
+    with torch.no_grad():
+        m.gc2.odefunc.norm1.weight.uniform_(0.5, 1.5)
+        m.gc2.odefunc.norm1.bias.uniform_(-0.5, 0.5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    opts = {"step_size": 1 / 16}
+    ref_out, ref_g, _ = oracle_odegcn3(sd, feats, adj, "rk4", opts, 1e-5, labels, idx)
+    out64, g64, _ = oracle_odegcn3(sd, feats, adj, "rk4", opts, 1e-5, labels, idx, dtype=torch.float64)
+    m = m.to(dev())
+    m.train()
+    m.nfe = 0
+    out = m(feats.to(dev()), adj.to(dev()))
+    assert m.nfe == 64
+    noise_floor_check(out, ref_out, out64, "logits", slack=2.0)
+    close(out, ref_out, 2e-5, what="logits")
+    torch.nn.functional.nll_loss(out[idx.to(dev())], labels.to(dev())[idx.to(dev())]).backward()
+    for k, p in m.named_parameters():
+        noise_floor_check(p.grad, ref_g[k], g64[k], "grad " + k, slack=4.0)
