@@ -230,6 +230,28 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(
     }
 }
 
+// One column (sparse matrix x vector: the source-side sum of the attention-logit cotangents): a wave per record, the
+// lanes stride over its non-zeros (the generic kernel above would walk a 1 024-entry record with ONE thread).
+__global__ __launch_bounds__(256) void spmv_wave_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const int4* __restrict__ items, int n_items, float* __restrict__ partial,
+    const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, Epilogue ep)
+{
+    const int gid = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (gid >= n_items) return;
+    int row, b, e, slot = -1;
+    if (items) { const int4 it = items[gid]; row = it.x; b = it.y; e = it.z; slot = it.w; }
+    else { row = gid; b = rowptr[gid]; e = rowptr[gid + 1]; }
+    float acc = 0.f;
+    for (int j = b + lane; j < e; j += 64) acc = fmaf(val ? val[j] : 1.f, X[(int64_t)col[j] * ldx], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (slot < 0) epilogue_store1(ep, acc, row, 0, 1, Y, ldy);
+        else partial[slot] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void spmm_finish_generic_kernel(
     const int4* __restrict__ long_rows, int n_long, const float* __restrict__ partial,
     float* __restrict__ Y, int64_t ldy, int d, int G, Epilogue ep)
@@ -325,7 +347,12 @@ extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
         }
     }
     int G = 1; while (G < d && G < 64) G <<= 1;
-    {
+    if (d == 1 && it4 != nullptr) {                    // record lists only: whole short rows are cheaper one thread each
+        const int64_t blocks = ((int64_t)n_items * 64 + 255) / 256;
+        hipLaunchKernelGGL(spmv_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                           rowptr, col, val, it4, (int)n_items, partial, X, ldx, Y, ldy, ep);
+        GODE_LAUNCH_CHECK();
+    } else {
         const int64_t blocks = ((int64_t)n_items * G + 255) / 256;
         hipLaunchKernelGGL(spmm_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            rowptr, col, val, it4, (int)n_items, partial, X, ldx, Y, ldy, (int)d, G, ep);
