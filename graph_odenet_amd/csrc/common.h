@@ -95,4 +95,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// gemm.hip: raise a kernel's dynamic-LDS limit once per (device, kernel); thread-safe, a no-op up to 64 KB
+int gode_set_lds_once(const void* fn, size_t bytes);
+// rk.hip: out[0..n) = 0 by a kernel (never a memset node)
+int gode_zero_f32(float* out, int64_t n, void* stream);
+
 #define GODE_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

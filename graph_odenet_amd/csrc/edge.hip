@@ -1138,12 +1138,8 @@ extern "C" int gode_gat_maxpath_heads_f32(const float* a, float* da, int64_t n_e
     const int nb = head_blocks(n_edges);
     float* psum = (float*)scratch;
     int* pidx = (int*)(psum + (int64_t)kHeadBlocks * heads);
-    static int lds_set = 0;
-    if (!lds_set) {
-        (void)hipFuncSetAttribute((const void*)gat_maxpath_heads_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kMaxHeads * 256 * (int)sizeof(float));
-        lds_set = 1;
-    }
+    { const int rc = gode_set_lds_once((const void*)gat_maxpath_heads_part_kernel, (size_t)heads * 256 * sizeof(float));
+      if (rc) return rc; }
     hipLaunchKernelGGL(gat_maxpath_heads_part_kernel, dim3(nb), dim3(256), (size_t)heads * 256 * sizeof(float), s, a,
                        (const float*)da, tgt, (int)n_edges, (int)heads, psum, pidx);
     GODE_LAUNCH_CHECK();

@@ -99,7 +99,7 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
                                            j ? &acc : nullptr, ka, affine ? w->gp + j * nb * d : nullptr,
                                            affine ? w->bp + j * nb * d : nullptr, stream));
     if (affine) GODE_TRY(gode_reduce_parts2_f32(g_gamma, w->gp, g_beta, w->bp, 3 * nb, d, 1.f, 0, stream));
-    else GODE_HIP(hipMemsetAsync(g_gamma, 0, (size_t)2 * d * sizeof(float), (hipStream_t)stream));
+    else GODE_TRY(gode_zero_f32(g_gamma, 2 * d, stream));
     float* gW[3] = {g_src, g_tgt, g_log};
     const int64_t lenW[3] = {nW, nW, nL};
     const int64_t npw = gode_wgrad_parts(n);

@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(256) void gn_gemm_fwd_generic(LinComb xin, int n_ro
 __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_rows, int d_in, int groups, float eps,
                                                            const float* gamma, const float* W, int d_out,
                                                            int has_time, const float* dS, float out_scale, LinComb pre,
-                                                           float* dx, float* dgamma_part, float* dbeta_part)
+                                                           float* dx, float* dgamma_part, float* dbeta_part, int n_part)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                       // raw x  [RB][d_in]
@@ -1094,7 +1094,9 @@ __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_ro
                                               (pre.n > 0 ? lc_load1(pre, (int64_t)row * d_in + c) : 0.f);
             }
             if (dgamma_part) {
-                // per-block partial over the block's rows (accumulated across the grid-stride loop)
+                // per-block partial over the block's rows: written by the block's first pass of the grid-stride loop,
+                // accumulated by its later ones (same thread, same address), so the buffer needs no zeroing beforehand
+                const bool first = blk == (int)blockIdx.x;
                 for (int c = threadIdx.x; c < d_in; c += 256) {
                     const int gi = c / cg;
                     float sg = 0.f, sb = 0.f;
@@ -1104,8 +1106,10 @@ __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_ro
                         sg += dy[rr * d_in + c] * (xs[rr * d_in + c] - m) * rs;
                         sb += dy[rr * d_in + c];
                     }
-                    dgamma_part[(int64_t)blockIdx.x * d_in + c] += sg;
-                    dbeta_part[(int64_t)blockIdx.x * d_in + c] += sb;
+                    float* pg = dgamma_part + (int64_t)blockIdx.x * d_in + c;
+                    float* pb = dbeta_part + (int64_t)blockIdx.x * d_in + c;
+                    *pg = first ? sg : *pg + sg;
+                    *pb = first ? sb : *pb + sb;
                 }
             }
         } else {
@@ -1115,6 +1119,13 @@ __global__ __launch_bounds__(256) void gn_gemm_bwd_generic(LinComb xin, int n_ro
                 if (row < n_rows) dx[(int64_t)row * d_in + c] = out_scale * dy[idx] + (pre.n > 0 ? lc_load1(pre, (int64_t)row * d_in + c) : 0.f);
             }
         }
+    }
+    if (dgamma_part && groups > 0) {
+        // rows of the partial buffers that belong to no block (the caller sizes them for the largest grid of any path;
+        // a block beyond the last row block never enters the loop above)
+        const int owned = n_blk < (int)gridDim.x ? n_blk : (int)gridDim.x;
+        for (int p = owned + blockIdx.x; p < n_part; p += gridDim.x)
+            for (int c = threadIdx.x; c < d_in; c += 256) { dgamma_part[(int64_t)p * d_in + c] = 0.f; dbeta_part[(int64_t)p * d_in + c] = 0.f; }
     }
 }
 
@@ -1145,26 +1156,8 @@ __global__ __launch_bounds__(256) void wgrad_generic(LinComb xin, int n_rows, in
     }
 }
 
-// Dynamic LDS above 64 KB needs the function attribute once per (device, kernel); remembering it keeps the call out
-// of the launch path (and out of HIP-graph captures, where only stream operations should occur).
-int set_lds_once(const void* fn, size_t bytes) {
-    if (bytes <= 64 * 1024) return 0;
-    static std::mutex mu;
-    static std::map<std::pair<int, const void*>, size_t> done;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    std::lock_guard<std::mutex> lk(mu);
-    auto key = std::make_pair(dev, fn);
-    auto it = done.find(key);
-    if (it != done.end() && it->second >= bytes) return 0;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return (int)e;
-    done[key] = bytes;
-    return 0;
-}
 template <typename K>
-int set_lds(K kernel, size_t bytes) { return set_lds_once(reinterpret_cast<const void*>(kernel), bytes); }
+int set_lds(K kernel, size_t bytes) { return gode_set_lds_once(reinterpret_cast<const void*>(kernel), bytes); }
 
 int fast_cg(int64_t d_in, int64_t d_out, int32_t groups) {
     // returns CG (0,1,2,4) when the MFMA fast path applies, else -1
@@ -1201,6 +1194,25 @@ int64_t wgrad_blocks(int64_t n_rows) {
 }
 
 }  // namespace
+
+// Dynamic LDS above 64 KB needs the function attribute once per (device, kernel); remembering it keeps the call out
+// of the launch path (and out of HIP-graph captures, where only stream operations should occur).
+int gode_set_lds_once(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(dev, fn);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    done[key] = bytes;
+    return 0;
+}
 
 #define GODE_DISPATCH_NJ_CG(NJV, CGV, MACRO)                                        \
     if (nj == NJV && cg == CGV) { MACRO(NJV, CGV) }
@@ -1378,18 +1390,13 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
 #undef GODE_NBWD
         }
     }
-    if (dgamma_part && groups > 0) {        // the generic kernel accumulates into its block partials
-        hipError_t e = hipMemsetAsync(dgamma_part, 0, (size_t)n_part * d_in * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
-        e = hipMemsetAsync(dbeta_part, 0, (size_t)n_part * d_in * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
-    }
     const size_t g2 = (size_t)RB * (groups > 0 ? groups : 1) * 2;
     const size_t lds = ((size_t)RB * d_in * 2 + g2 * 2) * sizeof(float);
     rc = set_lds(gn_gemm_bwd_generic, lds); if (rc) return rc;
     int64_t blocks = (n_rows + RB - 1) / RB; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gn_gemm_bwd_generic, dim3((unsigned)blocks), dim3(256), lds, s, lc, (int)n_rows, (int)d_in,
-                       (int)groups, eps, gamma, W, (int)d_out, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part);
+                       (int)groups, eps, gamma, W, (int)d_out, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part,
+                       (int)n_part);
     GODE_LAUNCH_CHECK();
     return 0;
 }
@@ -1479,19 +1486,14 @@ extern "C" int gode_group_norm_f32_bwd(const float* x, int64_t n_rows, int64_t d
     if (n_rows > INT32_MAX || d > 2048) return GODE_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n_part = gode_group_norm_parts(n_rows);
-    if (dgamma_part) {
-        hipError_t e = hipMemsetAsync(dgamma_part, 0, (size_t)n_part * d * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
-        e = hipMemsetAsync(dbeta_part, 0, (size_t)n_part * d * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
-    }
     gode_lincomb_t lc; lc.n = 1; lc.coef[0] = 1.f; lc.ptr[0] = x;
     LinComb none = make_lincomb(nullptr);
     const size_t g2 = (size_t)RB * groups * 2;
     const size_t lds = ((size_t)RB * d * 2 + g2 * 2) * sizeof(float);
     int rc = set_lds(gn_gemm_bwd_generic, lds); if (rc) return rc;
     hipLaunchKernelGGL(gn_gemm_bwd_generic, dim3((unsigned)n_part), dim3(256), lds, s, make_lincomb(&lc), (int)n_rows, (int)d,
-                       (int)groups, eps, gamma, (const float*)nullptr, (int)d, 0, dy, 1.f, none, dx, dgamma_part, dbeta_part);
+                       (int)groups, eps, gamma, (const float*)nullptr, (int)d, 0, dy, 1.f, none, dx, dgamma_part, dbeta_part,
+                       (int)n_part);
     GODE_LAUNCH_CHECK();
     return 0;
 }

@@ -200,7 +200,7 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
         if (f->groups > 0) {
             GODE_TRY(gode_reduce_parts2_f32(kt + nW + d, ws->gpart, kt + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
         } else {
-            GODE_HIP(hipMemsetAsync(kt + nW + d, 0, (size_t)2 * d * sizeof(float), hs));
+            GODE_TRY(gode_zero_f32(kt + nW + d, 2 * d, stream));
         }
         if (s == 3) {
             // theta <- theta + h * sum b_s ktheta_s   (packed small components, one launch)
@@ -288,7 +288,7 @@ int dp_eval_adjoint(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws,
         const int64_t gparts = gode_gemm_bwd_parts(n);
         GODE_TRY(gode_reduce_parts2_f32(kth + nW + d, ws->gpart, kth + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
     } else {
-        GODE_HIP(hipMemsetAsync(kth + nW + d, 0, (size_t)2 * d * sizeof(float), (hipStream_t)stream));
+        GODE_TRY(gode_zero_f32(kth + nW + d, 2 * d, stream));
     }
     return 0;
 }

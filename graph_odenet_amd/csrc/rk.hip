@@ -264,6 +264,19 @@ extern "C" int gode_lincomb_f32(float* out, const gode_lincomb_t* lc, int64_t n,
     return 0;
 }
 
+// out[0..n) = 0 as a kernel launch (internal; declared in common.h).  hipMemsetAsync is avoided on purpose: inside a
+// HIP-graph capture it becomes a memset node, and replays of captured solves with memset nodes returned non-finite
+// GroupNorm gradients on this ROCm (DESIGN.md section 2, round-2 finding) - kernels only on the captured paths.
+int gode_zero_f32(float* out, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (!out) return GODE_E_NULLPTR;
+    LinComb none = make_lincomb(nullptr);
+    int64_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(lincomb1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, none, n);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int64_t gode_rk_errnorm_scratch_bytes(void) { return (int64_t)RED_BLOCKS * sizeof(double); }
 
 extern "C" int gode_rk_errnorm_f32(double* out, const float* y0, const float* y1, const gode_lincomb_t* elc,

@@ -321,6 +321,7 @@ extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
     if (!items) { n_items = n_rows; n_long = 0; }
     if (n_items < 0 || n_items > INT32_MAX || n_long < 0 || n_long > INT32_MAX) return GODE_E_RANGE;
     if (n_long > 0 && (!long_rows || !partial)) return GODE_E_NULLPTR;
+    if (n_items * 64 >= ((int64_t)1 << 32)) return GODE_E_RANGE;      // a launch holds fewer than 2^32 threads
     const float* bias = epi ? epi->bias : nullptr;
     float* Y2 = epi ? epi->Y2 : nullptr;
     const gode_lincomb_t* cot = (epi && Y2) ? &epi->cot : nullptr;
@@ -349,8 +350,10 @@ extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
     int G = 1; while (G < d && G < 64) G <<= 1;
     if (d == 1 && it4 != nullptr) {                    // record lists only: whole short rows are cheaper one thread each
         const int64_t blocks = ((int64_t)n_items * 64 + 255) / 256;
+        const int slot = gode_prof_begin(s, 1, n_items, (int64_t)ep.pre.n + ep.cot.n + (ep.Y2 ? 1 : 0));
         hipLaunchKernelGGL(spmv_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            rowptr, col, val, it4, (int)n_items, partial, X, ldx, Y, ldy, ep);
+        gode_prof_end(s, slot);
         GODE_LAUNCH_CHECK();
     } else {
         const int64_t blocks = ((int64_t)n_items * G + 255) / 256;

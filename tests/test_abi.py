@@ -39,3 +39,18 @@ def test_argument_validation_without_gpu():
     assert lib.gode_lincomb_f32(None, None, 4, None) == -1         # GODE_E_NULLPTR
     assert lib.gode_spmm_csr_f32(None, None, None, None, 0, None, 0, None, None, 4, None, 4, 3, 8, None, None) == -2  # ldx < d
     assert lib.gode_spmm_csr_f32(None, None, None, None, 0, None, 0, None, None, 8, None, 8, 3, 8, None, None) == -1  # null pointers
+
+
+def test_library_sources_launch_no_memset():
+    """Every entry point may be captured into a HIP graph (odeint.py: _GraphedSolve).  A hipMemsetAsync inside a
+    capture becomes a memset node, and replayed memset nodes do not reliably clear their range on this ROCm
+    (tools/dev/memset_node_repro.py: 299 of 300 replays wrong; round 1's non-finite 8-head gradients).  Buffers are
+    cleared by kernels (gode_zero_f32) or written in full by their producer."""
+    csrc = os.path.join(ROOT, "graph_odenet_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        code = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, name)).read())
+        code = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
+        for call in ("hipMemsetAsync", "hipMemset(", "hipMemsetD32", "hipMemset2D"):
+            assert call not in code, "%s calls %s" % (name, call)

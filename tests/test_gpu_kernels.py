@@ -58,6 +58,29 @@ def test_spmm_matches_cpu(d, pattern_only):
     close(ops.spmm(g.transpose(), Y.to(dev())), torch.sparse.mm(A.t(), Y), what="spmm^T")
 
 
+@pytest.mark.parametrize("weighted", [True, False])
+def test_spmm_one_column_record_path(weighted):
+    """d = 1 over a record list (spmv_wave_kernel: a wave per record, lanes stride over its non-zeros): against the
+    dense product, with split long rows (n_long > 0), empty rows, and the strided output the attention VJP uses
+    (column 0 of an N x 2 matrix, ldy = 2, the other column untouched)."""
+    from graph_odenet_amd import graph as G, ops
+    n, m = 1100, 1700
+    r, c, v = powerlaw_graph(n, m, 8, 11, long_row=900, empty=5, vals=weighted)
+    g = G.from_coo(r.to(dev()), c.to(dev()), None if v is None else v.to(dev()), n, m, split=64)
+    assert g.n_long >= 1 and g.items is not None
+    x = torch.randn(m, 1)
+    ref = g.to_dense().cpu().double() @ x.double()
+    close(ops.spmm(g, x.to(dev())), ref, what="one column")
+    out2 = torch.full((n, 2), 7.0, device=dev())
+    ops.spmm(g, x.to(dev()), out=out2[:, 0:1])
+    close(out2[:, 0:1], ref, what="one column, ldy = 2")
+    assert bool((out2[:, 1] == 7.0).all()), "the neighbouring column was written"
+    b = torch.randn(1)
+    close(ops.spmm(g, x.to(dev()), bias=b.to(dev()), relu=True), (ref + b.double()).clamp_min(0), what="bias + relu")
+    y = torch.randn(n, 1)
+    close(ops.spmm(g.transpose(), y.to(dev())), g.to_dense().cpu().double().t() @ y.double(), what="transposed")
+
+
 def test_spmm_masked_cotangent_epilogue():
     from graph_odenet_amd import graph as G, ops
     n, d = 900, 128
