@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # same guide, "Matrix cores": f32-input MFMA = the fp32 vector rate
 
 
 def parse():
@@ -194,7 +195,7 @@ def main():
     for _ in range(args.warmup):
         step()
     model.nfe = 0
-    cap = args.steps * (3 * 4 * args.ode_steps + 8) + 16
+    cap = args.steps * (8 * 4 * args.ode_steps + 32) + 64
     prof = lib.gode_prof_create(cap)
     lib.gode_prof_enable(prof)
     barrier()
@@ -211,24 +212,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = tmax.item()
 
-    # ---- roofline of the dominant kernel (SpMM main kernel at d = hidden) ---------------------
+    # ---- roofline of the dominant kernel (SpMM main kernel at d = hidden) and of the dense kernels --------------
     ms = (ctypes.c_float * cap)()
     dd = (ctypes.c_int64 * cap)()
     rr = (ctypes.c_int64 * cap)()
     xx = (ctypes.c_int64 * cap)()
+    kk = (ctypes.c_int32 * cap)()
     cnt = lib.gode_prof_read(prof, ms, dd, rr, xx, cap)
-    sel = [i for i in range(max(cnt, 0)) if dd[i] == args.hidden and rr[i] in (g.n_items, g.transpose().n_items)]
+    lib.gode_prof_kinds(prof, kk, cap)
+    from graph_odenet_amd.gcn_ode import tuned_graph
+    g_run = tuned_graph(g, args.hidden)[0]        # the (possibly renumbered) graph the ODE block ran on; cached by the solve
+    sel = [i for i in range(max(cnt, 0)) if kk[i] == 0 and dd[i] == args.hidden
+           and rr[i] in (g_run.n_items, g_run.transpose().n_items)]
     lib.gode_prof_destroy(prof)
     roof = None
+    nd4 = n * args.hidden * 4
     if sel:
         tot_ms = sum(ms[i] for i in sel)
         avg_ms = tot_ms / len(sel)
-        # algorithmic bytes per launch: SURVEY 8(d) B_alg of the product itself + the N x d operand arrays the
-        # fused epilogue of THAT launch reads / writes (RK combine terms, adjoint cotangent terms, masked output)
+        # B_alg = nnz*(4+4+4d) + (N+1)*4 + N*d*4 per launch; `frac` prices exactly that.  The fused
+        # epilogue of a launch also reads / writes further N x d arrays (RK combine terms, adjoint cotangent terms,
+        # the masked output): those bytes are reported separately as frac_with_epilogue_operands.
         b_alg = g.algorithmic_bytes(args.hidden)
-        nd4 = n * args.hidden * 4
         tot_bytes = sum(b_alg + xx[i] * nd4 for i in sel)
-        ach = tot_bytes / (tot_ms * 1e-3) / 1e9
+        ach = b_alg / (avg_ms * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "spmm_traffic.json")
         if os.path.exists(tf) and (args.scale, args.edges, args.hidden) == (20, 10_000_000, 128):   # measured on THIS workload only
@@ -240,10 +247,30 @@ def main():
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "spmm_vec4_kernel<%d>" % (args.hidden // 4), "launches_timed": len(sel),
-                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(tot_bytes / len(sel)),
-                "algorithmic_bytes_plain_product": b_alg, "compulsory_bytes_plain_product": b_min,
-                "frac_plain_product": round(b_alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "epilogue_operand_arrays_per_launch": round(sum(xx[i] for i in sel) / len(sel), 3)}
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": b_alg,
+                "compulsory_bytes_per_launch": b_min,
+                "frac_with_epilogue_operands": round(tot_bytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "epilogue_operand_arrays_per_launch": round(sum(xx[i] for i in sel) / len(sel), 3),
+                "node_order": "renumbered (measured faster: %.3f -> %.3f ms per plain product)" % g.__dict__["_tuned_times"]
+                              if g_run is not g else "as given"}
+    # dense kernels (exact-fp32 MFMA): 2*N*d*d flop per launch against the fp32 matrix peak.  Durations are AS
+    # SCHEDULED: in the adjoint the VJP runs beside the weight gradient / next forward product on a second stream.
+    dense = None
+    names = {1: "gn_gemm_fwd_kernel", 2: "gn_gemm_bwd_kernel", 3: "wgrad_kernel"}
+    flop = 2.0 * n * args.hidden * args.hidden
+    for kind, nm in names.items():
+        ix = [i for i in range(max(cnt, 0)) if kk[i] == kind and dd[i] == args.hidden and rr[i] == n]
+        if not ix:
+            continue
+        if dense is None:
+            dense = {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_launch": flop, "kernels": {}}
+        avg = sum(ms[i] for i in ix) / len(ix)
+        plain = {1: 2, 2: 3, 3: 2}[kind]                                  # N x d arrays a one-term launch reads + writes
+        byts = sum((plain + xx[i]) * nd4 for i in ix) / len(ix)
+        dense["kernels"]["%s<%d,%d>" % (nm, args.hidden // 16, args.hidden // min(32, args.hidden))] = {
+            "launches_timed": len(ix), "avg_launch_ms": round(avg, 4), "achieved": round(flop / (avg * 1e-3) / 1e12, 1),
+            "frac": round(flop / (avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "algorithmic_bytes_per_launch": int(byts), "hbm_GBps": round(byts / (avg * 1e-3) / 1e9, 1)}
 
     extras = None
     if world == 1 and not args.no_secondary:
@@ -273,6 +300,7 @@ def main():
                        "parallelism": "dp%d (one graph per rank, 1 gradient all-reduce/step)" % world},
             "loss": round(float(loss), 5),
             "roofline": roof,
+            "roofline_dense": dense,
         }
         if extras is not None:
             res["secondary"] = extras

@@ -155,6 +155,7 @@ SIGNATURES = {
     "gode_prof_reset": (None, [c_p]),
     "gode_prof_count": (c_i, [c_p]),
     "gode_prof_read": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i]),
+    "gode_prof_kinds": (c_i, [c_p, c_p, c_i]),
 }
 
 _lib = None

@@ -22,6 +22,7 @@
 #include <utility>
 #include "common.h"
 #include "options.h"
+#include "prof.h"
 
 namespace {
 
@@ -1272,9 +1273,11 @@ extern "C" int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin, int64_t n_r
         const int64_t blocks = fwd_blocks(n_rows);
 #define GODE_FWD(NJV, CGV)                                                                          \
         { rc = set_lds(gn_gemm_fwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1 + (x_out ? 1 : 0), GODE_PROF_GEMM_FWD); \
           hipLaunchKernelGGL((gn_gemm_fwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
                              lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S, x_out,           \
                              (const float*)nullptr, (float*)nullptr);                               \
+          gode_prof_end(s, slot);                                                                   \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_FWD)
 #undef GODE_FWD
@@ -1369,8 +1372,10 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
         const int64_t blocks = fwd_blocks(n_rows);
 #define GODE_BWD(NJV, CGV)                                                                          \
         { rc = set_lds(gn_gemm_bwd_kernel<NJV, CGV>, lds); if (rc) return rc;                       \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1 + lpre.n, GODE_PROF_GEMM_BWD); \
           hipLaunchKernelGGL((gn_gemm_bwd_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
                              lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part, (int)n_part); \
+          gode_prof_end(s, slot);                                                                   \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_BWD)
 #undef GODE_BWD
@@ -1423,8 +1428,10 @@ extern "C" int gode_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t
         const size_t lds = (size_t)2 * 32 * (d_in + 16) * sizeof(float);
 #define GODE_WG(NJV, CGV)                                                                           \
         { rc = set_lds(wgrad_kernel<NJV, CGV>, lds); if (rc) return rc;                             \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1, GODE_PROF_WGRAD);   \
           hipLaunchKernelGGL((wgrad_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s,   \
                              lc, (int)n_rows, eps, gamma, beta, dS, has_time, dW_part);             \
+          gode_prof_end(s, slot);                                                                   \
           GODE_LAUNCH_CHECK(); return 0; }
         GODE_DISPATCH_ALL(GODE_WG)
 #undef GODE_WG

@@ -11,6 +11,7 @@ struct GodeProf {
     int count;
     std::vector<hipEvent_t> ev;      // 2*capacity
     std::vector<int64_t> d, rows, extra;
+    std::vector<int32_t> kind;
 };
 
 // process-global on purpose: torch's autograd engine runs backward on its own thread
@@ -20,7 +21,7 @@ extern "C" void* gode_prof_create(int capacity) {
     if (capacity <= 0) return nullptr;
     GodeProf* p = new GodeProf();
     p->capacity = capacity; p->count = 0;
-    p->ev.resize(2 * (size_t)capacity); p->d.resize(capacity); p->rows.resize(capacity); p->extra.resize(capacity);
+    p->ev.resize(2 * (size_t)capacity); p->d.resize(capacity); p->rows.resize(capacity); p->extra.resize(capacity); p->kind.resize(capacity);
     for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { delete p; return nullptr; }
     return p;
 }
@@ -51,11 +52,19 @@ extern "C" int gode_prof_read(void* prof, float* ms, int64_t* d, int64_t* rows, 
     return n;
 }
 
-int gode_prof_begin(hipStream_t s, int64_t d, int64_t rows, int64_t extra) {
+extern "C" int gode_prof_kinds(void* prof, int32_t* kinds, int max_n) {
+    GodeProf* p = (GodeProf*)prof;
+    if (!p || !kinds) return GODE_E_NULLPTR;
+    const int n = p->count < max_n ? p->count : max_n;
+    for (int i = 0; i < n; ++i) kinds[i] = p->kind[i];
+    return n;
+}
+
+int gode_prof_begin(hipStream_t s, int64_t d, int64_t rows, int64_t extra, int kind) {
     GodeProf* p = g_prof;
     if (!p || p->count >= p->capacity) return -1;
     const int i = p->count;
-    p->d[i] = d; p->rows[i] = rows; p->extra[i] = extra;
+    p->d[i] = d; p->rows[i] = rows; p->extra[i] = extra; p->kind[i] = kind;
     (void)hipEventRecord(p->ev[2 * i], s);
     return i;
 }

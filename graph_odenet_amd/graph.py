@@ -103,6 +103,37 @@ class CSRGraph:
             self._T._T = self
         return self._T
 
+    # -- node renumbering ---------------------------------------------------------
+    def degree_order(self):
+        """Nodes by decreasing (row + column) degree, ties in the given order: hubs first."""
+        rp = self.rowptr.to(torch.int64)
+        deg = rp[1:] - rp[:-1]
+        deg = deg + torch.bincount(self.col.to(torch.int64), minlength=self.n_cols)[: self.n_rows]
+        return torch.argsort(deg, descending=True, stable=True)
+
+    def relabel(self, order):
+        """P A P^T for the renumbering that puts old node order[k] at position k (square matrices).  Every row keeps
+        its entries in the order they have here (a CSR row need not be column-sorted), and so does every row of the
+        transpose, so A' (P x) = P (A x) and A'^T (P x) = P (A^T x) BIT FOR BIT: the kernels add the same numbers in
+        the same order, only the addresses of the operand rows change."""
+        if self.n_rows != self.n_cols:
+            raise ValueError("relabel: square matrices only")
+        order = order.to(torch.int64)
+        new_id = torch.empty_like(order)
+        new_id[order] = torch.arange(self.n_rows, device=self.device)
+
+        def one(g):
+            rp = g.rowptr.to(torch.int64)
+            deg = (rp[1:] - rp[:-1])[order]
+            rowptr = torch.zeros(g.n_rows + 1, dtype=torch.int64, device=g.device)
+            rowptr[1:] = torch.cumsum(deg, 0)
+            idx = torch.repeat_interleave(rp[order] - rowptr[:-1], deg) + torch.arange(g.nnz, device=g.device)
+            return CSRGraph(rowptr, new_id[g.col.to(torch.int64)[idx]], None if g.val is None else g.val[idx],
+                            g.n_rows, g.n_cols, split=g.split)
+        out, out_t = one(self), one(self.transpose())
+        out._T, out_t._T = out_t, out
+        return out
+
     def to_dense(self):
         rp = self.rowptr.to(torch.int64)
         rows = torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), rp[1:] - rp[:-1])

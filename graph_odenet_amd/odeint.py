@@ -224,6 +224,11 @@ def _fields(func, y0):
     return AutogradField(func, y0), (lambda: AutogradAdjointField(func, params, y0)), params
 
 
+def _rows(field):
+    """(order, inverse) when the field integrates on renumbered nodes (state rows y' = y[order]), else (None, None)."""
+    return getattr(field, "row_order", None), getattr(field, "row_inverse", None)
+
+
 def _bump_nfe(func, n):
     # fused fields do not call func.forward; keep the reference's counter (GCN/models.py:173) alive
     if getattr(func, "_gode_counts_nfe", False):
@@ -237,12 +242,13 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     method = _method(method)
     fwd, _, _ = _fields(func, y0)
     stats = Dopri5Stats()
-    ys = [y0.detach().contiguous().clone()]
-    outs = [ys[0].clone()]
+    order, inverse = _rows(fwd)
+    ys = [y0.detach().contiguous().clone() if order is None else y0.detach().index_select(0, order)]
+    outs = [y0.detach().contiguous().clone()]
     with torch.no_grad():
         for i in range(1, len(tl)):
             _integrate(fwd, ys, tl[i - 1], tl[i], rtol, atol, method, options, stats)
-            outs.append(ys[0].clone())
+            outs.append(ys[0].clone() if order is None else ys[0].index_select(0, inverse))
     _bump_nfe(func, stats.nfe if getattr(fwd, "fused", False) else 0)
     return torch.stack(outs)
 
@@ -252,7 +258,10 @@ class _OdeintAdjoint(torch.autograd.Function):
     def forward(ctx, func, tl, rtol, atol, method, options, y0, *params):
         plan, (fwd, mk_adj, plist) = _plan_for(func, y0, tl, method, options, params)
         stats = Dopri5Stats()
+        order, inverse = _rows(fwd)
         y_start = y0.detach().contiguous()
+        if order is not None:
+            y_start = y_start.index_select(0, order)          # state rows in the renumbered graph's order
         if plan is not None and plan.gf is None and plan.seen_f >= 1 and not plan.no_capture:
             plan.gf = _try_capture(plan, fwd, [y_start.clone()], tl[0], tl[1])
         if plan is not None and plan.gf is not None:
@@ -268,13 +277,18 @@ class _OdeintAdjoint(torch.autograd.Function):
             if plan is not None:
                 plan.seen_f += 1
         _bump_nfe(func, stats.nfe if getattr(fwd, "fused", False) else 0)
-        ans = torch.stack(outs)
+        ans_p = torch.stack(outs)                             # in the field's row order: what the adjoint starts from
+        if order is None:
+            ans = ans_p
+        else:
+            ans = torch.stack([y0.detach().contiguous().clone()] + [o.index_select(0, inverse) for o in outs[1:]])
         ctx.func, ctx.tl, ctx.rtol, ctx.atol, ctx.method, ctx.options = func, tl, rtol, atol, method, options
         ctx.mk_adj = mk_adj
         ctx.fwd = fwd
         ctx.plan = plan
         ctx.n_params = len(params)
-        ctx.save_for_backward(ans)
+        ctx.rows = (order, inverse)
+        ctx.save_for_backward(ans_p)
         return ans
 
     @staticmethod
@@ -282,6 +296,10 @@ class _OdeintAdjoint(torch.autograd.Function):
         (ans,) = ctx.saved_tensors
         func, tl = ctx.func, ctx.tl
         grad_out = grad_out.contiguous()
+        order, inverse = ctx.rows
+        if order is not None:
+            grad_out = grad_out.index_select(1, order)
+        back = (lambda g: g) if order is None else (lambda g: g.index_select(0, inverse))
         plan = ctx.plan
         if plan is not None and plan.seen_b >= 1 and plan.gb is None and not plan.no_capture:
             with torch.no_grad():
@@ -293,7 +311,7 @@ class _OdeintAdjoint(torch.autograd.Function):
                 comps = plan.gb.run(vals)
                 comps[1].add_(grad_out[0])
             _bump_nfe(func, plan.gb.nfe)
-            return (None, None, None, None, None, None, comps[1], *plan.adj.param_grads(comps))
+            return (None, None, None, None, None, None, back(comps[1]), *plan.adj.param_grads(comps))
         if plan is not None:
             plan.seen_b += 1
         adj = ctx.mk_adj()
@@ -322,7 +340,7 @@ class _OdeintAdjoint(torch.autograd.Function):
                 comps[1].add_(grad_out[i - 1])
         _bump_nfe(func, stats.nfe if getattr(adj, "fused", False) else 0)
         pg = adj.param_grads(comps) if hasattr(adj, "param_grads") else comps[3:]
-        return (None, None, None, None, None, None, comps[1], *pg)
+        return (None, None, None, None, None, None, back(comps[1]), *pg)
 
 
 def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):

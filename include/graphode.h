@@ -383,12 +383,19 @@ int gode_gat_ode_dopri5_step_adjoint(const gode_gat_odefunc_t* f, const float* y
                                      const gode_gat_workspace_t* ws, double t, double h, float rtol, float atol,
                                      double* sums /* 4 */, void* err_scratch, void* stream);
 
-/* ---- measurement aid (bench.py): HIP-event brackets around the SpMM main kernel ----------
- * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 fast-path launch
- * records a start/stop event pair on its stream (up to `capacity` launches).
+/* ---- measurement aid (bench.py): HIP-event brackets around the dominant kernels ----------
+ * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 main-kernel launch
+ * and every MFMA-path launch of the dense kernels (gn_gemm_fwd / gn_gemm_bwd / wgrad) records a start/stop event pair
+ * on the stream it is launched on (up to `capacity` launches).
  * gode_prof_read waits for the recorded events and returns the number of launches read, with
- * per-launch milliseconds, feature width d, record count and `extra` = number of additional
- * n_rows x d operand arrays the epilogue read or wrote (pre terms + cotangent terms + Y2). */
+ * per-launch milliseconds, feature width d, record count (SpMM) or row count (dense) and `extra` = number of
+ * additional n_rows x d operand arrays the launch read or wrote besides its plain operands (SpMM: pre terms +
+ * cotangent terms + Y2; dense: stage terms beyond the first, + x_out, + pre terms).
+ * gode_prof_kinds: what each launch was - GODE_PROF_SPMM / _GEMM_FWD / _GEMM_BWD / _WGRAD. */
+#define GODE_PROF_SPMM     0
+#define GODE_PROF_GEMM_FWD 1
+#define GODE_PROF_GEMM_BWD 2
+#define GODE_PROF_WGRAD    3
 void* gode_prof_create(int capacity);
 void  gode_prof_destroy(void* prof);
 void  gode_prof_enable(void* prof /* NULL = off */);
@@ -396,6 +403,7 @@ void  gode_prof_reset(void* prof);
 int   gode_prof_count(void* prof);
 int   gode_prof_read(void* prof, float* ms /* host */, int64_t* d /* host, nullable */,
                      int64_t* rows /* host, nullable */, int64_t* extra /* host, nullable */, int max_n);
+int   gode_prof_kinds(void* prof, int32_t* kinds /* host */, int max_n);
 
 #ifdef __cplusplus
 }

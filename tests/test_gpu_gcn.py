@@ -438,6 +438,53 @@ def test_hip_graph_captured_solves_match_eager(native, d):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_renumbered_ode_block_is_bit_identical(method):
+    """Large graphs are integrated on a renumbering of their nodes when that is measured faster (gcn_ode.tuned_graph:
+    hubs first; the solver permutes the state rows on entry and exit).  Forced here on a small power-law graph: outputs,
+    the input gradient and every parameter gradient equal the unrenumbered run bit for bit, and the SpMM on the
+    renumbered graph is the row permutation of the SpMM on the given one."""
+    from graph_odenet_amd import gcn_ode, graph as G, models, ops
+    n, d = 3000, 64
+    rs = np.random.RandomState(9)
+    deg = rs.zipf(1.7, n).clip(1, 400)
+    r = torch.from_numpy(np.repeat(np.arange(n), deg))
+    c = torch.from_numpy(rs.randint(0, n, r.numel()) // rs.randint(1, 40, r.numel()))          # skewed towards low ids
+    key = torch.unique(r * n + c)
+    r, c = key // n, key % n
+    v = 1.0 / torch.bincount(r, minlength=n).float()[r]
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n)).to(dev())
+    g = G.as_graph(adj)
+    order = g.degree_order()
+    h = g.relabel(order)
+    X = torch.randn(n, d, device=dev())
+    assert torch.equal(ops.spmm(h, X[order]), ops.spmm(g, X)[order])
+    assert torch.equal(ops.spmm(h.transpose(), X[order]), ops.spmm(g.transpose(), X)[order])
+    x = torch.randn(n, d, device=dev())
+    gout = torch.randn(n, d, device=dev())
+    res = {}
+    saved = (gcn_ode.RELABEL_MIN_OPERAND_BYTES, gcn_ode.RELABEL_MIN_NNZ, gcn_ode.RELABEL_MIN_GAIN)
+    for forced in (False, True):
+        g.__dict__.pop("_tuned", None)
+        if forced:
+            gcn_ode.RELABEL_MIN_OPERAND_BYTES, gcn_ode.RELABEL_MIN_NNZ, gcn_ode.RELABEL_MIN_GAIN = 0, 0, -1e9
+        try:
+            torch.manual_seed(3)
+            blk = models.ODEBlock(models.ODEfunc(d), method=method, step_size=0.25 if method == "rk4" else None).to(dev())
+            xi = x.clone().requires_grad_(True)
+            out = blk(xi, adj)
+            out.backward(gout)
+            res[forced] = (out.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()], blk.nfe)
+            assert (gcn_ode.tuned_graph(g, d)[1] is not None) == forced
+        finally:
+            gcn_ode.RELABEL_MIN_OPERAND_BYTES, gcn_ode.RELABEL_MIN_NNZ, gcn_ode.RELABEL_MIN_GAIN = saved
+            g.__dict__.pop("_tuned", None)
+    assert res[True][3] == res[False][3]
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("name,nl", [("GCNK", 2), ("GCNK", 4), ("GCNKnorm", 2), ("GCNKnorm", 5), ("RESK1", 3), ("RESK1", 5),
                                      ("RESK2", 4), ("RESK2", 7), ("RESK1norm", 3), ("RESK1norm", 6), ("RESK2norm", 4),
                                      ("RESK2norm", 7), ("RESK", 5), ("RESK", 6), ("RESKnorm", 5), ("RESKnorm", 6)])

@@ -109,16 +109,23 @@ def test_spmm_row_sum_property_full_size():
     ones = torch.ones(n, d, device=dev())
     out = ops.spmm(g, ones)
     assert (out - 1).abs().max().item() < 1e-5
-    x1 = torch.randn(n, d, device=dev())
-    x2 = torch.randn(n, d, device=dev())
+    gen = torch.Generator(device=dev()).manual_seed(123)
+    x1 = torch.randn(n, d, device=dev(), generator=gen)
+    x2 = torch.randn(n, d, device=dev(), generator=gen)
     lhs = ops.spmm(g, 2.0 * x1 - 0.5 * x2)
     rhs = 2.0 * ops.spmm(g, x1) - 0.5 * ops.spmm(g, x2)
     assert (lhs - rhs).abs().max().item() < 1e-4
     # <A x, y> == <x, A^T y>
-    y = torch.randn(n, d, device=dev())
-    a = (ops.spmm(g, x1).double() * y.double()).sum()
-    b = (x1.double() * ops.spmm(g.transpose(), y).double()).sum()
-    assert abs(a.item() - b.item()) <= 1e-6 * max(1.0, abs(a.item()))
+    y = torch.randn(n, d, device=dev(), generator=gen)
+    ta = ops.spmm(g, x1).double() * y.double()
+    tb = x1.double() * ops.spmm(g.transpose(), y).double()
+    a, b = ta.sum(), tb.sum()
+    # both sides are sums of 1.3e8 fp32-rounded terms (the products themselves are added in fp64 here): their
+    # difference is a random walk of the terms' rounding errors, a few ulp each - measured 1.0e-3 on |a| = 890.
+    # A wrong transpose is off by the order of |a| itself.
+    noise = 2.0 ** -24 * (ta.square().sum() + tb.square().sum()).sqrt().item()
+    assert abs(a.item()) > 100 * 32 * noise
+    assert abs(a.item() - b.item()) <= 32 * noise, (a.item(), b.item(), noise)
 
 
 def test_lincomb_and_error_norms():

@@ -67,3 +67,31 @@ def test_algorithmic_bytes_formula():
     g = G.from_coo(r, c, v, 10, 10)
     d = 128
     assert g.algorithmic_bytes(d) == g.nnz * (4 + 4 + 4 * d) + 11 * 4 + 10 * d * 4
+
+
+def test_relabel_is_a_symmetric_permutation_with_row_entries_in_place():
+    """CSRGraph.relabel(order): P A P^T with every row's entries (and every row's of the transpose) kept in their
+    original order - what makes the renumbered SpMM bit-identical (gcn_ode.tuned_graph)."""
+    from graph_odenet_amd import graph as G
+    g0 = torch.Generator().manual_seed(5)
+    n = 57
+    r, c = torch.randint(0, n, (400,), generator=g0), torch.randint(0, n, (400,), generator=g0)
+    v = torch.rand(400, generator=g0) + 0.1
+    g = G.from_coo(r, c, v, n, n)
+    order = g.degree_order()
+    assert sorted(order.tolist()) == list(range(n))
+    h = g.relabel(order)
+    A, B = g.to_dense(), h.to_dense()
+    assert torch.equal(B, A[order][:, order])
+    assert torch.equal(h.transpose().to_dense(), B.t())
+    new_id = torch.empty(n, dtype=torch.int64)
+    new_id[order] = torch.arange(n)
+    for k in range(n):                      # row k of h = row order[k] of g, same entry order, columns renamed
+        old = int(order[k])
+        a0, a1 = int(g.rowptr[old]), int(g.rowptr[old + 1])
+        b0, b1 = int(h.rowptr[k]), int(h.rowptr[k + 1])
+        assert b1 - b0 == a1 - a0
+        assert torch.equal(h.col[b0:b1].long(), new_id[g.col[a0:a1].long()])
+        assert torch.equal(h.val[b0:b1], g.val[a0:a1])
+    deg = (g.rowptr[1:] - g.rowptr[:-1]).long() + torch.bincount(g.col.long(), minlength=n)
+    assert bool((deg[order][:-1] >= deg[order][1:]).all())
