@@ -198,19 +198,11 @@ def main():
     cap = args.steps * (8 * 4 * args.ode_steps + 32) + 64
     prof = lib.gode_prof_create(cap)
     lib.gode_prof_enable(prof)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # exactly `steps` steps between barrier + synchronize on both sides, MAX over ranks (parallel.run_timed: the same
+    # helper the world_size-2 gloo test drives)
+    elapsed, loss = parallel.run_timed(step, args.steps, 0, dev)
     lib.gode_prof_enable(None)
     nfe_per_step = model.nfe / max(args.steps, 1)
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = tmax.item()
 
     # ---- roofline of the dominant kernel (SpMM main kernel at d = hidden) and of the dense kernels --------------
     ms = (ctypes.c_float * cap)()

@@ -6,6 +6,9 @@
 // sequence of an rk4 (3/8 rule) forward solve or adjoint solve from C with no allocation and no
 // synchronisation, which also makes the call capturable into a HIP graph by the caller.
 // Launch sequence per stage = graph_odenet_amd/gcn_ode.py (GcnOdeField / GcnOdeAdjointField).
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 #include "options.h"
 
@@ -90,23 +93,32 @@ extern "C" int gode_gcn_ode_rk4_forward(const gode_gcn_odefunc_t* f, float* y, f
 
 namespace {
 
-// Side stream + events for the two-chain schedule of the adjoint solve (created once per process/device).
+// Side stream + events for the two-chain schedule of the adjoint solve: one set per (device, caller stream), created
+// on first use and kept for the life of the process, so that two caller streams (or two threads, each on its own
+// stream) never share a side stream or an event.  The map is the only mutable state here and is mutex-guarded.
 struct Overlap {
     hipStream_t side = nullptr;
     hipEvent_t sp = nullptr, gf = nullptr, spt = nullptr, wg = nullptr;
     bool ok = false;
 };
-Overlap* overlap_ctx() {
-    static Overlap ctx = [] {
-        Overlap c;
-        if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return c;
+Overlap* overlap_ctx(hipStream_t caller) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Overlap*> ctxs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(dev, caller);
+    auto it = ctxs.find(key);
+    if (it != ctxs.end()) return it->second;
+    Overlap* c = new Overlap();
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess) {
         bool ok = true;
-        for (hipEvent_t* ev : {&c.sp, &c.gf, &c.spt, &c.wg})
+        for (hipEvent_t* ev : {&c->sp, &c->gf, &c->spt, &c->wg})
             ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
-        c.ok = ok;
-        return c;
-    }();
-    return &ctx;
+        c->ok = ok;
+    }
+    ctxs[key] = c;
+    return c;
 }
 #define GODE_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return (int)e__; } while (0)
 
@@ -132,8 +144,10 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
     const int64_t nW = (d + 1) * d, P = gode_gcn_ode_theta_len(d);
     const double h = ((double)t1 - (double)t0) / n_steps;   // negative: the adjoint runs from t0 (later) to t1 (earlier)
     hipStream_t hs = (hipStream_t)stream;
-    Overlap* ov = overlap_ctx();
-    const bool two = ov->ok && ws->S2 != nullptr && gode_opt_overlap();
+    // the side stream exists only for callers that ask for the two-chain schedule (never created inside a capture:
+    // odeint turns the option off around its HIP-graph captures)
+    Overlap* ov = (ws->S2 != nullptr && gode_opt_overlap()) ? overlap_ctx(hs) : nullptr;
+    const bool two = ov != nullptr && ov->ok;
     void* side = two ? (void*)ov->side : stream;
     float* Sbuf[2] = {ws->S, two ? ws->S2 : ws->S};
     float* ycur = y; float* acur = a;

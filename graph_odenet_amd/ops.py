@@ -105,12 +105,15 @@ _retired = []      # outgrown scratch buffers stay allocated: captured HIP graph
 
 
 def _scratch(device, nbytes):
-    buf = _red_scratch.get(device)
+    """Reduction scratch of the CURRENT stream of `device`: launches on one stream are ordered, so they can share a
+    buffer; two streams (or two threads on their own streams) each get their own."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _red_scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
             _retired.append(buf)
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _red_scratch[device] = buf
+        _red_scratch[key] = buf
     return buf
 
 

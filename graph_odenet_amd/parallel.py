@@ -38,53 +38,166 @@ def broadcast_parameters(module, src=0):
 
 
 class GradBucket:
-    """Persistent flat buffer so that the all-reduce is a single collective per step.  The parameters' `.grad`
-    tensors are made VIEWS of the buffer (autograd accumulates into an existing `.grad` in place), so no gradient is
-    copied in or out around the collective as long as the optimiser keeps them (`zero_grad(set_to_none=False)`);
-    a gradient that was dropped or replaced in the meantime is copied in and re-attached."""
+    """Gradient exchange of data-parallel training: ONE persistent flat fp32 buffer, cut into buckets of about
+    `bucket_bytes` in REVERSE registration order (the order backward produces gradients in), each bucket all-reduced
+    by one collective.  The parameters' `.grad` tensors are VIEWS of the buffer (autograd accumulates into an existing
+    `.grad` in place), so nothing is copied in or out around the collectives as long as the optimiser keeps them
+    (`zero_grad(set_to_none=False)`); a gradient that was dropped or replaced is copied in and re-attached.
 
-    def __init__(self, module):
+    overlap=True (default): a post-accumulate hook on every parameter launches its bucket's all-reduce (async) the
+    moment the bucket's last gradient has been written, i.e. WHILE backward is still computing the earlier layers -
+    SURVEY.md section 8(e): the 57 MB gradient of the QC model is dominated by the edge encoder, whose bucket can travel
+    while the message rounds are still in backward.  One backward per step in this mode (gradient accumulation over
+    several backward calls: overlap=False).  `allreduce_mean()` / `allreduce_sum()` finish the step: they launch what
+    is still pending, wait, and scale.
+
+    Parameters without a gradient: counted as zero on this rank; a parameter that received no gradient on ANY rank
+    gets `.grad = None` back, as in a single-process run (the optimiser then skips it instead of applying weight
+    decay / momentum to it) - one small mask all-reduce per step decides."""
+
+    def __init__(self, module, bucket_bytes=16 << 20, overlap=True):
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views = []
-        o = 0
-        for p in self.params:
+        self.mask = torch.zeros(max(len(self.params), 1), dtype=torch.float32, device=dev)
+        self.views = [None] * len(self.params)
+        self.buckets = []                     # (lo, hi, [param indices]) over the flat buffer, in launch order
+        o, cur, lo = 0, [], 0
+        for i in reversed(range(len(self.params))):      # flat layout = reverse registration order
+            p = self.params[i]
             k = p.numel()
             v = self.flat[o:o + k].view_as(p)
             if p.grad is not None:
                 v.copy_(p.grad)
             p.grad = v
-            self.views.append(v)
+            self.views[i] = v
+            cur.append(i)
             o += k
+            if (o - lo) * 4 >= bucket_bytes:
+                self.buckets.append((lo, o, cur))
+                cur, lo = [], o
+        if cur:
+            self.buckets.append((lo, o, cur))
+        self._bucket_of = {i: b for b, (_, _, idx) in enumerate(self.buckets) for i in idx}
+        self.overlap = bool(overlap)
+        self._reset()
+        # the hooks also tell which parameters received a gradient in this step (a kept `.grad` view looks the same
+        # whether or not backward wrote to it), so they are registered in both modes
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    def _reset(self):
+        self._ready = [0] * len(self.buckets)
+        self._seen = [False] * len(self.params)
+        self._work = [None] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+
+    def _attach(self, i):
+        p, v = self.params[i], self.views[i]
+        if p.grad is None:
+            return False
+        if p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)
+            p.grad = v
+        return True
+
+    def _make_hook(self, i):
+        def hook(_param):
+            if _alone() or self._seen[i]:
+                return
+            self._seen[i] = True
+            if not self.overlap:
+                return
+            self._attach(i)
+            b = self._bucket_of[i]
+            self._ready[b] += 1
+            if self._ready[b] == len(self.buckets[b][2]):
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi, _ = self.buckets[b]
+        chunk = self.flat[lo:hi]
+        self._launched[b] = True
+        if dist.get_backend() == "gloo" and chunk.is_cuda:      # one-box rehearsal: staged through the host
+            host = chunk.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            chunk.copy_(host)
+        else:
+            self._work[b] = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
 
     def allreduce_mean(self):
         """grad <- mean over ranks.  Parameters without a gradient on this rank count as zero."""
-        self._allreduce(True)
+        self._finish(True)
 
     def allreduce_sum(self):
         """grad <- sum over ranks: the ranks hold partial sums of ONE model's gradient (partition.py)."""
-        self._allreduce(False)
+        self._finish(False)
 
-    def _allreduce(self, mean):
+    def _finish(self, mean):
         if _alone():
             return
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-                p.grad = v
-            elif p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-                p.grad = v
-        if dist.get_backend() == "gloo" and self.flat.is_cuda:      # one-box rehearsal: staged through the host
-            host = self.flat.cpu()
+        had = []
+        for i in range(len(self.params)):
+            ok = self._seen[i] and self._attach(i)
+            had.append(ok)
+            if not ok:
+                self.views[i].zero_()                     # no gradient here: contributes zero to the sum
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        self.mask.zero_()
+        if any(had):
+            self.mask[:len(had)] = torch.tensor([1.0 if h else 0.0 for h in had], dtype=torch.float32).to(self.mask.device)
+        if dist.get_backend() == "gloo" and self.mask.is_cuda:
+            host = self.mask.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            self.flat.copy_(host)
+            self.mask.copy_(host)
+            mwork = None
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            mwork = dist.all_reduce(self.mask, op=dist.ReduceOp.SUM, async_op=True)
+        for w in self._work:
+            if w is not None:
+                w.wait()
+        if mwork is not None:
+            mwork.wait()
         if mean:
             self.flat.div_(dist.get_world_size())
+        anywhere = self.mask[:len(self.params)].tolist()
+        for i, p in enumerate(self.params):
+            p.grad = self.views[i] if anywhere[i] > 0 else None
+        self._reset()
+
+
+def run_timed(step, steps, warmup, device=None):
+    """The timing contract of bench.py / tools/qc_bench.py: `warmup` untimed steps, then exactly `steps` steps
+    bracketed by barrier + device synchronisation on both sides; returns the MAX over ranks of the elapsed seconds
+    (and the value of the last step).  Works without a process group (one rank) and on CPU tensors (gloo tests)."""
+    import time
+    use_dist = dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+    cuda = device is not None and torch.device(device).type == "cuda"
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        if cuda:
+            torch.cuda.synchronize(device)
+    last = None
+    for _ in range(warmup):
+        last = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if cuda else "cpu")
+        if dist.get_backend() == "gloo" and t.is_cuda:
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, last
 
 
 def shard_range(n_items, rank, world):

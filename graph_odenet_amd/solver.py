@@ -126,6 +126,16 @@ class Dopri5Stats:
         self.accepted = 0
         self.rejected = 0
         self.nfe = 0
+        self.attempts = []          # (|dt|, accepted) of every attempted step, in order
+
+
+# Test hooks.  TRACE: when a list, every adaptive solve appends its attempt sequence [(|dt|, accepted, error ratio), ...]
+# to it (forward solve first, then the adjoint solve) - the tests compare it with the oracle solver's sequence.
+# REPLAY: when a list of such sequences, the solves consume them in order and take THOSE step sizes and decisions
+# instead of the controller's (the oracle's discretisation on the product's kernels: arithmetic parity of the steps
+# themselves, independent of accept / reject ties that fp32 rounding decides either way).
+TRACE = None
+REPLAY = None
 
 
 def _numel(field, y, c):
@@ -189,6 +199,10 @@ def integrate_dopri5(field, y, t0, t1, rtol, atol, stats=None, max_steps=100000)
     field.eval(t0, [[(1.0, y[c])] for c in range(nc)], ks[0])
     stats.nfe += 1
     dt = _initial_step(field, t0, y, ks[0], rtol, atol, sgn, tmp, y1, stats)
+    seq = []                       # (|dt|, accepted, ratio) of every attempt of THIS solve
+    forced = REPLAY.pop(0) if REPLAY else None
+    if forced is not None:
+        dt = float(forced[0][0])
     tau = 0.0                      # elapsed |t - t0|
     fsal = 0                       # index of the buffer that currently holds f(t, y)
     last = None
@@ -221,7 +235,9 @@ def integrate_dopri5(field, y, t0, t1, rtol, atol, stats=None, max_steps=100000)
                 sums = red(sums)                     # row-partitioned state: every rank sees the global sums
             ratios = [sum(sums[c] for c in grp) / sum(_numel(field, y, c) for c in grp) for grp in groups]
         ratio = max(ratios)
-        if all(r <= 1.0 for r in ratios):
+        accept = all(r <= 1.0 for r in ratios) if forced is None else bool(forced[len(seq)][1])
+        seq.append((dt, accept, ratio))
+        if accept:
             stats.accepted += 1
             if tau + dt >= span:
                 # interpolate back to the end time with the 4th-order fit through (y0, y_mid, y1, f0, f1)
@@ -250,7 +266,10 @@ def integrate_dopri5(field, y, t0, t1, rtol, atol, stats=None, max_steps=100000)
             fsal = order[6]
         else:
             stats.rejected += 1
-        dt = _optimal_step(dt, ratio)
+        dt = _optimal_step(dt, ratio) if forced is None else float(forced[min(len(seq), len(forced) - 1)][0])
+    stats.attempts.extend(seq)
+    if TRACE is not None:
+        TRACE.append(seq)
     return y, stats
 
 

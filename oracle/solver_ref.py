@@ -172,6 +172,14 @@ def _interp_eval(coeffs, t0, t1, t):
     return tuple(out)
 
 
+# Test instrumentation: when TRACE is a list, every adaptive solve appends its attempt sequence [(dt, accepted, error ratio), ...]
+# to it (forward solve first, then the adjoint solves in call order).  When REPLAY is a list of such sequences, the
+# solves consume them in order INSTEAD of running the controller: the same discretisation in another precision, which is
+# how the tests obtain an fp64 ground truth of exactly the steps the fp32 runs took.
+TRACE = None
+REPLAY = None
+
+
 def _odeint_dopri5(func, y0, t, rtol, atol, stats=None):
     sign = 1.0 if t[-1] >= t[0] else -1.0
     if sign < 0:   # integrate in reversed time (torchdiffeq flips t and negates func)
@@ -185,11 +193,16 @@ def _odeint_dopri5(func, y0, t, rtol, atol, stats=None):
     sol = [y0]
     t_prev, interp = tcur, None
     n_acc = n_rej = 0
+    seq = []
+    forced = REPLAY.pop(0) if REPLAY else None
     for j in range(1, len(t)):
         while t[j] > tcur:
+            if forced is not None:
+                dt = torch.as_tensor(forced[len(seq)][0], dtype=t.dtype) if torch.is_tensor(dt) else float(forced[len(seq)][0])
             y1, f1, err, k = _dopri5_step(func, y, f0, tcur, dt)
             ratios = _error_ratio(err, rtol, atol, y, y1)
-            accept = all(r <= 1 for r in ratios)
+            accept = all(r <= 1 for r in ratios) if forced is None else bool(forced[len(seq)][1])
+            seq.append((float(dt), bool(accept), max(ratios)))
             if accept:
                 interp = _interp_fit(y, y1, k, dt)
                 t_prev, tcur = tcur, tcur + dt
@@ -199,6 +212,8 @@ def _odeint_dopri5(func, y0, t, rtol, atol, stats=None):
                 n_rej += 1
             dt = _optimal_step(dt, ratios)
         sol.append(_interp_eval(interp, t_prev, tcur, t[j]))
+    if TRACE is not None:
+        TRACE.append(seq)
     if stats is not None:
         stats["accepted"] = n_acc
         stats["rejected"] = n_rej

@@ -229,64 +229,142 @@ def test_odegcn3_rk4_forward_backward_vs_oracle_on_cora(golden, nhid):
         noise_floor_check(p.grad, ref_g[k], g64[k], "grad " + k, slack=4.0 if nhid == 128 else 20.0)
 
 
+MARGIN = 0.15      # error ratios this close to 1 are ties: the ratio itself is only reproducible to several per cent
+                   # deep in the adjoint solve (relu masks of pre-activations next to zero flip with fp32 rounding)
+
+
+def _same_steps(got, ref, what, dt_tol=(2e-3, 2e-2)):
+    """How far product and oracle controllers walk together: per solve, the number of leading attempts with the same
+    accept / reject decision and the same step size (forward solve: to 2e-3, the rounding of the fp32 error norms;
+    adjoint solve: to 2e-2).  The walk ends where the step sizes have drifted apart or a decision differs; a differing
+    decision is only tolerated at a tie (both error ratios within MARGIN of 1) - anywhere else it is a controller
+    bug.  From that point on the two runs integrate different grids and only the replayed comparison applies."""
+    assert len(got) == len(ref), "%s: %d solves vs %d" % (what, len(got), len(ref))
+    compared = []
+    for k, (a, b) in enumerate(zip(got, ref)):
+        n = 0
+        for (da, acc_a, ra), (db, acc_b, rb) in zip(a, b):
+            if abs(da - db) > dt_tol[min(k, 1)] * abs(db):
+                break
+            if acc_a != acc_b:
+                # forward solve: only a tie may be decided differently.  The adjoint solve's error estimate is not
+                # reproducible beyond its first ~20 attempts (measured: ratios 1.62 vs 0.76 at attempt 25 with the step
+                # sizes still within 2 %) - the walk just ends there.
+                assert k > 0 or (abs(rb - 1.0) <= MARGIN and abs(ra - 1.0) <= MARGIN), \
+                    "%s solve %d attempt %d: decisions differ at error ratios %.4f / %.4f" % (what, k, n, ra, rb)
+                break
+            n += 1
+        compared.append(n)
+    return compared
+
+
+def _dopri5_three_ways(sd, feats, adj, labels, idx, run_product):
+    """(1) the fp32 oracle, its step sequences recorded; (2) the fp64 oracle REPLAYING those steps (the ground truth of
+    the same discretisation); (3) the product twice: free-running (its own controller, sequences recorded) and
+    replaying the oracle's steps on its own kernels."""
+    from graph_odenet_amd import solver as PS
+    from oracle import solver_ref as S
+    S.TRACE = []
+    try:
+        ref_out, ref_g, _ = oracle_odegcn3(sd, feats, adj, None, None, 1e-5, labels, idx)
+        ref_seq = S.TRACE
+    finally:
+        S.TRACE = None
+    S.REPLAY = [list(q) for q in ref_seq]
+    try:
+        out64, g64, _ = oracle_odegcn3(sd, feats, adj, None, None, 1e-5, labels, idx, dtype=torch.float64)
+        assert S.REPLAY == []
+    finally:
+        S.REPLAY = None
+    PS.TRACE = []
+    try:
+        free = run_product()
+        got_seq = PS.TRACE
+    finally:
+        PS.TRACE = None
+    PS.REPLAY = [list(q) for q in ref_seq]
+    try:
+        replayed = run_product()
+        assert PS.REPLAY == []
+    finally:
+        PS.REPLAY = None
+    return (ref_out, ref_g, ref_seq), (out64, g64), (free, got_seq), replayed
+
+
 def test_odegcn3_dopri5_vs_oracle_on_cora(golden):
-    """Reference default (no method=, rtol=atol=1e-5).  Two correct dopri5 runs agree to O(tol);
-    solver parity vs torchdiffeq is unpinned (oracle/solver_ref.py)."""
+    """C1 with the reference's DEFAULT solver (no method=: dopri5, rtol = atol = 1e-5; GCN/models.py:192).  The
+    product's controller takes exactly the oracle's decisions (same accept / reject sequence, same step sizes, forward
+    and adjoint solve, up to the first accept / reject TIE - _same_steps); logits to 1e-4; and with the oracle's step
+    sequence replayed on the product's kernels, logits to 1e-5 and every gradient as close to the fp64 ground truth of
+    that step sequence as the fp32 oracle is (noise_floor_check).  Solver parity vs torchdiffeq itself is unpinned
+    (oracle/solver_ref.py)."""
     from graph_odenet_amd import models
     adj, feats, labels, idx = cora(golden)
     torch.manual_seed(7)
     m = models.ODEGCN3(nfeat=feats.shape[1], nhid=128, nclass=7, dropout=0.0)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
-    ref_out, ref_g, ref_nfe = oracle_odegcn3(sd, feats, adj, None, None, 1e-5, labels, idx)
     m = m.to(dev())
-    m.nfe = 0
-    out = m(feats.to(dev()), adj.to(dev()))
-    nfe_f = m.nfe
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        m.nfe = 0
+        out = m(feats.to(dev()), adj.to(dev()))
+        nfe_f = m.nfe
+        m.nfe = 0
+        torch.nn.functional.nll_loss(out[idx.to(dev())], labels.to(dev())[idx.to(dev())]).backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, (nfe_f, m.nfe)
+    (ref_out, ref_g, ref_seq), (out64, g64), ((out, grads, nfe), got_seq), (out_r, grads_r, _) = \
+        _dopri5_three_ways(sd, feats, adj, labels, idx, run)
+    compared = _same_steps(got_seq, ref_seq, "cora dopri5")
+    assert compared[0] == len(ref_seq[0]) and compared[1] >= 8          # whole forward solve; adjoint up to a tie
     close(out, ref_out, 1e-4, "dopri5 logits")
-    m.nfe = 0
-    torch.nn.functional.nll_loss(out[idx.to(dev())], labels.to(dev())[idx.to(dev())]).backward()
-    # This ODE is non-smooth (relu kinks, GroupNorm): in fp64 on the CPU, rk4 at h=1/64 and h=1/256
-    # still differ by 2e-2 in the logits and dopri5(1e-5) sits 4e-2 from either, so any two adaptive
-    # runs whose accept/reject sequences part ways differ at that level.  Product and oracle share the
-    # controller (logits agree to 1e-4 above); the adjoint pass is compared at 5e-2 of the magnitude.
-    for k, p in m.named_parameters():
-        close(p.grad, ref_g[k], 5e-2, "grad " + k)
-    assert 8 <= nfe_f <= 400 and m.nfe >= 8
+    # the oracle's steps on the product's kernels: arithmetic parity of the adaptive solve and its adjoint
+    close(out_r, ref_out, 1e-5, "dopri5 logits, replayed steps")
+    for k in grads_r:
+        noise_floor_check(grads_r[k], ref_g[k], g64[k], "grad (replayed steps) " + k)
+    assert 8 <= nfe[0] <= 400 and nfe[1] >= 8
 
 
 def test_pubmed_dense_paper_dopri5_vs_oracle(golden):
     """C2: Pubmed's real topology, symmetric normalisation, adjacency passed DENSE as GCN-dense-paper does
     (utils.py:87), ODEBlock with the reference's default dopri5 (rtol=atol=1e-5), d=16 (--hidden default).
     Features are synthetic (the reference checkout lacks ind.pubmed.allx): row-normalised sparse Bernoulli,
-    density 10 %, F=500, seed 0."""
+    density 10 %, F=500, seed 0.  Forward AND adjoint: same controller decisions as the oracle, logits 1e-4,
+    gradients at the noise floor of the fp32 computation (fp64 replay of the same steps as ground truth)."""
     from graph_odenet_amd import models
-    from oracle import layers_ref as R, solver_ref as S
     g = golden("pubmed_graph_sym.npz")
     n = int(g["n"])
     assert n == 19717 and g["rows"].shape[0] == 108365
-    idx = torch.stack([T(g["rows"].astype(np.int64)), T(g["cols"].astype(np.int64))])
-    adj_sp = torch.sparse_coo_tensor(idx, T(g["vals"]), (n, n))
+    ii = torch.stack([T(g["rows"].astype(np.int64)), T(g["cols"].astype(np.int64))])
+    adj_sp = torch.sparse_coo_tensor(ii, T(g["vals"]), (n, n))
     gen = torch.Generator().manual_seed(0)
     x = (torch.rand(n, 500, generator=gen) < 0.1).float()
     x = x / x.sum(1, keepdim=True).clamp_min(1)
+    labels = torch.randint(0, 3, (n,), generator=gen)
+    idx = torch.randperm(n, generator=gen)[:60]                 # Planetoid's 20 labelled nodes per class
     torch.manual_seed(1)
     m = models.ODEGCN3(nfeat=500, nhid=16, nclass=3, dropout=0.0)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
-
-    class F(torch.nn.Module):
-        def forward(self, t, h):
-            return R.odefunc(t, h, adj_sp, sd["gc2.odefunc.norm1.weight"], sd["gc2.odefunc.norm1.bias"],
-                             sd["gc2.odefunc.gc1.weight"], sd["gc2.odefunc.gc1.bias"])
-    with torch.no_grad():
-        h = torch.relu(R.graph_convolution(x, adj_sp, sd["gc1.weight"], sd["gc1.bias"]))
-        h = S.odeint(F(), h, torch.tensor([0., 1.]), 1e-5, 1e-5)[1]
-        ref = torch.log_softmax(R.graph_convolution(h, adj_sp, sd["gc3.weight"], sd["gc3.bias"]), 1)
-    m = m.to(dev()).eval()
+    m = m.to(dev())
     adj_dense = adj_sp.to(dev()).to_dense()          # 19717^2 fp32 = 1.55 GB, as the reference holds it
-    with torch.no_grad():
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        m.nfe = 0
         out = m(x.to(dev()), adj_dense)
-    assert m.nfe >= 8
-    close(out, ref, 1e-4, "pubmed dopri5 logits")
+        nfe_f = m.nfe
+        m.nfe = 0
+        torch.nn.functional.nll_loss(out[idx.to(dev())], labels.to(dev())[idx.to(dev())]).backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, (nfe_f, m.nfe)
+    (ref_out, ref_g, ref_seq), (out64, g64), ((out, grads, nfe), got_seq), (out_r, grads_r, _) = \
+        _dopri5_three_ways(sd, x, adj_sp, labels, idx, run)
+    compared = _same_steps(got_seq, ref_seq, "pubmed dopri5")
+    assert compared[0] == len(ref_seq[0]) and compared[1] >= 4
+    close(out, ref_out, 1e-4, "pubmed dopri5 logits")
+    close(out_r, ref_out, 1e-5, "pubmed dopri5 logits, replayed steps")
+    for k in grads_r:
+        noise_floor_check(grads_r[k], ref_g[k], g64[k], "grad (replayed steps) " + k, slack=8.0)
+    assert nfe[0] >= 8 and nfe[1] >= 8
 
 
 def test_generic_module_through_solver():
@@ -441,9 +519,10 @@ def test_hip_graph_captured_solves_match_eager(native, d):
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])
 def test_renumbered_ode_block_is_bit_identical(method):
     """Large graphs are integrated on a renumbering of their nodes when that is measured faster (gcn_ode.tuned_graph:
-    hubs first; the solver permutes the state rows on entry and exit).  Forced here on a small power-law graph: outputs,
-    the input gradient and every parameter gradient equal the unrenumbered run bit for bit, and the SpMM on the
-    renumbered graph is the row permutation of the SpMM on the given one."""
+    hubs first; the solver permutes the state rows on entry and exit).  Forced here on a small power-law graph: outputs
+    and the input gradient equal the unrenumbered run bit for bit (the SpMM on the renumbered graph is the row
+    permutation of the SpMM on the given one, also bit for bit); parameter gradients are sums over the nodes in row
+    order and agree to rounding."""
     from graph_odenet_amd import gcn_ode, graph as G, models, ops
     n, d = 3000, 64
     rs = np.random.RandomState(9)
@@ -481,8 +560,9 @@ def test_renumbered_ode_block_is_bit_identical(method):
             g.__dict__.pop("_tuned", None)
     assert res[True][3] == res[False][3]
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    # parameter gradients are sums over the nodes, taken in row order: the same numbers added in another order
     for a, b in zip(res[True][2], res[False][2]):
-        assert torch.equal(a, b)
+        close(a, b, 2e-5, "parameter gradient")
 
 
 @pytest.mark.parametrize("name,nl", [("GCNK", 2), ("GCNK", 4), ("GCNKnorm", 2), ("GCNKnorm", 5), ("RESK1", 3), ("RESK1", 5),
