@@ -149,6 +149,10 @@ SIGNATURES = {
                                                ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_p,
                                                c_p, ctypes.POINTER(GatWorkspace), ctypes.c_double, ctypes.c_double, c_f,
                                                c_f, c_p, c_p, c_p]),
+    "gode_gru_wgrad_parts": (c_i64, [c_i64]),
+    "gode_gru_cell_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "gode_gru_cell_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                    c_p]),
     "gode_prof_create": (c_p, [c_i]),
     "gode_prof_destroy": (None, [c_p]),
     "gode_prof_enable": (None, [c_p]),

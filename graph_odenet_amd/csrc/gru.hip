@@ -1,0 +1,247 @@
+// gru.hip — the node update of the QC message-passing layer as fused kernels (gfx950).
+//
+// Replaces `x = self.update_net(torch.cat([x, node_msg], 1), x)` with update_net = nn.GRUCell(2h, h) at
+// QC/mpnn.py:12,30 of the reference (the GRU half), and its autograd:
+//
+//   gi = [x | m] W_ih^T + b_ih      gh = x W_hh^T + b_hh                (W_ih: 3h x 2h, W_hh: 3h x h; gates r, z, n)
+//   r = sigmoid(gi_r + gh_r)   z = sigmoid(gi_z + gh_z)   n = tanh(gi_n + r * gh_n)   out = (1 - z) n + z x
+//
+// One launch forward (no concatenated input, no N x 3h gate matrices in memory besides the 4h values per row the
+// backward pass needs), three launches backward (gate derivatives + input gradients; weight / bias gradient partials
+// over row chunks; their fixed-order reduction).  The shapes are small and irregular (QM9 batch: N ~ 360 rows, h = 73,
+// 48 K weights): plain fp32 FMA out of LDS-staged rows, weights streamed from L2 - launch-bound work, where the
+// library path costs ~4 launches forward and ~10 backward, each re-tuned for every new N.
+// Bound: launch latency (35 MFLOP per product at N = 360).
+#include "common.h"
+
+namespace {
+
+constexpr int RB = 8;            // rows per block
+constexpr int WCHUNK = 256;      // rows per weight-gradient partial
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// forward: block = RB rows.  LDS: xm[RB][2h] | gi[RB][3h] | gh[RB][3h]
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                      const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                                      const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                      int n, int h, float* __restrict__ out, float* __restrict__ gates)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int h2 = 2 * h, h3 = 3 * h;
+    float* xm = smem;
+    float* gi = xm + RB * h2;
+    float* gh = gi + RB * h3;
+    const int row0 = blockIdx.x * RB;
+    for (int idx = threadIdx.x; idx < RB * h2; idx += 256) {
+        const int rr = idx / h2, k = idx % h2, row = row0 + rr;
+        float v = 0.f;
+        if (row < n) v = k < h ? x[(int64_t)row * h + k] : m[(int64_t)row * h + (k - h)];
+        xm[idx] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < h3; j += 256) {       // gate column j of every row of the block: weights read once
+        float ai[RB], ah[RB];
+        const float bi = b_ih ? b_ih[j] : 0.f, bh = b_hh ? b_hh[j] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) { ai[rr] = bi; ah[rr] = bh; }
+        const float* wi = w_ih + (int64_t)j * h2;
+        const float* wh = w_hh + (int64_t)j * h;
+        for (int k = 0; k < h2; ++k) {
+            const float w = wi[k];
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) ai[rr] = fmaf(w, xm[rr * h2 + k], ai[rr]);
+        }
+        for (int k = 0; k < h; ++k) {
+            const float w = wh[k];
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) ah[rr] = fmaf(w, xm[rr * h2 + k], ah[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) { gi[rr * h3 + j] = ai[rr]; gh[rr * h3 + j] = ah[rr]; }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < RB * h; idx += 256) {
+        const int rr = idx / h, c = idx % h, row = row0 + rr;
+        if (row >= n) continue;
+        const float r = sigmoidf_(gi[rr * h3 + c] + gh[rr * h3 + c]);
+        const float z = sigmoidf_(gi[rr * h3 + h + c] + gh[rr * h3 + h + c]);
+        const float hn = gh[rr * h3 + 2 * h + c];
+        const float nn = tanhf(gi[rr * h3 + 2 * h + c] + r * hn);
+        const float xv = xm[rr * h2 + c];
+        out[(int64_t)row * h + c] = (1.0f - z) * nn + z * xv;
+        if (gates) {
+            float* g = gates + (int64_t)row * 4 * h;
+            g[c] = r; g[h + c] = z; g[2 * h + c] = nn; g[3 * h + c] = hn;
+        }
+    }
+}
+
+// backward 1: gate derivatives (written out for the weight gradients) and the input gradients.
+// LDS: dgi[RB][3h] | dgh[RB][3h]
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w_ih,
+                                                      const float* __restrict__ w_hh, const float* __restrict__ gates,
+                                                      const float* __restrict__ dout, int n, int h,
+                                                      float* __restrict__ dx, float* __restrict__ dm,
+                                                      float* __restrict__ dgi_out, float* __restrict__ dgh_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int h2 = 2 * h, h3 = 3 * h;
+    float* dgi = smem;
+    float* dgh = dgi + RB * h3;
+    float* dxd = dgh + RB * h3;          // [RB][h]: dout * z (the direct path to x)
+    const int row0 = blockIdx.x * RB;
+    for (int idx = threadIdx.x; idx < RB * h; idx += 256) {
+        const int rr = idx / h, c = idx % h, row = row0 + rr;
+        float gr = 0.f, gz = 0.f, gn = 0.f, ghn = 0.f, d0 = 0.f;
+        if (row < n) {
+            const float* g = gates + (int64_t)row * 4 * h;
+            const float r = g[c], z = g[h + c], nn = g[2 * h + c], hn = g[3 * h + c];
+            const float dy = dout[(int64_t)row * h + c];
+            const float xv = x[(int64_t)row * h + c];
+            const float dn = dy * (1.0f - z);
+            const float dz = dy * (xv - nn);
+            gn = dn * (1.0f - nn * nn);
+            ghn = gn * r;
+            gr = gn * hn * r * (1.0f - r);
+            gz = dz * z * (1.0f - z);
+            d0 = dy * z;
+            float* oi = dgi_out + (int64_t)row * h3;
+            float* oh = dgh_out + (int64_t)row * h3;
+            oi[c] = gr; oi[h + c] = gz; oi[2 * h + c] = gn;
+            oh[c] = gr; oh[h + c] = gz; oh[2 * h + c] = ghn;
+        }
+        dgi[rr * h3 + c] = gr; dgi[rr * h3 + h + c] = gz; dgi[rr * h3 + 2 * h + c] = gn;
+        dgh[rr * h3 + c] = gr; dgh[rr * h3 + h + c] = gz; dgh[rr * h3 + 2 * h + c] = ghn;
+        dxd[rr * h + c] = d0;
+    }
+    __syncthreads();
+    // d[x | m][row][k] = sum_j dgi[row][j] W_ih[j][k]  (+ for k < h: sum_j dgh[row][j] W_hh[j][k] + dout*z)
+    for (int k = threadIdx.x; k < h2; k += 256) {       // adjacent threads read adjacent weights of a row
+        float a[RB];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) a[rr] = k < h ? dxd[rr * h + k] : 0.f;
+        for (int j = 0; j < h3; ++j) {
+            const float w = w_ih[(int64_t)j * h2 + k];
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgi[rr * h3 + j], w, a[rr]);
+        }
+        if (k < h) {
+            for (int j = 0; j < h3; ++j) {
+                const float w = w_hh[(int64_t)j * h + k];
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgh[rr * h3 + j], w, a[rr]);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int row = row0 + rr;
+            if (row >= n) continue;
+            if (k < h) { if (dx) dx[(int64_t)row * h + k] = a[rr]; }
+            else if (dm) dm[(int64_t)row * h + (k - h)] = a[rr];
+        }
+    }
+}
+
+// backward 2: partial weight / bias gradients over a chunk of rows.  grid = (3h gate rows, chunks); a partial is
+// [3h][3h + 2]: columns 0..2h-1 = dW_ih row, 2h..3h-1 = dW_hh row, 3h = db_ih, 3h+1 = db_hh.
+__global__ __launch_bounds__(256) void gru_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                        const float* __restrict__ dgi, const float* __restrict__ dgh,
+                                                        int n, int h, float* __restrict__ part)
+{
+    const int h2 = 2 * h, h3 = 3 * h, ld = h3 + 2;
+    const int j = blockIdx.x;
+    const int r0 = blockIdx.y * WCHUNK;
+    const int r1 = min(n, r0 + WCHUNK);
+    float* out = part + ((int64_t)blockIdx.y * h3 + j) * ld;
+    for (int k = threadIdx.x; k < ld; k += 256) {
+        float acc = 0.f;
+        if (k < h) {
+            for (int row = r0; row < r1; ++row) acc = fmaf(dgi[(int64_t)row * h3 + j], x[(int64_t)row * h + k], acc);
+        } else if (k < h2) {
+            for (int row = r0; row < r1; ++row) acc = fmaf(dgi[(int64_t)row * h3 + j], m[(int64_t)row * h + (k - h)], acc);
+        } else if (k < h3) {
+            for (int row = r0; row < r1; ++row) acc = fmaf(dgh[(int64_t)row * h3 + j], x[(int64_t)row * h + (k - h2)], acc);
+        } else if (k == h3) {
+            for (int row = r0; row < r1; ++row) acc += dgi[(int64_t)row * h3 + j];
+        } else {
+            for (int row = r0; row < r1; ++row) acc += dgh[(int64_t)row * h3 + j];
+        }
+        out[k] = acc;
+    }
+}
+
+// backward 3: partials added in chunk order and scattered into the four gradients
+__global__ __launch_bounds__(256) void gru_wreduce_kernel(const float* __restrict__ part, int n_part, int h,
+                                                          float* __restrict__ dw_ih, float* __restrict__ dw_hh,
+                                                          float* __restrict__ db_ih, float* __restrict__ db_hh)
+{
+    const int h2 = 2 * h, h3 = 3 * h, ld = h3 + 2;
+    const int64_t total = (int64_t)h3 * ld;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int p = 0; p < n_part; ++p) s += part[(int64_t)p * total + idx];
+        const int j = (int)(idx / ld), k = (int)(idx % ld);
+        if (k < h2) dw_ih[(int64_t)j * h2 + k] = s;
+        else if (k < h3) dw_hh[(int64_t)j * h + (k - h2)] = s;
+        else if (k == h3) { if (db_ih) db_ih[j] = s; }
+        else if (db_hh) db_hh[j] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t gode_gru_wgrad_parts(int64_t n) { return n <= 0 ? 1 : (n + WCHUNK - 1) / WCHUNK; }
+
+extern "C" int gode_gru_cell_f32_fwd(const float* x, const float* m, const float* w_ih, const float* w_hh,
+                                     const float* b_ih, const float* b_hh, int64_t n, int64_t h, float* out,
+                                     float* gates, void* stream)
+{
+    if (n < 0 || h <= 0) return GODE_E_SHAPE;
+    if (n == 0) return 0;
+    if (!x || !m || !w_ih || !w_hh || !out) return GODE_E_NULLPTR;
+    if (n > INT32_MAX || h > 1024) return GODE_E_RANGE;
+    const size_t lds = (size_t)RB * 8 * h * sizeof(float);
+    if (lds > 160 * 1024) return GODE_E_UNSUPPORTED;
+    int rc = gode_set_lds_once((const void*)gru_fwd_kernel, lds); if (rc) return rc;
+    const int64_t blocks = (n + RB - 1) / RB;
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
+                       x, m, w_ih, w_hh, b_ih, b_hh, (int)n, (int)h, out, gates);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_gru_cell_f32_bwd(const float* x, const float* m, const float* w_ih, const float* w_hh,
+                                     const float* gates, const float* dout, int64_t n, int64_t h,
+                                     float* dx, float* dm, float* dgi, float* dgh, float* part,
+                                     float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* stream)
+{
+    if (n < 0 || h <= 0) return GODE_E_SHAPE;
+    if (!w_ih || !w_hh || !dw_ih || !dw_hh) return GODE_E_NULLPTR;
+    if (n > INT32_MAX || h > 1024) return GODE_E_RANGE;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t h3 = 3 * h;
+    if (n == 0) {
+        int rc = gode_zero_f32(dw_ih, h3 * 2 * h, stream); if (rc) return rc;
+        rc = gode_zero_f32(dw_hh, h3 * h, stream); if (rc) return rc;
+        if (db_ih) { rc = gode_zero_f32(db_ih, h3, stream); if (rc) return rc; }
+        if (db_hh) { rc = gode_zero_f32(db_hh, h3, stream); if (rc) return rc; }
+        return 0;
+    }
+    if (!x || !m || !gates || !dout || !dgi || !dgh || !part) return GODE_E_NULLPTR;
+    const size_t lds = (size_t)RB * 7 * h * sizeof(float);
+    if (lds > 160 * 1024) return GODE_E_UNSUPPORTED;
+    int rc = gode_set_lds_once((const void*)gru_bwd_kernel, lds); if (rc) return rc;
+    const int64_t blocks = (n + RB - 1) / RB;
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, x, w_ih, w_hh, gates, dout, (int)n, (int)h,
+                       dx, dm, dgi, dgh);
+    GODE_LAUNCH_CHECK();
+    const int64_t parts = gode_gru_wgrad_parts(n);
+    if (parts > 65535) return GODE_E_RANGE;
+    hipLaunchKernelGGL(gru_wgrad_kernel, dim3((unsigned)h3, (unsigned)parts), dim3(256), 0, s, x, m, dgi, dgh, (int)n, (int)h, part);
+    GODE_LAUNCH_CHECK();
+    int64_t rb = (h3 * (h3 + 2) + 255) / 256; if (rb > 1024) rb = 1024;
+    hipLaunchKernelGGL(gru_wreduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, part, (int)parts, (int)h, dw_ih, dw_hh, db_ih, db_hh);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}

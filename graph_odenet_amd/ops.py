@@ -453,6 +453,41 @@ def edge_matvec_bwd(edge_row, edge_val, src, A, X, dM, want_dA=True, want_dx=Tru
     return dA, dxe
 
 
+# ---- QC node update: fused GRU cell ---------------------------------------------------------------
+def gru_cell_fwd(x, m, w_ih, w_hh, b_ih, b_hh, want_gates=True):
+    """out = GRUCell([x | m], x) with torch.nn.GRUCell's parameter layout; returns (out, gates[n, 4h] or None)."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (m, "m"), (w_ih, "weight_ih"), (w_hh, "weight_hh"), (b_ih, "bias_ih"), (b_hh, "bias_hh")):
+        _need(t, nm)
+    n, h = x.shape
+    if m.shape != x.shape or tuple(w_ih.shape) != (3 * h, 2 * h) or tuple(w_hh.shape) != (3 * h, h):
+        raise ValueError("gru_cell: x, m must be n x h, weight_ih 3h x 2h, weight_hh 3h x h (got %s %s %s %s)"
+                         % (tuple(x.shape), tuple(m.shape), tuple(w_ih.shape), tuple(w_hh.shape)))
+    out = torch.empty_like(x)
+    gates = torch.empty(n, 4 * h, dtype=torch.float32, device=x.device) if want_gates else None
+    check(lib.gode_gru_cell_f32_fwd(ptr(x), ptr(m), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), n, h, ptr(out), ptr(gates),
+                                    stream_ptr()), "gode_gru_cell_f32_fwd")
+    return out, gates
+
+
+def gru_cell_bwd(x, m, w_ih, w_hh, gates, dout, has_bias=True):
+    """Returns (dx, dm, dw_ih, dw_hh, db_ih, db_hh)."""
+    lib = _lib.load()
+    _need(dout, "dout"); _need(gates, "gates")
+    n, h = x.shape
+    f = dict(dtype=torch.float32, device=x.device)
+    dx, dm = torch.empty_like(x), torch.empty_like(x)
+    dgi, dgh = torch.empty(n, 3 * h, **f), torch.empty(n, 3 * h, **f)
+    part = torch.empty(lib.gode_gru_wgrad_parts(n) * 3 * h * (3 * h + 2), **f)
+    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+    db_ih = torch.empty(3 * h, **f) if has_bias else None
+    db_hh = torch.empty(3 * h, **f) if has_bias else None
+    check(lib.gode_gru_cell_f32_bwd(ptr(x), ptr(m), ptr(w_ih), ptr(w_hh), ptr(gates), ptr(dout), n, h, ptr(dx), ptr(dm),
+                                    ptr(dgi), ptr(dgh), ptr(part), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh),
+                                    stream_ptr()), "gode_gru_cell_f32_bwd")
+    return dx, dm, dw_ih, dw_hh, db_ih, db_hh
+
+
 # ---- Set2Set attention readout ---------------------------------------------------------------------
 def segment_attention_fwd(segptr, perm, x, q):
     """a = per-graph softmax(<x_i, q_b>), r_b = sum_i a_i x_i; returns (a[N], r[B, h])."""

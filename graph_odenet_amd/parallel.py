@@ -126,17 +126,21 @@ class GradBucket:
         else:
             self._work[b] = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
 
-    def allreduce_mean(self):
-        """grad <- mean over ranks.  Parameters without a gradient on this rank count as zero."""
-        self._finish(True)
+    def allreduce_mean(self, assume_all=False):
+        """grad <- mean over ranks.  Parameters without a gradient on this rank count as zero.  assume_all: every
+        parameter that HAS a `.grad` received it in this step although no hook fired (gradients written by a HIP-graph
+        replay, qc_step.py)."""
+        self._finish(True, assume_all)
 
-    def allreduce_sum(self):
+    def allreduce_sum(self, assume_all=False):
         """grad <- sum over ranks: the ranks hold partial sums of ONE model's gradient (partition.py)."""
-        self._finish(False)
+        self._finish(False, assume_all)
 
-    def _finish(self, mean):
+    def _finish(self, mean, assume_all=False):
         if _alone():
             return
+        if assume_all:
+            self._seen = [p.grad is not None for p in self.params]
         had = []
         for i in range(len(self.params)):
             ok = self._seen[i] and self._attach(i)

@@ -7,8 +7,8 @@
 
 `Etgt` is the reference's DENSE N x E incidence (QC/datasets/utils.py:214); it is converted once per
 tensor object to CSR (values kept).  The message step M = Etgt @ bmm(edge_data, x[Esrc]) runs in
-csrc/edge.hip without materialising the E x h edge messages; the GRU update stays a dense PyTorch
-cell (out of the hot-path scope).
+csrc/edge.hip without materialising the E x h edge messages; the GRU update of QC/mpnn.py:30 is the fused cell of
+csrc/gru.hip on the nn.GRUCell's own parameters (the GRU half).
 """
 import math
 
@@ -37,7 +37,9 @@ class _EdgeSet:
                 raise ValueError("Etgt must be N x E with E = len(Esrc)")
             nz = Etgt != 0
             per_col = nz.sum(0)
-            if self.E and int(per_col.max().item()) > 1:
+            # the validity check is this conversion's one host synchronisation; inside a HIP-graph capture (qc_step.py:
+            # batches built by qc_batch.pad_batch, valid by construction) nothing may synchronise and it is skipped
+            if self.E and not torch.cuda.is_current_stream_capturing() and int(per_col.max().item()) > 1:
                 raise NotImplementedError("Etgt with more than one entry per edge column is not supported")
             tgt = nz.to(torch.uint8).argmax(0)                                   # the entry's row (0 for an empty column)
             val = Etgt.gather(0, tgt.unsqueeze(0)).squeeze(0).to(torch.float32)    # its value (0 for an empty column)
@@ -98,6 +100,34 @@ def edge_message(x, Esrc, Etgt, edge_data):
     return _EdgeMessageFn.apply(_edges(Esrc, Etgt), x, edge_data)
 
 
+class _GruUpdateFn(torch.autograd.Function):
+    """x' = GRUCell([x | m], x) on the parameters of an nn.GRUCell(2h, h) (QC/mpnn.py:12,30): one launch forward, three
+    backward (csrc/gru.hip) - no concatenated input, no library GEMM whose shape changes with every batch."""
+
+    @staticmethod
+    def forward(ctx, x, m, w_ih, w_hh, b_ih, b_hh):
+        x, m = x.contiguous(), m.contiguous()
+        out, gates = ops.gru_cell_fwd(x, m, w_ih.contiguous(), w_hh.contiguous(), b_ih, b_hh)
+        ctx.has_bias = b_ih is not None
+        ctx.save_for_backward(x, m, w_ih, w_hh, gates)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, m, w_ih, w_hh, gates = ctx.saved_tensors
+        dx, dm, dw_ih, dw_hh, db_ih, db_hh = ops.gru_cell_bwd(x, m, w_ih.contiguous(), w_hh.contiguous(), gates,
+                                                              dout.contiguous(), ctx.has_bias)
+        return dx, dm, dw_ih, dw_hh, db_ih, db_hh
+
+
+def gru_update(cell, x, m):
+    """cell(torch.cat([x, m], 1), x) for cell = nn.GRUCell(2h, h), fused."""
+    if cell.input_size != 2 * cell.hidden_size or x.shape[1] != cell.hidden_size:
+        raise ValueError("gru_update: the update cell must be GRUCell(2h, h) on n x h states")
+    return _GruUpdateFn.apply(x, m, cell.weight_ih, cell.weight_hh, getattr(cell, "bias_ih", None),
+                              getattr(cell, "bias_hh", None))
+
+
 class MPNN_enn_edge(nn.Module):
     """QC/mpnn.py:5-32."""
 
@@ -114,7 +144,7 @@ class MPNN_enn_edge(nn.Module):
     def forward(self, x, Esrc, Etgt, edge_data):
         for t in range(self.T):
             node_msg = edge_message(x, Esrc, Etgt, edge_data)
-            x = self.update_net(torch.cat([x, node_msg], 1), x)
+            x = gru_update(self.update_net, x, node_msg)
         return x
 
 

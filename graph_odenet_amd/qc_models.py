@@ -90,7 +90,12 @@ class _Segments:
     def __init__(self, batch):
         b64 = batch.to(torch.int64)
         n = b64.numel()
-        if n:
+        known = getattr(batch, "_gode_n_graphs", None)
+        if known is not None:
+            # static batch of a captured step (qc_step.py): the number of graphs is a property of the bucket and the
+            # batch vector is sorted (collate order) - no host synchronisation, so the conversion can be captured
+            self.nb, uns = int(known), 0
+        elif n:
             # one host synchronisation for both facts the layout depends on: number of graphs, sortedness
             unsorted = (b64[1:] < b64[:-1]).any().to(torch.int64) if n > 1 else torch.zeros((), dtype=torch.int64, device=b64.device)
             mx, uns = torch.stack([b64.max(), unsorted]).tolist()

@@ -383,6 +383,20 @@ int gode_gat_ode_dopri5_step_adjoint(const gode_gat_odefunc_t* f, const float* y
                                      const gode_gat_workspace_t* ws, double t, double h, float rtol, float atol,
                                      double* sums /* 4 */, void* err_scratch, void* stream);
 
+/* ---- QC node update: fused GRU cell (replaces nn.GRUCell(2h, h) applied to ([x | m], x), QC/mpnn.py:12,30) -----
+ * x, m: n x h (state and aggregated messages; the concatenation [x | m] is never formed).  w_ih: 3h x 2h, w_hh: 3h x h,
+ * b_ih, b_hh: 3h (nullable), gate order r, z, n as torch.nn.GRUCell.  out: n x h.  gates (nullable; n x 4h) receives
+ * r, z, n and W_hn x + b_hn per row - what the backward pass reads.
+ * bwd: dout n x h -> dx, dm (n x h, nullable), the gate derivatives dgi, dgh (n x 3h each, caller-owned, also outputs),
+ * and the parameter gradients dw_ih, dw_hh, db_ih, db_hh (bias pointers nullable); `part` is scratch of
+ * gode_gru_wgrad_parts(n) * 3h * (3h + 2) floats (row-chunk partials, added in fixed order: deterministic). */
+int64_t gode_gru_wgrad_parts(int64_t n);
+int gode_gru_cell_f32_fwd(const float* x, const float* m, const float* w_ih, const float* w_hh, const float* b_ih,
+                          const float* b_hh, int64_t n, int64_t h, float* out, float* gates, void* stream);
+int gode_gru_cell_f32_bwd(const float* x, const float* m, const float* w_ih, const float* w_hh, const float* gates,
+                          const float* dout, int64_t n, int64_t h, float* dx, float* dm, float* dgi, float* dgh,
+                          float* part, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* stream);
+
 /* ---- measurement aid (bench.py): HIP-event brackets around the dominant kernels ----------
  * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 main-kernel launch
  * and every MFMA-path launch of the dense kernels (gn_gemm_fwd / gn_gemm_bwd / wgrad) records a start/stop event pair

@@ -1,6 +1,11 @@
 import os
 import sys
 
+# graph_odenet_amd/hipgraph.py: on this ROCm replayed memset nodes only work with the HIP runtime's graph fast path
+# off.  libgraphode launches no memset (test_abi.py), but captures of PyTorch autograd (qc_step.CapturedQCStep) need it;
+# must be set before the first HIP call of the process.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -150,6 +150,143 @@ def test_qc_mpnn_and_edge_gcn_vs_reference_golden(golden):
     close(egc.weight.grad, g["egc__gw"], 2e-5, "egc gw"); close(egc.bias.grad, g["egc__gb"], 2e-5, "egc gb")
 
 
+@pytest.mark.parametrize("n,h,bias", [(360, 73, True), (37, 16, True), (1000, 200, True), (5, 8, False), (700, 73, True)])
+def test_fused_gru_update_vs_torch_cpu(n, h, bias):
+    """SURVEY 8(f) N2, GRU half: x' = update_net(cat([x, m], 1), x) of QC/mpnn.py:30 as the fused cell of csrc/gru.hip,
+    on the nn.GRUCell's own parameters, against torch's CPU GRUCell: output, input gradients, parameter gradients."""
+    from graph_odenet_amd.qc_layers import gru_update
+    torch.manual_seed(n + h)
+    cell = torch.nn.GRUCell(2 * h, h, bias=bias)
+    x = torch.randn(n, h, requires_grad=True)
+    m = torch.randn(n, h, requires_grad=True)
+    gout = torch.randn(n, h)
+    ref = cell(torch.cat([x, m], 1), x)
+    ref.backward(gout)
+    want = [x.grad.clone(), m.grad.clone()] + [p.grad.clone() for p in cell.parameters()]
+    cell_g = torch.nn.GRUCell(2 * h, h, bias=bias)
+    cell_g.load_state_dict(cell.state_dict())
+    cell_g = cell_g.to(dev())
+    xg, mg = x.detach().to(dev()).requires_grad_(True), m.detach().to(dev()).requires_grad_(True)
+    out = gru_update(cell_g, xg, mg)
+    close(out, ref, 1e-5, "GRU output")
+    out.backward(gout.to(dev()))
+    got = [xg.grad, mg.grad] + [p.grad for p in cell_g.parameters()]
+    names = ["dx", "dm"] + [k for k, _ in cell_g.named_parameters()]
+    for nm, a, b in zip(names, got, want):
+        close(a, b, 2e-5, nm)
+
+
+@pytest.mark.parametrize("name", ["EdgeGCN_K_Sum", "MPNN_ENN_K_Set2Set"])
+def test_c4_full_size_training_steps_match_reference(golden, name):
+    """BASELINE.json configs[3] / SURVEY 8(d) C4 at its real size: 20 synthetic molecules, h = 73, T = 3, the
+    reference's 14.4 M-parameter shapes; three Adam steps (MSE, lr 1e-3, QC/train_egcn.py:122) of the reference's own
+    classes (tests/golden/train_traj_qc_c4.npz, weights regenerated by name) against ours: loss sequence and outputs.
+    Batch-20 sizes run the fused < 4096-edge message kernel, the fused GRU cell and the Set2Set segment kernels."""
+    import os
+    import sys
+    import torch.nn.functional as F
+    from graph_odenet_amd import qc_models
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from named_init import fill_by_name
+    g = golden("train_traj_qc_c4.npz")
+    n = int(g["n"])
+    x, ef, tgt = T(g["x"]).to(dev()), T(g["ef"]).to(dev()), T(g["target"]).to(dev())
+    Esrc, batch = T(g["Esrc"]).long().to(dev()), T(g["batch"]).long().to(dev())
+    E = Esrc.numel()
+    assert E < 4096 and n == x.shape[0]
+    Etgt = torch.zeros(n, E)
+    Etgt[T(g["etgt"]).long(), torch.arange(E)] = 1.0
+    Etgt = Etgt.to(dev())
+    m = getattr(qc_models, name)(node_features=13, edge_features=5, target_features=12, hidden_features=73, num_layers=3,
+                                 s2s_processing_steps=12, dropout=0.0)
+    assert sum(p.numel() for p in m.parameters()) == int(g[name + "__n_params"])
+    m = fill_by_name(m).to(dev()).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = F.mse_loss(m(x, ef, Esrc, Etgt, batch), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    ref = np.asarray(g[name + "__losses"])
+    assert np.abs(np.asarray(losses) - ref).max() < 5e-5 * max(1.0, float(ref.max())), (losses, ref)
+    out = m(x, ef, Esrc, Etgt, batch).detach()
+    close(out, g[name + "__out"], 2e-4, "outputs after three steps")
+
+
+@pytest.mark.parametrize("name", ["EdgeGCN_K_Sum", "MPNN_ENN_K_Set2Set"])
+def test_shape_bucket_padding_leaves_the_batch_unchanged(name):
+    """qc_batch.pad_batch: a batch rounded up to its shape bucket (one extra graph of isolated dummy atoms and dummy
+    edges) gives the original outputs in its first n_graphs rows and the original parameter gradients."""
+    import torch.nn.functional as F
+    from graph_odenet_amd import qc_models
+    from graph_odenet_amd.qc_batch import pad_batch
+    from graph_odenet_amd.synth import qm9_like_batch
+    x, ef, Esrc, Etgt, batch = qm9_like_batch(7, seed=4, device=dev())
+    tgt = torch.randn(7, 12, generator=torch.Generator().manual_seed(1)).to(dev())
+    torch.manual_seed(2)
+    m = getattr(qc_models, name)(node_features=13, edge_features=5, target_features=12, hidden_features=24, num_layers=2,
+                                 s2s_processing_steps=3, dropout=0.0).to(dev())
+    out = m(x, ef, Esrc, Etgt, batch)
+    F.mse_loss(out, tgt).backward()
+    want = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    xp, efp, srcp, Etp, bp, nb = pad_batch(x, ef, Esrc, Etgt, batch, node_multiple=64, edge_multiple=128)
+    assert nb == 7 and xp.shape[0] % 64 == 0 and srcp.numel() % 128 == 0 and xp.shape[0] > x.shape[0]
+    outp = m(xp, efp, srcp, Etp, bp)
+    assert outp.shape[0] == 8
+    close(outp[:nb], out, 1e-5, "outputs of the real graphs")
+    F.mse_loss(outp[:nb], tgt).backward()
+    for (nm, p), w in zip(m.named_parameters(), want):
+        close(p.grad, w, 2e-5, nm)
+
+
+@pytest.mark.parametrize("name", ["EdgeGCN_K_Sum", "MPNN_ENN_K_Set2Set"])
+def test_captured_qc_step_matches_eager(name):
+    """qc_step.CapturedQCStep: the whole training step of a shape bucket (graph conversion, forward, MSE, backward, Adam)
+    captured into one HIP graph and replayed on new batches of the bucket - losses and final parameters equal the eager
+    run of the same padded batches."""
+    import torch.nn.functional as F
+    from graph_odenet_amd import qc_models
+    from graph_odenet_amd.qc_batch import pad_batch
+    from graph_odenet_amd.qc_step import CapturedQCStep
+    from graph_odenet_amd.synth import qm9_like_batch
+    batches = []
+    for b in range(40):
+        x, ef, Esrc, Etgt, batch = qm9_like_batch(6, seed=100 + b, device=dev())
+        tgt = torch.randn(6, 12, generator=torch.Generator().manual_seed(b)).to(dev())
+        batches.append(pad_batch(x, ef, Esrc, Etgt, batch, 64, 128)[:5] + (tgt,))
+    shapes = {}
+    for i, bt in enumerate(batches):
+        shapes.setdefault((bt[0].shape, bt[1].shape), []).append(i)
+    idx = max(shapes.values(), key=len)[:6]                      # six batches of the most frequent bucket
+    assert len(idx) >= 4, "need several batches of one bucket"
+    res = {}
+    for captured in (False, True):
+        torch.manual_seed(3)
+        m = getattr(qc_models, name)(node_features=13, edge_features=5, target_features=12, hidden_features=24,
+                                     num_layers=2, s2s_processing_steps=3, dropout=0.0).to(dev())
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+        losses = []
+        if captured:
+            step = CapturedQCStep(m, opt, F.mse_loss, warmup=1)
+            for i in idx:
+                losses.append(float(step(*batches[i])))
+            assert len(step.buckets) == 1 and next(iter(step.buckets.values())).graph is not None
+        else:
+            for i in idx:
+                x, ef, Esrc, Etgt, batch, tgt = batches[i]
+                opt.zero_grad(set_to_none=True)
+                loss = F.mse_loss(m(x, ef, Esrc, Etgt, batch)[:6], tgt)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        res[captured] = (losses, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone())
+    assert np.abs(np.asarray(res[True][0]) - np.asarray(res[False][0])).max() < 1e-5 * max(1.0, max(res[False][0]))
+    close(res[True][1], res[False][1], 1e-5, "parameters after the steps")
+
+
 def test_qc_colliding_indices_and_weighted_incidence():
     """Q5 of SURVEY.md: the reference's batches do not offset node ids, so many edges collide on the
     first nodes; Etgt is a dense float matrix whose values are used as weights."""

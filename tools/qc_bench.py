@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")     # graph_odenet_amd/hipgraph.py: memset nodes must work for --captured
+
 import torch
 import torch.nn.functional as F
 
@@ -26,8 +28,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build(dev, model_name, seed, n_batches, batch_size):
+def build(dev, model_name, seed, n_batches, batch_size, bucket=False):
     from graph_odenet_amd import qc_models
+    from graph_odenet_amd.qc_batch import pad_batch
     from graph_odenet_amd.synth import qm9_like_batch
     torch.manual_seed(0)
     net = getattr(qc_models, model_name)(node_features=13, edge_features=5, target_features=12,
@@ -35,6 +38,8 @@ def build(dev, model_name, seed, n_batches, batch_size):
     batches = []
     for b in range(n_batches):
         x, ef, Esrc, Etgt, batch = qm9_like_batch(batch_size, seed=seed * 1000 + b, device=dev)
+        if bucket:            # collate-time padding to the shape bucket (qc_batch.py): part of data loading, not of the step
+            x, ef, Esrc, Etgt, batch, _ = pad_batch(x, ef, Esrc, Etgt, batch)
         tgt = torch.randn(batch_size, 12, generator=torch.Generator().manual_seed(seed * 1000 + b)).to(dev)
         batches.append((x, ef, Esrc, Etgt, batch, tgt))
     return net, batches
@@ -68,6 +73,10 @@ def main():
     ap.add_argument("--batch-size", type=int, default=20)
     ap.add_argument("--model", default="MPNN_ENN_K_Set2Set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--captured", action="store_true",
+                    help="one HIP-graph replay per step and shape bucket (qc_step.CapturedQCStep; implies --bucket)")
+    ap.add_argument("--bucket", action="store_true",
+                    help="pad every batch to its shape bucket (multiples of 64 atoms / 128 edges, one dummy graph)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -83,15 +92,22 @@ def main():
     from graph_odenet_amd.parallel import GradBucket, broadcast_parameters
 
     # one distinct batch per step, as in training: the per-batch graph conversion is inside the timed region
-    net, batches = build(dev, args.model, rank, args.steps + args.warmup, args.batch_size)
+    args.bucket = args.bucket or args.captured
+    net, batches = build(dev, args.model, rank, args.steps + args.warmup, args.batch_size, args.bucket)
     broadcast_parameters(net, 0)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-    bucket = GradBucket(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=args.captured)
+    bucket = GradBucket(net, overlap=not args.captured)
+    cstep = None
+    if args.captured:
+        from graph_odenet_amd.qc_step import CapturedQCStep
+        cstep = CapturedQCStep(net, opt, F.mse_loss, exchange=(lambda: bucket.allreduce_mean(assume_all=True)) if world > 1 else None)
 
     def step(i):
         x, ef, Esrc, Etgt, batch, tgt = batches[i]
+        if cstep is not None:
+            return cstep(x, ef, Esrc, Etgt, batch, tgt)
         opt.zero_grad(set_to_none=False)
-        loss = F.mse_loss(net(x, ef, Esrc, Etgt, batch), tgt)
+        loss = F.mse_loss(net(x, ef, Esrc, Etgt, batch)[:tgt.shape[0]], tgt)
         loss.backward()
         bucket.allreduce_mean()
         opt.step()
@@ -119,10 +135,13 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * el / args.steps, 3), "scaling": "weak", "dtype": "f32",
                "data": "synthetic", "loss": round(float(loss), 5),
-               "config": {"workload": "%s h=73 T=3, %d QM9-like molecules per rank, a new batch every step (graph conversion timed)"
-                                      % (args.model, args.batch_size),
+               "config": {"workload": "%s h=73 T=3, %d QM9-like molecules per rank, a new batch every step (graph conversion timed)%s"
+                                      % (args.model, args.batch_size, ", padded to shape buckets" if args.bucket else ""),
                           "params": sum(p.numel() for p in net.parameters()),
                           "gradient_bytes_allreduced_per_step": 4 * bucket.flat.numel() if world > 1 else 0}}
+        if cstep is not None:
+            res["config"]["shape_buckets_captured"] = sum(1 for b in cstep.buckets.values() if b.graph is not None)
+            res["config"]["shape_buckets_seen"] = len(cstep.buckets)
         if world == 1 and not args.no_cpu_baseline:
             t = cpu_oracle_step(args.model, args.batch_size, 3)
             res["cpu_baseline"] = {"value": round(args.batch_size / t, 1), "unit": "graphs/s",
