@@ -62,14 +62,15 @@ class GatOdeFunc(ctypes.Structure):
                 ("n_edges", ctypes.c_int64), ("n", ctypes.c_int64), ("d", ctypes.c_int64), ("groups", ctypes.c_int32),
                 ("eps_gn", ctypes.c_float), ("eps", ctypes.c_float), ("Wsrc", ctypes.c_void_p), ("Wtgt", ctypes.c_void_p),
                 ("Wlog", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("bw", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
-                ("beta", ctypes.c_void_p)]
+                ("beta", ctypes.c_void_p), ("heads", ctypes.c_int32)]
 
 
 class GatWorkspace(ctypes.Structure):
     """Mirror of gode_gat_workspace_t."""
     _fields_ = [(k, ctypes.c_void_p) for k in ("X", "Ps", "Pt", "A2", "a", "amax", "wgt", "den", "logits_scratch", "dz", "da",
                                                "dPs", "dPt", "dA2", "pair", "gp", "bp")] + \
-               [("wp", ctypes.c_void_p * 3), ("maxpath_scratch", ctypes.c_void_p), ("colsum_scratch", ctypes.c_void_p)]
+               [("wp", ctypes.c_void_p * 3), ("maxpath_scratch", ctypes.c_void_p), ("colsum_scratch", ctypes.c_void_p),
+                ("zeros", ctypes.c_void_p), ("heads_scratch", ctypes.c_void_p)]
 
 
 c_i64 = ctypes.c_int64
@@ -142,6 +143,7 @@ SIGNATURES = {
                                                ctypes.POINTER(Rk4Workspace), ctypes.c_double, ctypes.c_double, c_f, c_f,
                                                c_p, c_p, c_p]),
     "gode_gat_ode_theta_len": (c_i64, [c_i64]),
+    "gode_gat_ode_theta_len_heads": (c_i64, [c_i64, c_i64]),
     "gode_gat_ode_dopri5_step_forward": (c_i, [ctypes.POINTER(GatOdeFunc), c_p, ctypes.POINTER(c_p), c_p,
                                                ctypes.POINTER(GatWorkspace), ctypes.c_double, ctypes.c_double, c_f, c_f,
                                                c_p, c_p, c_p]),

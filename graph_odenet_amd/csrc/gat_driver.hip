@@ -35,10 +35,26 @@ gode_lincomb_t dp_terms(const float* y, float* const* k, const double* coef, int
     return lc;
 }
 
-gode_gat_proj_t proj_of(const gode_gat_workspace_t* w, int64_t d) {
+inline int64_t n_heads(const gode_gat_odefunc_t* f) { return f->heads > 1 ? f->heads : 1; }
+
+// projections as the edge kernels see them: with H heads the n x (H*o) matrices ARE the (n*H) x o matrices of the
+// virtual nodes (row stride o), and A2 (n x 2H) is (n*H) x 2
+gode_gat_proj_t proj_of(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w) {
+    const int64_t o = f->d / n_heads(f);
     gode_gat_proj_t p;
-    p.ps = w->Ps; p.ld_s = d; p.pt = w->Pt; p.ld_t = d; p.as = w->A2; p.at = w->A2 + 1; p.ld_a = 2;
+    p.ps = w->Ps; p.ld_s = o; p.pt = w->Pt; p.ld_t = o; p.as = w->A2; p.at = w->A2 + 1; p.ld_a = 2;
     return p;
+}
+
+// Pt[row, :] += bf  (heads: the per-head message biases ride the target-side projection)
+__global__ __launch_bounds__(256) void add_row_bias_kernel(float* __restrict__ P, const float* __restrict__ b, int64_t n, int d) {
+    const int64_t total = n * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) P[i] += b[i % d];
+}
+// dst[h] = src[2h + 1]  (logit-bias gradients out of the column sums of dA2)
+__global__ void odd_entries_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[2 * i + 1];
 }
 
 // Ps, Pt, A2 of the stage input; a multi-term input is combined once (x_out) and read back as one array afterwards
@@ -48,51 +64,71 @@ int project(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lin
     GODE_TRY(gode_gn_time_gemm_pair_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, f->Wtgt, 1, t, w->Ps, w->Pt,
                                         xo, stream));
     if (xo) { yin->n = 1; yin->coef[0] = 1.f; yin->ptr[0] = xo; }
-    return gode_gn_time_gemm_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wlog, 2, 1, t, w->A2, stream);
+    const int64_t H = n_heads(f);
+    GODE_TRY(gode_gn_time_gemm_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wlog, 2 * H, 1, t, w->A2, stream));
+    if (H > 1) {
+        int64_t blocks = (n * d + 255) / 256; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(add_row_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w->Pt, f->bf, n, (int)d);
+        GODE_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 int eval_forward(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lincomb_t* yin, float t, float* ky,
                  void* stream) {
     GODE_TRY(project(f, w, yin, t, stream));
-    const gode_gat_proj_t pr = proj_of(w, f->d);
+    const gode_gat_proj_t pr = proj_of(f, w);
+    const int64_t H = n_heads(f);
+    if (H > 1) {     // logits shifted by their head's maximum (so the aggregation runs with amax = 0), biases in Pt
+        GODE_TRY(gode_gat_logits_heads_f32(&pr, f->bw, f->src, f->tgt, f->n_edges, H, w->a, nullptr, w->heads_scratch, stream));
+        return gode_gat_agg_f32_fwd(&f->mt, f->src, f->tgt, &pr, f->d / H, w->zeros, w->a, w->zeros, f->eps, ky, w->wgt, w->den,
+                                    stream);
+    }
     GODE_TRY(gode_gat_logits_f32(&pr, f->bw, f->src, f->tgt, f->n_edges, w->a, w->amax, (float*)w->logits_scratch, stream));
     return gode_gat_agg_f32_fwd(&f->mt, f->src, f->tgt, &pr, f->d, f->bf, w->a, w->amax, f->eps, ky, w->wgt, w->den, stream);
 }
 
-// theta-k layout: [Wsrc ((d+1)*d) | Wtgt ((d+1)*d) | Wlog ((d+1)*2) | bf (d) | bw (1) | gamma (d) | beta (d)]
+// theta-k layout: [Wsrc ((d+1)*d) | Wtgt ((d+1)*d) | Wlog ((d+1)*2H) | bf (d) | bw (H) | gamma (d) | beta (d)]   (H = 1: one head)
 int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lincomb_t yin, const gode_lincomb_t& ain,
                  float t, float* ky, float* ka, float* kat, float* kth, void* stream) {
-    const int64_t n = f->n, d = f->d, nW = (d + 1) * d, nL = (d + 1) * 2;
+    const int64_t H = n_heads(f);
+    const int64_t n = f->n, d = f->d, o = d / H, nv = n * H, nW = (d + 1) * d, nL = (d + 1) * 2 * H;
     GODE_TRY(eval_forward(f, w, &yin, t, ky, stream));                  // yin now names the combined input
-    const gode_gat_proj_t pr = proj_of(w, d);
+    const gode_gat_proj_t pr = proj_of(f, w);
     int32_t did = 0;
-    GODE_TRY(gode_gat_agg_f32_bwd(&f->mt, f->src, f->tgt, &pr, d, f->bf, w->wgt, w->den, ky, nullptr, &ain, -1.f, w->dz,
-                                  w->da, w->dPt, d, w->dA2 + 1, 2, &did, stream));
-    if (f->n_edges > 0)
-        GODE_TRY(gode_gat_maxpath_f32(w->a, w->amax, w->da, f->n_edges, did ? f->tgt : nullptr, did ? w->dA2 + 1 : nullptr, 2,
-                                      w->maxpath_scratch, stream));
+    GODE_TRY(gode_gat_agg_f32_bwd(&f->mt, f->src, f->tgt, &pr, o, H > 1 ? w->zeros : f->bf, w->wgt, w->den, ky, nullptr, &ain,
+                                  -1.f, w->dz, w->da, w->dPt, o, w->dA2 + 1, 2, &did, stream));
+    if (f->n_edges > 0) {
+        if (H > 1)
+            GODE_TRY(gode_gat_maxpath_heads_f32(w->a, w->da, f->n_edges, H, f->tgt, did ? w->dA2 + 1 : nullptr, 2,
+                                                w->heads_scratch, stream));
+        else
+            GODE_TRY(gode_gat_maxpath_f32(w->a, w->amax, w->da, f->n_edges, did ? f->tgt : nullptr, did ? w->dA2 + 1 : nullptr, 2,
+                                          w->maxpath_scratch, stream));
+    }
     if (did) {
         GODE_TRY(gode_spmm_csr_f32(f->ms_inc.rowptr, f->ms_inc.col, nullptr, f->ms_inc.items, f->ms_inc.n_items,
-                                   f->ms_inc.long_rows, f->ms_inc.n_long, f->ms_inc.partial, w->dz, d, w->dPs, d, n, d,
+                                   f->ms_inc.long_rows, f->ms_inc.n_long, f->ms_inc.partial, w->dz, o, w->dPs, o, nv, o,
                                    nullptr, stream));
         GODE_TRY(gode_spmm_csr_f32(f->ms_inc.rowptr, f->ms_inc.col, nullptr, f->ms_inc.items, f->ms_inc.n_items,
-                                   f->ms_inc.long_rows, f->ms_inc.n_long, f->ms_inc.partial, w->da, 1, w->dA2, 2, n, 1,
+                                   f->ms_inc.long_rows, f->ms_inc.n_long, f->ms_inc.partial, w->da, 1, w->dA2, 2, nv, 1,
                                    nullptr, stream));
     } else {
-        GODE_TRY(gode_gat_scatter_f32(f->ms_inc.rowptr, f->ms_inc.col, f->mt_inc.rowptr, f->mt_inc.col, w->dz, w->da, d, n,
-                                      w->dPs, d, w->dPt, d, w->dA2, w->dA2 + 1, 2, stream));
+        GODE_TRY(gode_gat_scatter_f32(f->ms_inc.rowptr, f->ms_inc.col, f->mt_inc.rowptr, f->mt_inc.col, w->dz, w->da, o, nv,
+                                      w->dPs, o, w->dPt, o, w->dA2, w->dA2 + 1, 2, stream));
     }
     float* g_src = kth; float* g_tgt = kth + nW; float* g_log = kth + 2 * nW;
-    float* g_bf = g_log + nL; float* g_bw = g_bf + d; float* g_gamma = g_bw + 1; float* g_beta = g_gamma + d;
+    float* g_bf = g_log + nL; float* g_bw = g_bf + d; float* g_gamma = g_bw + H; float* g_beta = g_gamma + d;
     // bias gradients from the per-target node sums (every edge has exactly one target)
     GODE_TRY(gode_colsum_f32(g_bf, w->dPt, n, d, 1.f, 0, (float*)w->colsum_scratch, stream));
-    GODE_TRY(gode_colsum_f32(w->pair, w->dA2, n, 2, 1.f, 0, (float*)w->colsum_scratch, stream));
-    { gode_lincomb_t one; one.n = 1; one.coef[0] = 1.f; one.ptr[0] = w->pair + 1; GODE_TRY(gode_lincomb_f32(g_bw, &one, 1, stream)); }
+    GODE_TRY(gode_colsum_f32(w->pair, w->dA2, n, 2 * H, 1.f, 0, (float*)w->colsum_scratch, stream));
+    hipLaunchKernelGGL(odd_entries_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, (hipStream_t)stream, g_bw, (const float*)w->pair, (int)H);
+    GODE_LAUNCH_CHECK();
     const int64_t nb = gode_gemm_bwd_parts(n);
     const bool affine = f->groups > 0;
     const float* Wj[3] = {f->Wsrc, f->Wtgt, f->Wlog};
     const float* dPj[3] = {w->dPs, w->dPt, w->dA2};
-    const int64_t dout[3] = {d, d, 2};
+    const int64_t dout[3] = {d, d, 2 * H};
     gode_lincomb_t acc; acc.n = 1; acc.coef[0] = 1.f; acc.ptr[0] = ka;
     for (int j = 0; j < 3; ++j)
         GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, Wj[j], dout[j], 1, dPj[j], 1.f,
@@ -113,7 +149,11 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
 
 int check_common(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, bool adjoint) {
     if (!f || !w) return GODE_E_NULLPTR;
-    if (f->n <= 0 || f->d <= 0 || f->n_edges < 0) return GODE_E_SHAPE;
+    if (f->n <= 0 || f->d <= 0 || f->n_edges < 0 || f->heads < 0) return GODE_E_SHAPE;
+    if (f->heads > 1) {
+        if (f->d % f->heads || f->heads > 64) return GODE_E_SHAPE;
+        if (!w->zeros || !w->heads_scratch) return GODE_E_NULLPTR;
+    }
     if (!f->Wsrc || !f->Wtgt || !f->Wlog || !f->bf || !f->bw || !f->mt.rowptr) return GODE_E_NULLPTR;
     if (!w->X || !w->Ps || !w->Pt || !w->A2 || !w->amax || !w->den || !w->logits_scratch) return GODE_E_NULLPTR;
     if (f->n_edges > 0 && (!f->src || !f->tgt || !w->a || !w->wgt)) return GODE_E_NULLPTR;
@@ -129,6 +169,10 @@ int check_common(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, boo
 }  // namespace
 
 extern "C" int64_t gode_gat_ode_theta_len(int64_t d) { return 2 * (d + 1) * d + (d + 1) * 2 + d + 1 + 2 * d; }
+extern "C" int64_t gode_gat_ode_theta_len_heads(int64_t d, int64_t heads) {
+    if (heads < 1) heads = 1;
+    return 2 * (d + 1) * d + (d + 1) * 2 * heads + d + heads + 2 * d;
+}
 
 extern "C" int gode_gat_ode_dopri5_step_forward(const gode_gat_odefunc_t* f, const float* y, float* const* k, float* y1,
                                                 const gode_gat_workspace_t* w, double t, double h, float rtol, float atol,
@@ -159,7 +203,7 @@ extern "C" int gode_gat_ode_dopri5_step_adjoint(const gode_gat_odefunc_t* f, con
     if (!y || !a || !a_t || !theta || !ky || !ka || !kat || !kth || !y1 || !a1 || !a_t1 || !theta1 || !sums || !err_scratch)
         return GODE_E_NULLPTR;
     for (int s = 0; s < 7; ++s) if (!ky[s] || !ka[s] || !kat[s] || !kth[s]) return GODE_E_NULLPTR;
-    const int64_t nd = f->n * f->d, P = gode_gat_ode_theta_len(f->d);
+    const int64_t nd = f->n * f->d, P = gode_gat_ode_theta_len_heads(f->d, n_heads(f));
     for (int s = 1; s < 7; ++s) {
         gode_lincomb_t yin = dp_terms(y, ky, DPA[s], s, h, true);
         gode_lincomb_t ain = dp_terms(a, ka, DPA[s], s, h, true);

@@ -119,8 +119,8 @@ class MultiHeadGraphConvolution(Module):
 
 
 def _heads_forward(layer, x, src, tgt, Mtgt):
-    if layer.act is not F.relu:
-        raise NotImplementedError("graph_odenet_amd GAT layer: only act=F.relu (the reference default) is fused")
+    if layer.act is not F.relu:          # any other activation: every head through the general (unfused) layer path
+        return torch.cat([hd(x, src, tgt, Mtgt) for hd in layer.heads], 1)
     eg = edge_graph(src, tgt, Mtgt)
     Wsrc, Wtgt, Wlog, bf, ba = layer.packed()
     Ps, Pt, A2 = torch.mm(x, Wsrc), torch.mm(x, Wtgt) + bf, torch.mm(x, Wlog) + ba
@@ -210,6 +210,13 @@ class _HeadsWork:
         npw = lib.gode_wgrad_parts(n)
         self.wp = [torch.empty(npw, spec.i * d, **f), torch.empty(npw, spec.i * d, **f), torch.empty(npw, spec.i * 2 * H, **f)]
         self.ba_grad = torch.empty(2 * H, **f)
+        # extras of the C-level dopri5 step (csrc/gat_driver.hip, heads > 1)
+        u8 = dict(dtype=torch.uint8, device=device)
+        self.zeros = torch.zeros(max(o, 1), **f)
+        self.pair = torch.empty(2 * H, **f)
+        self.heads_scratch = torch.empty(max(lib.gode_gat_heads_scratch_bytes(E, H), 16), **u8)
+        self.colsum_scratch = torch.empty(max(lib.gode_colsum_scratch_bytes(n, d), 16), **u8)
+        self.err_scratch = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), **u8)
         if spec.pad_logits:
             self.A2pad, self.dA2pad = torch.empty(n, d, **f), torch.zeros(n, d, **f)     # columns >= 2H of dA2pad stay 0
             self.wp[2] = torch.empty(npw, spec.i * d, **f)
@@ -218,12 +225,51 @@ class _HeadsWork:
 
 class GatHeadsField(GatOdeField):
     """f(t, x) = relu(heads([t | GroupNorm(x)])) as a kernel sequence (the one-head sequence of gat_ode.py on the
-    H-fold graph).  The C-level dopri5 step is not offered: the adaptive solver takes the per-stage path."""
-    dopri5_step_native = None
+    H-fold graph).  Adaptive steps run as one C call (csrc/gat_driver.hip with heads = H) on launch-bound graphs; above
+    PAD_LOGITS_MIN_ROWS nodes the logit columns ride the padded square kernels and the solver takes the per-stage
+    path."""
 
     def __init__(self, spec, work):
         self.s, self.w = spec, work
         self.token = ("gat-heads", id(spec.eg))
+
+    @property
+    def dopri5_step_native(self):
+        return None if self.s.pad_logits else self._dopri5_step
+
+    def _dopri5_step(self, y, kk, y1, t, h, rtol, atol):
+        return GatOdeField.dopri5_step_native(self, y, kk, y1, t, h, rtol, atol)
+
+    def _structs(self, adjoint):
+        s, w, eg = self.s, self.w, self.s.eg
+        fs = _lib.GatOdeFunc()
+        fs.mt = ops._edge_csr(eg, s.o + 4)
+        for name, gph in (("ms_inc", eg.Ms_inc), ("mt_inc", eg.Mt_inc)):
+            gs = _lib.Graph()
+            gs.rowptr, gs.col, gs.val = gph.rowptr.data_ptr(), gph.col.data_ptr(), None
+            gs.items, gs.n_items = (gph.items.data_ptr() if gph.items is not None else None), gph.n_items
+            gs.long_rows = gph.long_rows.data_ptr() if gph.long_rows is not None else None
+            gs.n_long = gph.n_long
+            part = gph.partial(s.o) if adjoint else None
+            gs.partial = part.data_ptr() if part is not None else None
+            gs.n_rows, gs.nnz = gph.n_rows, gph.nnz
+            setattr(fs, name, gs)
+        p = lambda t: (t.data_ptr() or None) if t is not None else None      # noqa: E731
+        fs.src, fs.tgt, fs.n_edges = p(eg.src), p(eg.tgt), eg.E
+        fs.n, fs.d, fs.groups, fs.eps_gn, fs.eps, fs.heads = s.n, s.d, s.groups, s.eps_gn, s.eps, s.heads
+        fs.Wsrc, fs.Wtgt, fs.Wlog = s.Wsrc.data_ptr(), s.Wtgt.data_ptr(), s.Wlog.data_ptr()
+        fs.bf, fs.bw, fs.gamma, fs.beta = s.bf.data_ptr(), s.bw.data_ptr(), s.gamma.data_ptr(), s.beta.data_ptr()
+        ws = _lib.GatWorkspace()
+        for k in ("X", "Ps", "Pt", "A2", "a", "wgt", "den", "zeros", "heads_scratch"):
+            setattr(ws, k, p(getattr(w, k)))
+        ws.amax, ws.logits_scratch = p(w.zero), p(w.heads_scratch)          # unused by the heads sequence, must be set
+        if adjoint:
+            for k in ("dz", "da", "dPs", "dPt", "dA2", "pair", "gp", "bp", "colsum_scratch"):
+                setattr(ws, k, p(getattr(w, k)))
+            for j in range(3):
+                ws.wp[j] = w.wp[j].data_ptr()
+            ws.maxpath_scratch = p(w.heads_scratch)
+        return fs, ws
 
     def _project(self, t, y_terms):
         s, w = self.s, self.w
@@ -257,6 +303,9 @@ class GatHeadsAdjointField(GatHeadsField):
         self.ratio_groups = [[0], [1], [2], [3]]
 
     new_state = GatOdeAdjointField.new_state
+
+    def _dopri5_step(self, y, kk, y1, t, h, rtol, atol):
+        return GatOdeAdjointField.dopri5_step_native(self, y, kk, y1, t, h, rtol, atol)
 
     def param_grads(self, comps):
         s = self.s
@@ -359,6 +408,29 @@ class ODEfunc(nn.Module):
         return GatHeadsField(spec, work), (lambda: GatHeadsAdjointField(spec, work, order)), tuple(plist)
 
 
+class ODEfunc2(nn.Module):
+    """Two stacked (H-head layer -> relu -> GroupNorm) with the time column re-attached before each layer: the GAT
+    variant's ODEfunc2 (GAT/models.py:551-575) with `heads` reference layers side by side in both positions."""
+
+    def __init__(self, dim, dropout, heads=8):
+        super(ODEfunc2, self).__init__()
+        self.norm1, self.norm2 = _gn(dim), _gn(dim)
+        self.gc1 = FixedMultiHeadGraphConvolution(dim + 1, dim, heads)
+        self.gc2 = FixedMultiHeadGraphConvolution(dim + 1, dim, heads)
+        self.dropout = dropout
+        self.nfe = 0
+
+    def set_adj(self, src, tgt, Mtgt):
+        self.gc1.set_adj(src, tgt, Mtgt)
+        self.gc2.set_adj(src, tgt, Mtgt)
+
+    def forward(self, t, x):
+        self.nfe += 1
+        tt = torch.ones_like(x[:, :1]) * t
+        x = self.norm1(F.relu(self.gc1(torch.cat([tt, x], 1))))
+        return self.norm2(F.relu(self.gc2(torch.cat([tt, x], 1))))
+
+
 # ---- model zoo ----------------------------------------------------------------------------------------------------
 _zoos = {}
 MIN_HEAD_WIDTH = 4
@@ -381,7 +453,7 @@ def zoo(heads=8):
         return ODEfunc(dim, heads)
 
     def odefunc2(dim, dropout):
-        raise NotImplementedError("the two-layer ODE function (ODEK2) has no multi-head form here")
+        return ODEfunc2(dim, dropout, heads)
 
     kit = type("GatHeadsKit%d" % heads, (), {"GraphConvolution": staticmethod(layer), "ODEfunc": staticmethod(odefunc),
                                              "ODEfunc2": staticmethod(odefunc2), "input_dropout": False})

@@ -34,6 +34,7 @@ class EdgeGraph:
         self.n = Mtgt.shape[0] if torch.is_tensor(Mtgt) else Mtgt.n_rows
         self.E = src.numel()
         mt = as_graph(Mtgt)
+        self.Mt_given = mt                      # CSR of Mtgt over the edge ids as given (general-activation path)
         if mt.n_cols != self.E:
             raise ValueError("Mtgt must be N x E with E = len(src)")
         cols = mt.col.to(torch.int64)
@@ -111,9 +112,27 @@ class _EdgeAttentionFn(torch.autograd.Function):
         return None, dPs, dPt, dA2, dbf, dbw, None
 
 
+def _gat_forward_general(layer, x, src, tgt, Mtgt):
+    """The layer with an arbitrary activation callable (the `act=` constructor argument, GAT/layers.py:16): an
+    activation that is not relu cannot be folded into the aggregation kernels, so the per-edge messages are formed as
+    the reference forms them (GAT/layers.py:40-46: gather both endpoints, two Linear layers, act) with PyTorch ops and
+    only the two per-target sums (GAT/layers.py:53,55) run on libgraphode's SpMM."""
+    from .functional import graph_aggregate
+    eg = edge_graph(src, tgt, Mtgt)
+    if eg.E == 0:
+        return torch.zeros(x.shape[0], layer.out_features, dtype=x.dtype, device=x.device) + 0.0 * x.sum()
+    h = torch.cat([x.index_select(0, src), x.index_select(0, tgt)], 1)
+    y = layer.act(layer.f(h))
+    a = layer.w(h)
+    e = torch.exp(a - a.max())                                   # global maximum, as GAT/layers.py:47
+    num = graph_aggregate(eg.Mt_given, y * e)
+    den = graph_aggregate(eg.Mt_given, e)
+    return num / (den + layer.eps)
+
+
 def _gat_forward(layer, x, src, tgt, Mtgt):
     if layer.act is not F.relu:
-        raise NotImplementedError("graph_odenet_amd GAT layer: only act=F.relu (the reference default) is fused")
+        return _gat_forward_general(layer, x, src, tgt, Mtgt)
     eg = edge_graph(src, tgt, Mtgt)
     i, o = layer.in_features, layer.out_features
     Wf, ww = layer.f.weight, layer.w.weight                      # (o, 2i), (1, 2i)

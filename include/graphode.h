@@ -359,6 +359,11 @@ typedef struct gode_gat_odefunc {
     int64_t n, d; int32_t groups; float eps_gn; float eps;
     const float* Wsrc; const float* Wtgt; const float* Wlog;
     const float* bf; const float* bw; const float* gamma; const float* beta;
+    /* H heads side by side (graph_odenet_amd/gat_heads.py; 0 or 1: one head).  With heads = H > 1 the graphs, src, tgt
+     * and n_edges above are those of the H-fold graph (virtual node v*H + h = head h of node v; n stays the number of
+     * real nodes, d = H * o), Wlog is (d+1) x 2H, bw holds H logit biases, bf (d) is added to the target-side
+     * projection, and theta = [Wsrc | Wtgt | Wlog | bf | bw (H) | gamma | beta] (gode_gat_ode_theta_len_heads). */
+    int32_t heads;
 } gode_gat_odefunc_t;
 
 typedef struct gode_gat_workspace {
@@ -371,9 +376,13 @@ typedef struct gode_gat_workspace {
     float* gp; float* bp;                               /* 3 * gode_gemm_bwd_parts(n) * d floats each */
     float* wp[3];                                       /* gode_wgrad_parts(n) * (d+1)*d, same, * (d+1)*2 */
     void* maxpath_scratch; void* colsum_scratch;        /* gode_gat_maxpath_scratch_bytes(E); gode_colsum_scratch_bytes(n, d) */
+    /* heads > 1 only: A2 / dA2 are n x 2H; pair holds 2H floats; zeros (max(o, 1) floats, all 0, read-only);
+     * heads_scratch >= gode_gat_heads_scratch_bytes(n_edges, heads) */
+    const float* zeros; void* heads_scratch;
 } gode_gat_workspace_t;
 
 int64_t gode_gat_ode_theta_len(int64_t d);
+int64_t gode_gat_ode_theta_len_heads(int64_t d, int64_t heads);
 int gode_gat_ode_dopri5_step_forward(const gode_gat_odefunc_t* f, const float* y, float* const* k /* 7 */, float* y1,
                                      const gode_gat_workspace_t* ws, double t, double h, float rtol, float atol,
                                      double* sums, void* err_scratch, void* stream);

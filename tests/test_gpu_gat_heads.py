@@ -306,3 +306,111 @@ def test_head_counts_and_widths_vs_fp64_oracle(H, o, n, E, weighted):
     for hd, ps in zip(layer.heads, heads):
         for p, q in zip((hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias), ps):
             close(p.grad, q.grad, 2e-5, "param")
+
+
+@pytest.mark.parametrize("act_name", ["tanh", "elu", "identity"])
+@pytest.mark.parametrize("H", [1, 4])
+def test_non_relu_activation_vs_fp64_oracle(act_name, H):
+    """The `act=` constructor argument of the layer (GAT/layers.py:16) with something other than relu: the general path
+    (messages as the reference forms them, the two per-target sums on the SpMM kernel), one head and H heads, forward
+    and every gradient against the fp64 oracle."""
+    import torch.nn.functional as F
+    from graph_odenet_amd.gat_heads import MultiHeadGraphConvolution
+    from graph_odenet_amd.gat_layers import GraphConvolution
+    from oracle import layers_ref as R
+    act = {"tanh": torch.tanh, "elu": F.elu, "identity": (lambda v: v)}[act_name]
+    g = torch.Generator().manual_seed(31 + H)
+    n, E, nin, o = 211, 1900, 9, 6
+    src, tgt = torch.randint(0, n, (E,), generator=g), torch.randint(0, n - 3, (E,), generator=g)
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+    torch.manual_seed(H)
+    layer = GraphConvolution(nin, o, act=act) if H == 1 else MultiHeadGraphConvolution(nin, H * o, heads=H, act=act)
+    hds = [layer] if H == 1 else list(layer.heads)
+    x, gout = torch.randn(n, nin, generator=g), torch.randn(n, H * o, generator=g)
+    xd = x.double().requires_grad_(True)
+    ps = [[p.detach().double().requires_grad_(True) for p in (hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias)] for hd in hds]
+    ref = torch.cat([R.gat_layer(xd, src, tgt, Mtgt.double(), *p4, act=act) for p4 in ps], 1)
+    ref.backward(gout.double())
+    layer = layer.to(dev())
+    xg = x.to(dev()).requires_grad_(True)
+    out = layer(xg, src.to(dev()), tgt.to(dev()), Mtgt.to(dev()))
+    close(out, ref, 1e-5, "out")
+    out.backward(gout.to(dev()))
+    close(xg.grad, xd.grad, 2e-5, "gx")
+    for hd, p4 in zip(hds, ps):
+        for p, q in zip((hd.f.weight, hd.f.bias, hd.w.weight, hd.w.bias), p4):
+            close(p.grad, q.grad, 2e-5, "param")
+
+
+def test_multihead_odefunc2_and_odek2(golden):
+    """The two-layer ODE function with H-head layers (the GAT variant's ODEfunc2, GAT/models.py:551-575) and the ODEK2
+    model built on it: against the oracle heads composed the same way, and one training step of the zoo's ODEK2."""
+    from graph_odenet_amd import gat_heads
+    from oracle import layers_ref as R
+    g = golden("gat_heads.npz")
+    n, src, tgt = int(g["n"]), T(g["src"]).long(), T(g["tgt"]).long()
+    E = src.numel()
+    Mtgt = torch.sparse_coo_tensor(torch.stack([tgt, torch.arange(E)]), torch.ones(E), (n, E))
+    d, H = 128, 4                      # 4 channels per GroupNorm group: well conditioned (SURVEY Q4)
+    torch.manual_seed(9)
+    f = gat_heads.ODEfunc2(d, 0.0, heads=H)
+    x = torch.randn(n, d)
+    t = 0.3
+
+    def heads_of(layer):
+        return [[hd.f.weight.detach().double(), hd.f.bias.detach().double(), hd.w.weight.detach().double(),
+                 hd.w.bias.detach().double()] for hd in layer.heads]
+
+    def gn(v, norm):
+        return torch.nn.functional.group_norm(v, norm.num_groups, norm.weight.detach().double(), norm.bias.detach().double(), norm.eps)
+    xd = x.double()
+    tt = torch.full((n, 1), t, dtype=torch.float64)
+    h1 = gn(torch.relu(R.gat_multihead_layer(torch.cat([tt, xd], 1), src, tgt, Mtgt.double(), heads_of(f.gc1))), f.norm1)
+    ref = gn(torch.relu(R.gat_multihead_layer(torch.cat([tt, h1], 1), src, tgt, Mtgt.double(), heads_of(f.gc2))), f.norm2)
+    f = f.to(dev())
+    f.set_adj(src.to(dev()), tgt.to(dev()), Mtgt.to(dev()))
+    out = f(torch.tensor(t), x.to(dev()))
+    # GroupNorm after relu: groups whose four messages are all near zero are normalised with rstd up to 1/sqrt(eps) =
+    # 316, which amplifies the 1e-6 rounding of the layer output (measured 4.5e-5 on outputs of magnitude 1.7)
+    close(out, ref, 1e-4, "ODEfunc2 with heads")
+    zoo = gat_heads.zoo(H)
+    torch.manual_seed(2)
+    m = zoo.ODEK2(nfeat=12, nhid=d, nclass=5, dropout=0.3, nlayers=4, method="rk4", step_size=0.5).to(dev())
+    assert type(m.gcs[1].odefunc).__name__ == "ODEfunc2" and type(m.gcs[1].odefunc.gc1).__name__ == "FixedMultiHeadGraphConvolution"
+    xin = torch.randn(n, 12, device=dev())
+    y = torch.randint(0, 5, (n,), device=dev())
+    loss = torch.nn.functional.nll_loss(m(xin, src.to(dev()), tgt.to(dev()), Mtgt.to(dev())), y)
+    loss.backward()
+    _finite_grads(m, 0)
+
+
+@pytest.mark.parametrize("d,H", [(32, 4), (64, 8)])
+def test_native_dopri5_step_for_heads_matches_python_driver(golden, d, H):
+    """The H-head field's adaptive step as ONE C call (csrc/gat_driver.hip, heads = H) against the per-stage Python
+    driver: same kernels in the same order, so outputs, gradients and nfe agree bit for bit."""
+    from graph_odenet_amd import solver as PS
+    from graph_odenet_amd.gat_heads import ODEfunc
+    from graph_odenet_amd.models import ODEBlock
+    n, src, tgt, Mtgt = _citeseer(golden)
+    src, tgt, Mtgt = src.to(dev()), tgt.to(dev()), Mtgt.to(dev())
+    x = torch.randn(n, d, generator=torch.Generator().manual_seed(3)).to(dev()) * 0.5
+    gout = torch.randn(n, d, generator=torch.Generator().manual_seed(4)).to(dev())
+    res = {}
+    for native in (True, False):
+        PS.DOPRI5_NATIVE = native
+        try:
+            torch.manual_seed(6)
+            blk = ODEBlock(ODEfunc(d, H), tol=1e-4).to(dev())
+            xi = x.clone().requires_grad_(True)
+            out = blk(xi, src, tgt, Mtgt)
+            nfe_f = blk.nfe
+            out.backward(gout)
+            res[native] = (out.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()], nfe_f, blk.nfe)
+            fld = blk.odefunc.gode_fields(x)[0]
+            assert (fld.dopri5_step_native is not None) and not fld.s.pad_logits
+        finally:
+            PS.DOPRI5_NATIVE = True
+    assert res[True][3:] == res[False][3:]
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)
