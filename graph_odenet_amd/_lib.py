@@ -105,6 +105,9 @@ SIGNATURES = {
     "gode_wgrad_parts": (c_i64, [c_i64]),
     "gode_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
                              c_p, c_i64, c_i, c_p, c_p]),
+    "gode_bwd_wgrad_parts": (c_i64, [c_i64]),
+    "gode_gn_time_gemm_bwd_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_i,
+                                              c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p, c_p, c_p]),
     "gode_reduce_parts_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
     "gode_reduce_parts2_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
     "gode_colsum_scratch_bytes": (c_i64, [c_i64, c_i64]),

@@ -244,6 +244,42 @@ def wgrad(x_terms, n_rows, d_in, groups, eps, gamma, beta, dS, has_time, part=No
     return part
 
 
+def gn_time_gemm_bwd_wgrad(x_terms, n_rows, d, groups, eps, gamma, beta, W, has_time, dS, out_scale=1.0, out=None,
+                           pre_terms=None, dW=None, dgamma=None, dbeta=None):
+    """VJP and weight gradient in one pass (gode_gn_time_gemm_bwd_wgrad_f32).  Returns (dx, dW, dgamma, dbeta), or
+    None when the shape is outside the fused path (use gn_time_gemm_bwd + wgrad then)."""
+    lib = _lib.load()
+    _need(W, "W"); _need(gamma, "gamma"); _need(beta, "beta"); _need(dS, "dS")
+    if _need_terms(x_terms, "x") != n_rows * d:
+        raise ValueError("gn_time_gemm_bwd_wgrad: x terms have wrong size")
+    k = d + (1 if has_time else 0)
+    if tuple(W.shape) != (k, d) or dS.numel() != n_rows * d:
+        raise ValueError("gn_time_gemm_bwd_wgrad: W must be (%d, %d) and dS n x d" % (k, d))
+    f = dict(dtype=torch.float32, device=W.device)
+    out = torch.empty(n_rows, d, **f) if out is None else out
+    dW = torch.empty(k, d, **f) if dW is None else dW
+    if groups > 0:
+        dgamma = torch.empty(d, **f) if dgamma is None else dgamma
+        dbeta = torch.empty(d, **f) if dbeta is None else dbeta
+    for t, nm in ((out, "out"), (dW, "dW"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _need(t, nm)
+    part = torch.empty(lib.gode_bwd_wgrad_parts(n_rows) * (d * d + d), **f)
+    lc = lincomb(x_terms)
+    pre = None
+    if pre_terms is not None:
+        if _need_terms(pre_terms, "pre") != n_rows * d:
+            raise ValueError("gn_time_gemm_bwd_wgrad: pre terms have wrong size")
+        pre = lincomb(pre_terms)
+    rc = lib.gode_gn_time_gemm_bwd_wgrad_f32(ctypes.byref(lc), n_rows, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(W),
+                                             1 if has_time else 0, ptr(dS), float(out_scale),
+                                             ctypes.byref(pre) if pre is not None else None, ptr(out), ptr(part), ptr(dW),
+                                             ptr(dgamma), ptr(dbeta), stream_ptr())
+    if rc == -5:                         # GODE_E_UNSUPPORTED
+        return None
+    check(rc, "gode_gn_time_gemm_bwd_wgrad_f32")
+    return out, dW, dgamma, dbeta
+
+
 def reduce_parts_(out, part, scale=1.0, accumulate=False):
     """out (+)= scale * part.sum(0)   with `part` of shape [n_part, out.numel()]."""
     lib = _lib.load()

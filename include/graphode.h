@@ -171,6 +171,19 @@ int gode_wgrad_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t
                    const float* dS, int64_t d_out, int has_time,
                    float* dW_part, void* stream);
 
+/* VJP and weight gradient of S = [t | GroupNorm(x)] W in ONE pass over dS and x (square W, d in {16, 32, 64, 128},
+ * GroupNorm with 1, 2 or 4 channels per group or none; 16-byte aligned operands) - what an adjoint stage needs from
+ * autograd of GCN/models.py:175-177 + GCN/layers.py:70:
+ *   dx = out_scale * GN'(x)^T (dS W1^T) (+ sum pre),  dW ((d+has_time) x d; row 0 = colsum(dS) with has_time),
+ *   dgamma, dbeta (d each; nullable; written when groups > 0).
+ * `part`: gode_bwd_wgrad_parts(n_rows) * (d*d + d) floats of scratch.  Returns GODE_E_UNSUPPORTED for shapes outside
+ * this path (the caller then uses gode_gn_time_gemm_bwd_f32 + gode_wgrad_f32). */
+int64_t gode_bwd_wgrad_parts(int64_t n_rows);
+int gode_gn_time_gemm_bwd_wgrad_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d, int32_t groups,
+                                    float eps, const float* gamma, const float* beta, const float* W, int has_time,
+                                    const float* dS, float out_scale, const gode_lincomb_t* pre /* host, nullable */,
+                                    float* dx, float* part, float* dW, float* dgamma, float* dbeta, void* stream);
+
 /* out[j] (+)= scale * sum_p part[p*len + j]   (accumulate != 0 adds to out) */
 int gode_reduce_parts_f32(float* out, const float* part, int64_t n_part, int64_t len,
                           float scale, int accumulate, void* stream);
@@ -414,11 +427,12 @@ int gode_gru_cell_f32_bwd(const float* x, const float* m, const float* w_ih, con
  * per-launch milliseconds, feature width d, record count (SpMM) or row count (dense) and `extra` = number of
  * additional n_rows x d operand arrays the launch read or wrote besides its plain operands (SpMM: pre terms +
  * cotangent terms + Y2; dense: stage terms beyond the first, + x_out, + pre terms).
- * gode_prof_kinds: what each launch was - GODE_PROF_SPMM / _GEMM_FWD / _GEMM_BWD / _WGRAD. */
+ * gode_prof_kinds: what each launch was - GODE_PROF_SPMM / _GEMM_FWD / _GEMM_BWD / _WGRAD / _BWD_WGRAD. */
 #define GODE_PROF_SPMM     0
 #define GODE_PROF_GEMM_FWD 1
 #define GODE_PROF_GEMM_BWD 2
 #define GODE_PROF_WGRAD    3
+#define GODE_PROF_BWD_WGRAD 4
 void* gode_prof_create(int capacity);
 void  gode_prof_destroy(void* prof);
 void  gode_prof_enable(void* prof /* NULL = off */);

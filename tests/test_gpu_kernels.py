@@ -208,6 +208,49 @@ def test_gn_time_gemm_fwd_bwd_wgrad(d, groups, n):
     close(gW[0] * t, W.grad[0], tol=2e-5 * max(1, n ** 0.5), what="dW time row")
 
 
+@pytest.mark.parametrize("d,groups", [(16, 16), (32, 32), (64, 32), (128, 32), (128, 0), (64, 0)])
+@pytest.mark.parametrize("n", [1, 15, 257, 4100, 70001])
+def test_fused_vjp_and_weight_gradient(d, groups, n):
+    """gode_gn_time_gemm_bwd_wgrad_f32 (one pass over dS and x: dx, dW, dgamma, dbeta) against autograd of the plain
+    torch CPU ops, with a two-term input, an output scale and accumulated pre-terms as the rk4 adjoint uses them."""
+    from graph_odenet_amd import ops
+    import torch.nn.functional as F
+    if n == 1 and groups == d:
+        pytest.skip("torch's own group_norm refuses one value per group at batch 1")
+    torch.manual_seed(d * 11 + n)
+    y, k1 = torch.randn(n, d), torch.randn(n, d)
+    h = 0.3
+    x = (y + h * k1).requires_grad_(True)
+    gam = (torch.rand(d) + 0.5).requires_grad_(True)
+    bet = (torch.rand(d) - 0.5).requires_grad_(True)
+    W = (torch.randn(d + 1, d) / d ** 0.5).requires_grad_(True)
+    t = 0.37
+    xn = F.group_norm(x, groups, gam, bet, 1e-5) if groups else x
+    S = torch.cat([torch.full((n, 1), t), xn], 1) @ W
+    dS = torch.randn(n, d)
+    S.backward(dS)
+    D = dev()
+    terms = [(1.0, y.to(D)), (h, k1.to(D))]
+    g_, b_ = (gam.detach().to(D), bet.detach().to(D)) if groups else (None, None)
+    p0 = torch.randn(n, d)
+    res = ops.gn_time_gemm_bwd_wgrad(terms, n, d, groups, 1e-5, g_, b_, W.detach().to(D), True, dS.to(D), out_scale=0.7,
+                                     pre_terms=[(2.0, p0.to(D))])
+    assert res is not None, "shape should be on the fused path"
+    dx, gW, dg, db = res
+    cg = d // groups if groups else 0
+    close(dx, 2.0 * p0 + 0.7 * x.grad, tol={0: TOL, 1: 2e-3, 2: 1e-4}.get(cg, 2e-5), what="dx")
+    rt = max(1, n ** 0.5)
+    tol = {0: TOL, 1: 2e-4, 2: 2e-5}.get(cg, TOL)
+    close(gW[1:], W.grad[1:], tol=max(tol, 2e-5) * rt, what="dW")
+    close(gW[0] * t, W.grad[0], tol=2e-5 * rt, what="dW time row")
+    if groups:
+        close(dg, gam.grad, tol=(2e-3 if cg == 1 else 2e-5) * rt, what="dgamma")
+        close(db, bet.grad, tol=2e-5 * rt, what="dbeta")
+    # shapes outside the path are refused, not mis-computed
+    assert ops.gn_time_gemm_bwd_wgrad([(1.0, torch.randn(8, 24, device=D))], 8, 24, 0, 1e-5, None, None,
+                                      torch.randn(25, 24, device=D), True, torch.randn(8, 24, device=D)) is None
+
+
 @pytest.mark.parametrize("d,dout,groups", [(16, 34, 16), (64, 130, 32), (128, 258, 32), (24, 7, 0)])
 def test_gn_time_gemm_rectangular(d, dout, groups):
     """d_out != d_in (the GAT node-level projection is d x (2o+2)): generic kernels, same parity bar."""
