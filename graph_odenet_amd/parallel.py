@@ -53,38 +53,50 @@ class GradBucket:
 
     Parameters without a gradient: counted as zero on this rank; a parameter that received no gradient on ANY rank
     gets `.grad = None` back, as in a single-process run (the optimiser then skips it instead of applying weight
-    decay / momentum to it) - one small mask all-reduce per step decides."""
+    decay / momentum to it) - every bucket's slice ends with one flag per parameter, summed by the same collective."""
 
     def __init__(self, module, bucket_bytes=16 << 20, overlap=True):
         self.params = [p for p in module.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.mask = torch.zeros(max(len(self.params), 1), dtype=torch.float32, device=dev)
-        self.views = [None] * len(self.params)
-        self.buckets = []                     # (lo, hi, [param indices]) over the flat buffer, in launch order
-        o, cur, lo = 0, [], 0
-        for i in reversed(range(len(self.params))):      # flat layout = reverse registration order
-            p = self.params[i]
-            k = p.numel()
-            v = self.flat[o:o + k].view_as(p)
-            if p.grad is not None:
-                v.copy_(p.grad)
-            p.grad = v
-            self.views[i] = v
+        # buckets in reverse registration order; the slice of a bucket in the flat buffer is its gradients followed by
+        # one "received a gradient" flag per parameter, so that ONE collective per bucket carries both
+        groups, cur, size = [], [], 0
+        for i in reversed(range(len(self.params))):
             cur.append(i)
-            o += k
-            if (o - lo) * 4 >= bucket_bytes:
-                self.buckets.append((lo, o, cur))
-                cur, lo = [], o
+            size += self.params[i].numel() * 4
+            if size >= bucket_bytes:
+                groups.append(cur)
+                cur, size = [], 0
         if cur:
-            self.buckets.append((lo, o, cur))
-        self._bucket_of = {i: b for b, (_, _, idx) in enumerate(self.buckets) for i in idx}
+            groups.append(cur)
+        total = sum(sum(self.params[i].numel() for i in g) + len(g) for g in groups)
+        self.buf = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views = [None] * len(self.params)
+        self.buckets = []                     # (lo, hi_grads, hi, [param indices]) over self.buf, in launch order
+        o = 0
+        for g in groups:
+            lo = o
+            for i in g:
+                p = self.params[i]
+                v = self.buf[o:o + p.numel()].view_as(p)
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+                self.views[i] = v
+                o += p.numel()
+            self.buckets.append((lo, o, o + len(g), g))
+            o += len(g)
+        self._bucket_of = {i: b for b, (_, _, _, idx) in enumerate(self.buckets) for i in idx}
         self.overlap = bool(overlap)
         self._reset()
         # the hooks also tell which parameters received a gradient in this step (a kept `.grad` view looks the same
         # whether or not backward wrote to it), so they are registered in both modes
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    @property
+    def flat(self):
+        """The exchanged buffer (gradients + per-parameter flags)."""
+        return self.buf
 
     def _reset(self):
         self._ready = [0] * len(self.buckets)
@@ -111,13 +123,21 @@ class GradBucket:
             self._attach(i)
             b = self._bucket_of[i]
             self._ready[b] += 1
-            if self._ready[b] == len(self.buckets[b][2]):
+            if self._ready[b] == len(self.buckets[b][3]):
                 self._launch(b)
         return hook
 
     def _launch(self, b):
-        lo, hi, _ = self.buckets[b]
-        chunk = self.flat[lo:hi]
+        lo, hg, hi, idx = self.buckets[b]
+        flags = [1.0 if (self._seen[i] and self._attach(i)) else 0.0 for i in idx]
+        for i, f in zip(idx, flags):
+            if not f:
+                self.views[i].zero_()                     # no gradient here: contributes zero to the sum
+        if all(flags):
+            self.buf[hg:hi].fill_(1.0)
+        else:
+            self.buf[hg:hi].copy_(torch.tensor(flags, dtype=torch.float32))
+        chunk = self.buf[lo:hi]
         self._launched[b] = True
         if dist.get_backend() == "gloo" and chunk.is_cuda:      # one-box rehearsal: staged through the host
             host = chunk.cpu()
@@ -141,35 +161,26 @@ class GradBucket:
             return
         if assume_all:
             self._seen = [p.grad is not None for p in self.params]
-        had = []
-        for i in range(len(self.params)):
-            ok = self._seen[i] and self._attach(i)
-            had.append(ok)
-            if not ok:
-                self.views[i].zero_()                     # no gradient here: contributes zero to the sum
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        self.mask.zero_()
-        if any(had):
-            self.mask[:len(had)] = torch.tensor([1.0 if h else 0.0 for h in had], dtype=torch.float32).to(self.mask.device)
-        if dist.get_backend() == "gloo" and self.mask.is_cuda:
-            host = self.mask.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            self.mask.copy_(host)
-            mwork = None
-        else:
-            mwork = dist.all_reduce(self.mask, op=dist.ReduceOp.SUM, async_op=True)
         for w in self._work:
             if w is not None:
                 w.wait()
-        if mwork is not None:
-            mwork.wait()
         if mean:
-            self.flat.div_(dist.get_world_size())
-        anywhere = self.mask[:len(self.params)].tolist()
-        for i, p in enumerate(self.params):
-            p.grad = self.views[i] if anywhere[i] > 0 else None
+            self.buf.div_(dist.get_world_size())
+        if all(self._seen):
+            # every parameter has a gradient on THIS rank, hence somewhere: no need to read the flags back (the common
+            # case stays free of host synchronisation)
+            for i, p in enumerate(self.params):
+                p.grad = self.views[i]
+        else:
+            flags = torch.cat([self.buf[hg:hi] for (_, hg, hi, _) in self.buckets]).tolist()
+            k = 0
+            for (_, _, _, idx) in self.buckets:
+                for i in idx:
+                    self.params[i].grad = self.views[i] if flags[k] > 0 else None
+                    k += 1
         self._reset()
 
 
