@@ -11,7 +11,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 echo "stats rc=$?"; tail -1 $OUT/bench_stats.log | cut -c1-400
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$n.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-configs --no-secondary > $OUT/pmc_$n.log 2>&1
   echo "pmc $c rc=$?"
 done
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -19,3 +19,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "cal $c rc=$?"
 done
 python $R/tools/summarize_profile.py $OUT $TAG
+# the raw traces are hundreds of MB (gpurun copies back at most 64 MiB): keep the summaries and the logs only
+rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_TCC_HIT_sum_TCC_MISS_sum $OUT/cal_FETCH_SIZE $OUT/cal_WRITE_SIZE
