@@ -25,6 +25,10 @@ import os
 import sys
 import time
 
+# graph_odenet_amd/hipgraph.py: replayed memset nodes need the HIP runtime's graph fast path off (read at runtime
+# initialisation, which torch.cuda.set_device below triggers); no measurable cost on the captured solves
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")     # graph_odenet_amd/hipgraph.py (stand-alone runs)
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -99,7 +101,7 @@ def c3_citeseer_gat(dev, heads, nhid):
             "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
 
 
-def c4_qc(dev, model_name):
+def c4_qc(dev, model_name, captured=False):
     from graph_odenet_amd import qc_models
     from graph_odenet_amd.synth import qm9_like_batch
     torch.manual_seed(0)
@@ -119,19 +121,45 @@ def c4_qc(dev, model_name):
         F.mse_loss(net(x, ef, Esrc, Etgt, batch), tgt).backward()
         opt.step()
     ms, _ = _time_steps(step, warm=len(batches), n=2 * len(batches))     # first pass: every batch shape seen once
-    return {"workload": "%s h=73 T=3, 20 QM9-like molecules per step, 16 distinct batches cycled (each shape seen once before "
-                        "timing; tools/qc_bench.py times never-repeating batches)" % model_name,
-            "ms_per_step": round(ms, 3), "graphs_per_s": round(20e3 / ms, 1)}
+    res = {"workload": "%s h=73 T=3, 20 QM9-like molecules per step, 16 distinct batches cycled (each shape seen once before "
+                       "timing; tools/qc_bench.py times never-repeating batches)" % model_name,
+           "ms_per_step": round(ms, 3), "graphs_per_s": round(20e3 / ms, 1)}
+    if not captured:
+        return res
+    # the same batches padded to shape buckets, one HIP-graph replay per step (qc_step.CapturedQCStep); only when this
+    # process honours replayed memset nodes (graph_odenet_amd/hipgraph.py).  Stand-alone runs only: bench.py keeps
+    # graph captures of arbitrary autograd away from the process that has to print the contract line.
+    try:
+        from graph_odenet_amd import hipgraph
+        from graph_odenet_amd.qc_batch import pad_batch
+        from graph_odenet_amd.qc_step import CapturedQCStep
+        if hipgraph.memset_nodes_ok(dev):
+            padded = [pad_batch(*b[:5])[:5] + (b[5],) for b in batches]
+            opt2 = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+            cstep = CapturedQCStep(net, opt2, F.mse_loss)
+            jt = [0]
+
+            def step2():
+                cstep(*padded[jt[0] % len(padded)])
+                jt[0] += 1
+            ms2, _ = _time_steps(step2, warm=4 * len(padded), n=2 * len(padded))
+            res["ms_per_step_captured"] = round(ms2, 3)
+            res["shape_buckets"] = len(cstep.buckets)
+        else:
+            res["ms_per_step_captured"] = None
+    except Exception as e:
+        res["ms_per_step_captured"] = "error: %s: %s" % (type(e).__name__, e)
+    return res
 
 
-def all_configs(dev):
+def all_configs(dev, qc_captured=False):
     out = {}
     for key, fn in (("C1_cora_gcn_ode_rk4", lambda: c1_cora(dev)),
                     ("C2_pubmed_dense_paper_ode_dopri5", lambda: c2_pubmed(dev)),
                     ("C3_citeseer_gat_8head_ode_rk4", lambda: c3_citeseer_gat(dev, 8, 64)),
                     ("C3_citeseer_gat_1head_ode_rk4", lambda: c3_citeseer_gat(dev, 1, 16)),
-                    ("C4_qc_edge_gcn_sum", lambda: c4_qc(dev, "EdgeGCN_K_Sum")),
-                    ("C4_qc_mpnn_enn_set2set", lambda: c4_qc(dev, "MPNN_ENN_K_Set2Set"))):
+                    ("C4_qc_edge_gcn_sum", lambda: c4_qc(dev, "EdgeGCN_K_Sum", qc_captured)),
+                    ("C4_qc_mpnn_enn_set2set", lambda: c4_qc(dev, "MPNN_ENN_K_Set2Set", qc_captured))):
         try:
             out[key] = fn()
         except Exception as e:                     # a secondary number must never take the contract line down
@@ -141,4 +169,4 @@ def all_configs(dev):
 
 
 if __name__ == "__main__":
-    print(json.dumps(all_configs(torch.device("cuda:0")), indent=1))
+    print(json.dumps(all_configs(torch.device("cuda:0"), qc_captured=True), indent=1))
