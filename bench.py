@@ -294,7 +294,7 @@ def main():
                        "nodes": n, "nnz": g.nnz, "nfeat": args.nfeat, "hidden": args.hidden,
                        "nclass": args.nclass, "nfe_per_step": nfe_per_step,
                        "parallelism": "dp%d (one graph per rank, 1 gradient all-reduce/step)" % world},
-            "loss": round(float(loss), 5),
+            "loss": round(float(loss.detach()), 5),
             "roofline": roof,
             "roofline_dense": dense,
         }

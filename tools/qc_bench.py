@@ -134,7 +134,7 @@ def main():
                "value": round(world * args.batch_size * args.steps / el, 1), "unit": "graphs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * el / args.steps, 3), "scaling": "weak", "dtype": "f32",
-               "data": "synthetic", "loss": round(float(loss), 5),
+               "data": "synthetic", "loss": round(float(loss.detach()), 5),
                "config": {"workload": "%s h=73 T=3, %d QM9-like molecules per rank, a new batch every step (graph conversion timed)%s"
                                       % (args.model, args.batch_size, ", padded to shape buckets" if args.bucket else ""),
                           "params": sum(p.numel() for p in net.parameters()),
