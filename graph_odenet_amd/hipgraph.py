@@ -12,7 +12,7 @@ Consequences here:
   * libgraphode launches no memset at all (tests/test_abi.py checks the sources), so captured solves of the fused
     fields (odeint._GraphedSolve: our kernels plus copies / fills / small single-block reductions) are safe either way;
   * captures that contain arbitrary PyTorch autograd (qc_step.CapturedQCStep) are only taken when `memset_nodes_ok()`
-    says the running process honours memset nodes - otherwise the step stays on the eager path.
+    says so: the variable reads 0 and a replay self-test passes - otherwise the step stays on the eager path.
 `prefer_safe_graphs()` sets the variable when the HIP runtime has not been initialised yet.
 """
 import ctypes
@@ -33,10 +33,17 @@ def prefer_safe_graphs():
 
 
 def memset_nodes_ok(device=None):
-    """Self-test (once per process, ~1 ms): capture  memset(buf); buf += 1; out += sum(buf)  ten times in a row and
-    replay the graph 20 times."""
+    """True when this process may rely on replayed memset nodes: the variable must read 0 (the only setting under which
+    every replay of every probe was right) AND a self-test must pass (once per process, ~1 ms: capture
+    memset(buf); buf += 1; out += sum(buf)  ten times in a row, replay 20 times).  The self-test alone is NOT
+    sufficient: on the fast path it fails in a fresh process but was seen to pass after other GPU work had run in the
+    process (round 2, `pytest -k "captured_qc or fused_gru"` with the variable set to 1), i.e. the fast path's
+    behaviour depends on process state and a toy graph cannot certify another graph."""
     global _ok
     if _ok is not None:
+        return _ok
+    if os.environ.get(ENV) != "0":
+        _ok = False
         return _ok
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("memset_nodes_ok() must be called outside a capture")

@@ -252,10 +252,13 @@ def test_captured_qc_step_matches_eager(name):
     captured into one HIP graph per bucket and replayed on new batches, two buckets interleaved - losses and final
     parameters equal the eager run of the same padded batches."""
     import torch.nn.functional as F
-    from graph_odenet_amd import qc_models
+    from graph_odenet_amd import hipgraph, qc_models
     from graph_odenet_amd.qc_batch import pad_batch
     from graph_odenet_amd.qc_step import CapturedQCStep
     from graph_odenet_amd.synth import qm9_like_batch
+    if not hipgraph.memset_nodes_ok():
+        pytest.skip("this process runs HIP's graph fast path, on which replayed memset nodes are unreliable "
+                    "(hipgraph.py): CapturedQCStep stays eager by design")
     batches = []
     for b in range(60):
         x, ef, Esrc, Etgt, batch = qm9_like_batch(6, seed=100 + b, device=dev())
