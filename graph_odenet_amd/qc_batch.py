@@ -14,10 +14,17 @@ import torch
 
 def pad_batch(x, edge_feat, Esrc, Etgt, batch, node_multiple=64, edge_multiple=128):
     """Returns (x, edge_feat, Esrc, Etgt, batch, n_graphs) with x.shape[0] a multiple of `node_multiple`, Esrc.numel()
-    a multiple of `edge_multiple`, and the dummy graph numbered n_graphs (use `out[:n_graphs]`)."""
+    a multiple of `edge_multiple`, and the dummy graph numbered n_graphs (use `out[:n_graphs]`).  `Etgt` is the dense
+    N x E matrix of the reference's collate, or the per-edge target index vector (int64[E]) a loader has before it
+    builds that matrix - the same kind comes back."""
     n, e = x.shape[0], Esrc.numel()
-    if Etgt.dim() != 2 or tuple(Etgt.shape) != (n, e) or Etgt.layout != torch.strided:
-        raise ValueError("pad_batch: Etgt must be the dense N x E incidence of the reference's collate")
+    by_index = Etgt.dim() == 1 and not Etgt.is_floating_point()       # per-edge target index instead of the dense matrix
+    if by_index:
+        if Etgt.numel() != e:
+            raise ValueError("pad_batch: one target index per edge")
+    elif Etgt.dim() != 2 or tuple(Etgt.shape) != (n, e) or Etgt.layout != torch.strided:
+        raise ValueError("pad_batch: Etgt must be the dense N x E incidence of the reference's collate (or the per-edge "
+                         "target index vector)")
     n_graphs = int(batch.max().item()) + 1 if n else 0
     e_pad = -(-max(e, 1) // edge_multiple) * edge_multiple
     n_pad = -(-(n + 1) // node_multiple) * node_multiple            # at least one dummy atom: dummy edges live on it
@@ -26,9 +33,23 @@ def pad_batch(x, edge_feat, Esrc, Etgt, batch, node_multiple=64, edge_multiple=1
     x2 = torch.cat([x, x.new_zeros(dn, x.shape[1])])
     ef2 = torch.cat([edge_feat, edge_feat.new_zeros(de, edge_feat.shape[1])])
     src2 = torch.cat([Esrc, torch.full((de,), n, dtype=Esrc.dtype, device=dev)])
-    Etgt2 = Etgt.new_zeros(n_pad, e_pad)
-    Etgt2[:n, :e] = Etgt
-    if de:
-        Etgt2[n, e:] = 1.0
+    if by_index:
+        Etgt2 = torch.cat([Etgt, torch.full((de,), n, dtype=Etgt.dtype, device=dev)])
+    else:
+        Etgt2 = Etgt.new_zeros(n_pad, e_pad)
+        Etgt2[:n, :e] = Etgt
+        if de:
+            Etgt2[n, e:] = 1.0
     batch2 = torch.cat([batch, torch.full((dn,), n_graphs, dtype=batch.dtype, device=dev)])
     return x2, ef2, src2, Etgt2, batch2, n_graphs
+
+
+def prepare(Esrc, etgt, batch, n_nodes, n_graphs):
+    """Loader-side preparation of a batch for the QC models: returns (edges, batch) to be passed in place of
+    (Etgt, batch).  `etgt` is the per-edge target index (the loader has it before it builds the reference's dense
+    N x E matrix); nothing here synchronises with the host, so a training loop that prepares its batches this way keeps
+    the GPU queue full (the dense-matrix route costs a column arg-max over N x E, a validity check and a second
+    synchronisation for the number of graphs - DESIGN.md section 5)."""
+    from .qc_layers import prepared_edges
+    batch._gode_n_graphs = int(n_graphs)
+    return prepared_edges(Esrc, etgt, n_nodes), batch

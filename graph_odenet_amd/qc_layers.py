@@ -62,8 +62,36 @@ class _EdgeSet:
             self.edge_val[cols] = self.Mt.val if self.Mt.val is not None else 1.0
         self.Ms_inc = incidence_from_index(self.src, self.n)
 
+    @classmethod
+    def from_index(cls, Esrc, etgt, n_nodes, values=None):
+        """The same object from the per-edge TARGET INDEX vector (what a loader has before it scatters it into the
+        reference's dense N x E matrix, QC/datasets/utils.py:194-214): no dense matrix, no validity check, hence no
+        host synchronisation - a training loop can hand the result to the models in place of `Etgt`."""
+        self = cls.__new__(cls)
+        self.E = Esrc.numel()
+        self.n = int(n_nodes)
+        if etgt.numel() != self.E:
+            raise ValueError("from_index: one target per edge")
+        self.src = Esrc.to(torch.int32).contiguous()
+        tgt = etgt.to(torch.int64)
+        val = torch.ones(self.E, dtype=torch.float32, device=Esrc.device) if values is None else values.to(torch.float32)
+        self.Mt = csr_from_assignment(tgt, self.n, val)            # record list (one sync) only from 65 536 edges on
+        self.edge_row = tgt.to(torch.int32).contiguous()
+        self.edge_val = val.contiguous()
+        self.Ms_inc = incidence_from_index(self.src, self.n)
+        return self
+
+
+def prepared_edges(Esrc, etgt, n_nodes, values=None):
+    """Loader-side form of (Esrc, Etgt): pass the result wherever a model takes `Etgt` (see _EdgeSet.from_index)."""
+    return _EdgeSet.from_index(Esrc, etgt, n_nodes, values)
+
 
 def _edges(Esrc, Etgt):
+    if isinstance(Etgt, _EdgeSet):                   # prepared by the loader (qc_layers.prepared_edges)
+        if Etgt.E != Esrc.numel():
+            raise ValueError("prepared edges do not belong to this Esrc")
+        return Etgt
     key = (id(Esrc), id(Etgt))
     hit = _cache.get(key)
     if hit is not None and hit[0] is Esrc and hit[1] is Etgt:

@@ -9,6 +9,7 @@ graph's pool, or launches a memset (tests/test_abi.py).
 
     step = CapturedQCStep(model, optimizer, loss_fn)          # optimizer: torch.optim.Adam(..., capturable=True)
     loss = step(x, edge_feat, Esrc, Etgt, batch, target)      # tensors of a padded batch; returns the loss tensor
+                                                              # (Etgt: the dense N x E matrix or the int64[E] target index)
 
 The capture contains arbitrary PyTorch autograd, whose reductions may clear buffers with memset nodes: it is only taken
 when hipgraph.memset_nodes_ok() passes in this process (see hipgraph.py: start the process with
@@ -49,7 +50,11 @@ class CapturedQCStep:
             raise ValueError("CapturedQCStep: the optimiser must be built with capturable=True")
 
     def _run(self, b):
-        out = self.model(b.x, b.ef, b.Esrc, b.Etgt, b.batch)
+        Etgt = b.Etgt
+        if Etgt.dim() == 1:            # per-edge target index (qc_batch.prepare): converted without a dense matrix
+            from .qc_layers import prepared_edges
+            Etgt = prepared_edges(b.Esrc, Etgt, b.x.shape[0])
+        out = self.model(b.x, b.ef, b.Esrc, Etgt, b.batch)
         loss = self.loss_fn(out[:b.target.shape[0]], b.target)
         loss.backward()
         if self.capture_optimizer:

@@ -297,6 +297,31 @@ def test_captured_qc_step_matches_eager(name):
     close(res[True][1], res[False][1], 1e-5, "parameters after the steps")
 
 
+@pytest.mark.parametrize("name", ["EdgeGCN_K_Sum", "MPNN_ENN_K_Set2Set"])
+def test_loader_prepared_batch_equals_the_dense_route(name):
+    """qc_batch.prepare: edges handed over as index vectors (no dense N x E matrix, no host synchronisation) give the
+    outputs and gradients of the reference's (Esrc, dense Etgt, batch) call."""
+    import torch.nn.functional as F
+    from graph_odenet_amd import qc_models
+    from graph_odenet_amd.qc_batch import prepare
+    from graph_odenet_amd.synth import qm9_like_batch
+    x, ef, Esrc, Etgt, batch = qm9_like_batch(9, seed=13, device=dev())
+    tgt = torch.randn(9, 12, generator=torch.Generator().manual_seed(4)).to(dev())
+    torch.manual_seed(5)
+    m = getattr(qc_models, name)(node_features=13, edge_features=5, target_features=12, hidden_features=24, num_layers=2,
+                                 s2s_processing_steps=3, dropout=0.0).to(dev())
+    out = m(x, ef, Esrc, Etgt, batch)
+    F.mse_loss(out, tgt).backward()
+    want = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    edges, b2 = prepare(Esrc, Etgt.argmax(0), batch.clone(), x.shape[0], 9)
+    out2 = m(x, ef, Esrc, edges, b2)
+    assert torch.equal(out2, out)
+    F.mse_loss(out2, tgt).backward()
+    for (nm, p), w in zip(m.named_parameters(), want):
+        close(p.grad, w, 1e-6, nm)
+
+
 def test_qc_colliding_indices_and_weighted_incidence():
     """Q5 of SURVEY.md: the reference's batches do not offset node ids, so many edges collide on the
     first nodes; Etgt is a dense float matrix whose values are used as weights."""

@@ -46,3 +46,12 @@ def test_padded_batch_gives_the_reference_formulas_the_same_outputs():
     s0 = torch.zeros(4, h).index_add_(0, batch, z0)
     s1 = torch.zeros(nb + 1, h).index_add_(0, bp, z1)
     assert (s1[:nb] - s0).abs().max() < 1e-5
+
+
+def test_pad_batch_accepts_the_target_index_vector():
+    x, ef, Esrc, Etgt, batch = qm9_like_batch(3, seed=5)
+    etgt = Etgt.argmax(0)
+    a = pad_batch(x, ef, Esrc, Etgt, batch, 32, 64)
+    b = pad_batch(x, ef, Esrc, etgt, batch, 32, 64)
+    assert b[3].dim() == 1 and b[3].numel() == a[3].shape[1]
+    assert torch.equal(a[3].argmax(0), b[3]) and torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build(dev, model_name, seed, n_batches, batch_size, bucket=False):
+def build(dev, model_name, seed, n_batches, batch_size, bucket=False, by_index=False):
     from graph_odenet_amd import qc_models
     from graph_odenet_amd.qc_batch import pad_batch
     from graph_odenet_amd.synth import qm9_like_batch
@@ -38,6 +38,8 @@ def build(dev, model_name, seed, n_batches, batch_size, bucket=False):
     batches = []
     for b in range(n_batches):
         x, ef, Esrc, Etgt, batch = qm9_like_batch(batch_size, seed=seed * 1000 + b, device=dev)
+        if by_index:          # what a loader has before it builds the dense matrix: the per-edge target index
+            Etgt = Etgt.argmax(0)
         if bucket:            # collate-time padding to the shape bucket (qc_batch.py): part of data loading, not of the step
             x, ef, Esrc, Etgt, batch, _ = pad_batch(x, ef, Esrc, Etgt, batch)
         tgt = torch.randn(batch_size, 12, generator=torch.Generator().manual_seed(seed * 1000 + b)).to(dev)
@@ -75,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--captured", action="store_true",
                     help="one HIP-graph replay per step and shape bucket (qc_step.CapturedQCStep; implies --bucket)")
+    ap.add_argument("--prepared", action="store_true",
+                    help="hand the edges over as index vectors (qc_batch.prepare: no dense Etgt, no host synchronisation)")
     ap.add_argument("--bucket", action="store_true",
                     help="pad every batch to its shape bucket (multiples of 64 atoms / 128 edges, one dummy graph)")
     args = ap.parse_args()
@@ -93,7 +97,7 @@ def main():
 
     # one distinct batch per step, as in training: the per-batch graph conversion is inside the timed region
     args.bucket = args.bucket or args.captured
-    net, batches = build(dev, args.model, rank, args.steps + args.warmup, args.batch_size, args.bucket)
+    net, batches = build(dev, args.model, rank, args.steps + args.warmup, args.batch_size, args.bucket, args.prepared)
     broadcast_parameters(net, 0)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=args.captured)
     bucket = GradBucket(net, overlap=not args.captured)
@@ -105,7 +109,11 @@ def main():
     def step(i):
         x, ef, Esrc, Etgt, batch, tgt = batches[i]
         if cstep is not None:
-            return cstep(x, ef, Esrc, Etgt, batch, tgt)
+            return cstep(x, ef, Esrc, Etgt, batch, tgt)            # index-vector batches are converted inside the graph
+        if args.prepared:
+            from graph_odenet_amd.qc_batch import prepare
+            n_graphs = tgt.shape[0] + (1 if args.bucket else 0)
+            Etgt, batch = prepare(Esrc, Etgt, batch, x.shape[0], n_graphs)          # timed: part of every step
         opt.zero_grad(set_to_none=False)
         loss = F.mse_loss(net(x, ef, Esrc, Etgt, batch)[:tgt.shape[0]], tgt)
         loss.backward()
@@ -135,8 +143,9 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * el / args.steps, 3), "scaling": "weak", "dtype": "f32",
                "data": "synthetic", "loss": round(float(loss.detach()), 5),
-               "config": {"workload": "%s h=73 T=3, %d QM9-like molecules per rank, a new batch every step (graph conversion timed)%s"
-                                      % (args.model, args.batch_size, ", padded to shape buckets" if args.bucket else ""),
+               "config": {"workload": "%s h=73 T=3, %d QM9-like molecules per rank, a new batch every step (graph conversion timed)%s%s"
+                                      % (args.model, args.batch_size, ", padded to shape buckets" if args.bucket else "",
+                                         ", edges handed over as index vectors" if args.prepared else ""),
                           "params": sum(p.numel() for p in net.parameters()),
                           "gradient_bytes_allreduced_per_step": 4 * bucket.flat.numel() if world > 1 else 0}}
         if cstep is not None:
