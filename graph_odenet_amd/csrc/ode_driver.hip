@@ -59,6 +59,27 @@ __global__ void theta_fixup_kernel(float* ktheta, const float* W, float t, int d
 
 #define GODE_TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 
+// Launch-bound graphs: the four reduction launches that close an adjoint stage (weight-gradient partials, time-row
+// bookkeeping, bias column sums, GroupNorm affine partials) as ONE launch (rk.hip: reduce_segments_kernel).  Above this
+// many rows the separate launches are kept: the weight-gradient reduction has a 16-byte form that matters there.
+constexpr int64_t kMergedFinishMaxRows = 1 << 16;
+
+// kt = [W | b | gamma | beta | a_t] from ws->wpart, colsum partials of dZ, ws->gpart / ws->bpart
+int stage_finish_merged(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws, float* kt, float ts, void* stream) {
+    const int64_t n = f->n, d = f->d, nW = (d + 1) * d, P = gode_gcn_ode_theta_len(d);
+    int64_t cparts = 0;
+    GODE_TRY(gode_colsum_parts_f32(ws->dZ, n, d, (float*)ws->colsum_scratch, &cparts, stream));
+    float* outs[4] = {kt, kt + nW, kt + nW + d, kt + nW + 2 * d};
+    const float* parts[4] = {ws->wpart, (const float*)ws->colsum_scratch, ws->gpart, ws->bpart};
+    const int64_t gp = gode_gemm_bwd_parts(n);
+    const int64_t n_parts[4] = {gode_wgrad_parts(n), cparts, gp, gp};
+    const int64_t lens[4] = {nW, d, d, d};
+    const int nseg = f->groups > 0 ? 4 : 2;
+    GODE_TRY(gode_reduce_segments_f32(nseg, outs, parts, n_parts, lens, d, ts, f->W, kt + (P - 1), stream));
+    if (f->groups <= 0) GODE_TRY(gode_zero_f32(kt + nW + d, 2 * d, stream));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int64_t gode_gcn_ode_theta_len(int64_t d) { return (d + 1) * d + 3 * d + 1; }
@@ -146,7 +167,9 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
     hipStream_t hs = (hipStream_t)stream;
     // the side stream exists only for callers that ask for the two-chain schedule (never created inside a capture:
     // odeint turns the option off around its HIP-graph captures)
-    Overlap* ov = (ws->S2 != nullptr && gode_opt_overlap()) ? overlap_ctx(hs) : nullptr;
+    // launch-bound sizes gain nothing from the second stream and close every stage with one merged reduction launch
+    const bool small = f->n <= kMergedFinishMaxRows;
+    Overlap* ov = (!small && ws->S2 != nullptr && gode_opt_overlap()) ? overlap_ctx(hs) : nullptr;
     const bool two = ov != nullptr && ov->ok;
     void* side = two ? (void*)ov->side : stream;
     float* Sbuf[2] = {ws->S, two ? ws->S2 : ws->S};
@@ -194,10 +217,13 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
         }
         // side stream, beside Gb(g) on the main stream: Wg(g), then the dense part of the NEXT stage
         float* kt = ws->ktheta[s];
+        const bool merged = small;                                    // launch-bound: one finishing launch per stage
         GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, ws->dS, d, 1, ws->wpart, side));   // Wg(g)
-        GODE_TRY(gode_reduce_parts_f32(kt, ws->wpart, wparts, nW, 1.f, 0, side));
-        hipLaunchKernelGGL(theta_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)side, kt, f->W, ts, (int)d, P - 1);
-        GODE_LAUNCH_CHECK();
+        if (!merged) {
+            GODE_TRY(gode_reduce_parts_f32(kt, ws->wpart, wparts, nW, 1.f, 0, side));
+            hipLaunchKernelGGL(theta_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)side, kt, f->W, ts, (int)d, P - 1);
+            GODE_LAUNCH_CHECK();
+        }
         if (two) { GODE_HIP(hipEventRecord(ov->wg, ov->side)); wg_pending = true; }
         if (g + 1 < total) {                                                    // Gf(g+1)
             const int i2 = (g + 1) / 4, s2 = (g + 1) % 4;
@@ -210,11 +236,15 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
         GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->W, d, 1, ws->dS,
                                            s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &apre : nullptr, ka[s],
                                            f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr, stream));   // Gb(g)
-        GODE_TRY(gode_colsum_f32(kt + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, stream));
-        if (f->groups > 0) {
-            GODE_TRY(gode_reduce_parts2_f32(kt + nW + d, ws->gpart, kt + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
+        if (merged) {
+            GODE_TRY(stage_finish_merged(f, ws, kt, ts, stream));
         } else {
-            GODE_TRY(gode_zero_f32(kt + nW + d, 2 * d, stream));
+            GODE_TRY(gode_colsum_f32(kt + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, stream));
+            if (f->groups > 0) {
+                GODE_TRY(gode_reduce_parts2_f32(kt + nW + d, ws->gpart, kt + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, stream));
+            } else {
+                GODE_TRY(gode_zero_f32(kt + nW + d, 2 * d, stream));
+            }
         }
         if (s == 3) {
             // theta <- theta + h * sum b_s ktheta_s   (packed small components, one launch)
@@ -294,6 +324,7 @@ int dp_eval_adjoint(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws,
     GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->W, d, 1, ws->dS, 1.f, nullptr, ka,
                                        f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr, stream));
     GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, ws->dS, d, 1, ws->wpart, stream));
+    if (n <= kMergedFinishMaxRows) return stage_finish_merged(f, ws, kth, t, stream);
     GODE_TRY(gode_reduce_parts_f32(kth, ws->wpart, gode_wgrad_parts(n), nW, 1.f, 0, stream));
     hipLaunchKernelGGL(theta_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kth, f->W, t, (int)d, P - 1);
     GODE_LAUNCH_CHECK();
