@@ -56,6 +56,13 @@ class Rk4Workspace(ctypes.Structure):
                 ("colsum_scratch", ctypes.c_void_p), ("X", ctypes.c_void_p * 2)]
 
 
+class ReduceSeg(ctypes.Structure):
+    """Mirror of gode_reduce_seg_t."""
+    _fields_ = [("out", ctypes.c_void_p), ("part", ctypes.c_void_p), ("n_part", ctypes.c_int64), ("ld", ctypes.c_int64),
+                ("col0", ctypes.c_int64), ("col_stride", ctypes.c_int64), ("len", ctypes.c_int64),
+                ("w_row0", ctypes.c_void_p), ("time_len", ctypes.c_int64)]
+
+
 class GatOdeFunc(ctypes.Structure):
     """Mirror of gode_gat_odefunc_t."""
     _fields_ = [("mt", Graph), ("ms_inc", Graph), ("mt_inc", Graph), ("src", ctypes.c_void_p), ("tgt", ctypes.c_void_p),
@@ -70,7 +77,7 @@ class GatWorkspace(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("X", "Ps", "Pt", "A2", "a", "amax", "wgt", "den", "logits_scratch", "dz", "da",
                                                "dPs", "dPt", "dA2", "pair", "gp", "bp")] + \
                [("wp", ctypes.c_void_p * 3), ("maxpath_scratch", ctypes.c_void_p), ("colsum_scratch", ctypes.c_void_p),
-                ("zeros", ctypes.c_void_p), ("heads_scratch", ctypes.c_void_p)]
+                ("zeros", ctypes.c_void_p), ("heads_scratch", ctypes.c_void_p), ("colsum_scratch2", ctypes.c_void_p)]
 
 
 c_i64 = ctypes.c_int64
@@ -110,6 +117,8 @@ SIGNATURES = {
                                               c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p, c_p, c_p]),
     "gode_reduce_parts_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
     "gode_reduce_parts2_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
+    "gode_reduce_segments_f32": (c_i, [ctypes.POINTER(ReduceSeg), ctypes.c_int32, c_f, c_p, c_p]),
+    "gode_colsum_parts_f32": (c_i, [c_p, c_i64, c_i64, c_p, ctypes.POINTER(c_i64), c_p]),
     "gode_colsum_scratch_bytes": (c_i64, [c_i64, c_i64]),
     "gode_colsum_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p, c_p]),
     "gode_gat_logits_scratch_bytes": (c_i64, [c_i64]),

@@ -97,11 +97,6 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // gemm.hip: raise a kernel's dynamic-LDS limit once per (device, kernel); thread-safe, a no-op up to 64 KB
 int gode_set_lds_once(const void* fn, size_t bytes);
-// rk.hip: up to four block-partial reductions (out[s][j] = sum_p parts[s][p*len+j]) in one launch; with at_out, the first
-// time_len outputs of segment 0 are scaled by t and *at_out = <their unscaled sums, w_row0> (time-row bookkeeping)
-int gode_reduce_segments_f32(int n_segs, float* const* outs, const float* const* parts, const int64_t* n_parts,
-                             const int64_t* lens, int64_t time_len, float t, const float* w_row0, float* at_out, void* stream);
-int gode_colsum_parts_f32(const float* X, int64_t n_rows, int64_t d, float* scratch, int64_t* n_parts, void* stream);
 // rk.hip: out[0..n) = 0 by a kernel (never a memset node)
 int gode_zero_f32(float* out, int64_t n, void* stream);
 

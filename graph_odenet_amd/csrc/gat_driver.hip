@@ -36,6 +36,7 @@ gode_lincomb_t dp_terms(const float* y, float* const* k, const double* coef, int
 }
 
 inline int64_t n_heads(const gode_gat_odefunc_t* f) { return f->heads > 1 ? f->heads : 1; }
+constexpr int64_t kMergedFinishMaxRows = 1 << 16;      // as graph_odenet_amd/gat_ode.py: MERGED_FINISH_MAX_ROWS
 
 // projections as the edge kernels see them: with H heads the n x (H*o) matrices ARE the (n*H) x o matrices of the
 // virtual nodes (row stride o), and A2 (n x 2H) is (n*H) x 2
@@ -119,28 +120,47 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
     }
     float* g_src = kth; float* g_tgt = kth + nW; float* g_log = kth + 2 * nW;
     float* g_bf = g_log + nL; float* g_bw = g_bf + d; float* g_gamma = g_bw + H; float* g_beta = g_gamma + d;
-    // bias gradients from the per-target node sums (every edge has exactly one target)
-    GODE_TRY(gode_colsum_f32(g_bf, w->dPt, n, d, 1.f, 0, (float*)w->colsum_scratch, stream));
-    GODE_TRY(gode_colsum_f32(w->pair, w->dA2, n, 2 * H, 1.f, 0, (float*)w->colsum_scratch, stream));
-    hipLaunchKernelGGL(odd_entries_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, (hipStream_t)stream, g_bw, (const float*)w->pair, (int)H);
-    GODE_LAUNCH_CHECK();
     const int64_t nb = gode_gemm_bwd_parts(n);
     const bool affine = f->groups > 0;
     const float* Wj[3] = {f->Wsrc, f->Wtgt, f->Wlog};
     const float* dPj[3] = {w->dPs, w->dPt, w->dA2};
     const int64_t dout[3] = {d, d, 2 * H};
+    // launch-bound graphs: ONE reduction launch closes the stage (the same launch sequence as gat_ode.py / gat_heads.py)
+    const bool merged = n <= kMergedFinishMaxRows && affine && w->colsum_scratch2 != nullptr;
+    int64_t n_a = 0, n_b = 0;
+    if (merged) {
+        GODE_TRY(gode_colsum_parts_f32(w->dPt, n, d, (float*)w->colsum_scratch, &n_a, stream));
+        GODE_TRY(gode_colsum_parts_f32(w->dA2, n, 2 * H, (float*)w->colsum_scratch2, &n_b, stream));
+    } else {
+        // bias gradients from the per-target node sums (every edge has exactly one target)
+        GODE_TRY(gode_colsum_f32(g_bf, w->dPt, n, d, 1.f, 0, (float*)w->colsum_scratch, stream));
+        GODE_TRY(gode_colsum_f32(w->pair, w->dA2, n, 2 * H, 1.f, 0, (float*)w->colsum_scratch, stream));
+        hipLaunchKernelGGL(odd_entries_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, (hipStream_t)stream, g_bw, (const float*)w->pair, (int)H);
+        GODE_LAUNCH_CHECK();
+    }
     gode_lincomb_t acc; acc.n = 1; acc.coef[0] = 1.f; acc.ptr[0] = ka;
     for (int j = 0; j < 3; ++j)
         GODE_TRY(gode_gn_time_gemm_bwd_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, Wj[j], dout[j], 1, dPj[j], 1.f,
                                            j ? &acc : nullptr, ka, affine ? w->gp + j * nb * d : nullptr,
                                            affine ? w->bp + j * nb * d : nullptr, stream));
-    if (affine) GODE_TRY(gode_reduce_parts2_f32(g_gamma, w->gp, g_beta, w->bp, 3 * nb, d, 1.f, 0, stream));
-    else GODE_TRY(gode_zero_f32(g_gamma, 2 * d, stream));
+    if (affine && !merged) GODE_TRY(gode_reduce_parts2_f32(g_gamma, w->gp, g_beta, w->bp, 3 * nb, d, 1.f, 0, stream));
+    else if (!affine) GODE_TRY(gode_zero_f32(g_gamma, 2 * d, stream));
     float* gW[3] = {g_src, g_tgt, g_log};
     const int64_t lenW[3] = {nW, nW, nL};
     const int64_t npw = gode_wgrad_parts(n);
     for (int j = 0; j < 3; ++j)
         GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, dPj[j], dout[j], 1, w->wp[j], stream));
+    if (merged) {
+        gode_reduce_seg_t sg[7] = {};
+        sg[0] = {g_src, w->wp[0], npw, nW, 0, 1, nW, f->Wsrc, d};                              // row 0 of each block: its time row
+        sg[1] = {g_tgt, w->wp[1], npw, nW, 0, 1, nW, f->Wtgt, d};
+        sg[2] = {g_log, w->wp[2], npw, nL, 0, 1, nL, f->Wlog, 2 * H};
+        sg[3] = {g_bf, (const float*)w->colsum_scratch, n_a, d, 0, 1, d, nullptr, 0};
+        sg[4] = {g_bw, (const float*)w->colsum_scratch2, n_b, 2 * H, 1, 2, H, nullptr, 0};      // odd columns of the n x 2H sums
+        sg[5] = {g_gamma, w->gp, 3 * nb, d, 0, 1, d, nullptr, 0};
+        sg[6] = {g_beta, w->bp, 3 * nb, d, 0, 1, d, nullptr, 0};
+        return gode_reduce_segments_f32(sg, 7, t, kat, stream);
+    }
     GODE_TRY(gode_reduce_parts2_f32(gW[0], w->wp[0], gW[1], w->wp[1], npw, lenW[0], 1.f, 0, stream));
     GODE_TRY(gode_reduce_parts_f32(gW[2], w->wp[2], npw, lenW[2], 1.f, 0, stream));
     // a_t' = -a^T df/dt over the three time rows; each row 0 *= t

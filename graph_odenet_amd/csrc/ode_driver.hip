@@ -69,13 +69,13 @@ int stage_finish_merged(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t*
     const int64_t n = f->n, d = f->d, nW = (d + 1) * d, P = gode_gcn_ode_theta_len(d);
     int64_t cparts = 0;
     GODE_TRY(gode_colsum_parts_f32(ws->dZ, n, d, (float*)ws->colsum_scratch, &cparts, stream));
-    float* outs[4] = {kt, kt + nW, kt + nW + d, kt + nW + 2 * d};
-    const float* parts[4] = {ws->wpart, (const float*)ws->colsum_scratch, ws->gpart, ws->bpart};
     const int64_t gp = gode_gemm_bwd_parts(n);
-    const int64_t n_parts[4] = {gode_wgrad_parts(n), cparts, gp, gp};
-    const int64_t lens[4] = {nW, d, d, d};
-    const int nseg = f->groups > 0 ? 4 : 2;
-    GODE_TRY(gode_reduce_segments_f32(nseg, outs, parts, n_parts, lens, d, ts, f->W, kt + (P - 1), stream));
+    gode_reduce_seg_t sg[4] = {};
+    sg[0] = {kt, ws->wpart, gode_wgrad_parts(n), nW, 0, 1, nW, f->W, d};                       // dW; row 0 is the time row
+    sg[1] = {kt + nW, (const float*)ws->colsum_scratch, cparts, d, 0, 1, d, nullptr, 0};           // bias: colsum(dZ)
+    sg[2] = {kt + nW + d, ws->gpart, gp, d, 0, 1, d, nullptr, 0};
+    sg[3] = {kt + nW + 2 * d, ws->bpart, gp, d, 0, 1, d, nullptr, 0};
+    GODE_TRY(gode_reduce_segments_f32(sg, f->groups > 0 ? 4 : 2, ts, kt + (P - 1), stream));
     if (f->groups <= 0) GODE_TRY(gode_zero_f32(kt + nW + d, 2 * d, stream));
     return 0;
 }

@@ -118,39 +118,47 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(float* out, const flo
     }
 }
 
-// Several block-partial reductions of one adjoint stage in ONE launch (launch-bound graphs: the four reduction launches
-// of a stage - weight gradient, bias column sums, GroupNorm affine partials, time-row bookkeeping - cost more than
-// the work).  Segment s owns blocks [blk0[s], blk0[s+1]); inside a segment the arithmetic is reduce_parts_kernel's.
-// Time row (segment 0, outputs j < time_len): out = t * sum, and the LAST block of the grid forms
-// at = sum_c (sum_p part0[p][c]) * w_row0[c] from the partials themselves, so no block waits for another.
+// Several block-partial reductions of one adjoint stage in ONE launch (launch-bound graphs: the reduction launches of
+// a stage - weight gradients, bias column sums, GroupNorm affine partials, time-row bookkeeping - cost more than the
+// work).  Segment s owns blocks [blk0[s], blk0[s+1]); inside a segment the arithmetic is reduce_parts_kernel's (8
+// part-groups, fixed order).  A segment may read a strided column subset of its partial rows (col0, col_stride).
+// Time rows (segments with w_row0): outputs j < time_len are written as t * sum, and ONE extra block forms
+// at = sum over those segments of sum_c (sum_p part[p][c]) * w_row0[c] from the partials themselves, so no block waits
+// for another.
 struct ReduceSegs {
     int n;
-    float* out[4];
-    const float* part[4];
-    int64_t n_part[4], len[4];
-    int blk0[5];
-    int64_t time_len; float t; const float* w_row0; float* at_out;
+    float* out[GODE_MAX_REDUCE_SEGS];
+    const float* part[GODE_MAX_REDUCE_SEGS];
+    int64_t n_part[GODE_MAX_REDUCE_SEGS], ld[GODE_MAX_REDUCE_SEGS], col0[GODE_MAX_REDUCE_SEGS], cstride[GODE_MAX_REDUCE_SEGS],
+            len[GODE_MAX_REDUCE_SEGS], time_len[GODE_MAX_REDUCE_SEGS];
+    const float* w_row0[GODE_MAX_REDUCE_SEGS];
+    int blk0[GODE_MAX_REDUCE_SEGS + 1];
+    int time_block;             // index of the extra block, or -1
+    float t; float* at_out;
 };
 
 __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs g) {
     __shared__ float sm[8][33];
     const int jj = threadIdx.x & 31, q = threadIdx.x >> 5;
-    if ((int)blockIdx.x == g.blk0[g.n]) {          // the time-derivative block
+    if ((int)blockIdx.x == g.time_block) {         // the time-derivative block
         float acc = 0.f;
-        for (int64_t c0 = 0; c0 < g.time_len; c0 += 32) {
-            const int64_t c = c0 + jj;
-            float s = 0.f;
-            if (c < g.time_len)
-                for (int64_t p = q; p < g.n_part[0]; p += 8) s += g.part[0][p * g.len[0] + c];
-            sm[q][jj] = s;
-            __syncthreads();
-            if (q == 0 && c < g.time_len) {
-                float t = sm[0][jj];
+        for (int s = 0; s < g.n; ++s) {
+            if (!g.w_row0[s]) continue;
+            for (int64_t c0 = 0; c0 < g.time_len[s]; c0 += 32) {
+                const int64_t c = c0 + jj;
+                float v = 0.f;
+                if (c < g.time_len[s])
+                    for (int64_t p = q; p < g.n_part[s]; p += 8) v += g.part[s][p * g.ld[s] + g.col0[s] + c * g.cstride[s]];
+                sm[q][jj] = v;
+                __syncthreads();
+                if (q == 0 && c < g.time_len[s]) {
+                    float t = sm[0][jj];
 #pragma unroll
-                for (int k = 1; k < 8; ++k) t += sm[k][jj];
-                acc = fmaf(t, g.w_row0[c], acc);
+                    for (int k = 1; k < 8; ++k) t += sm[k][jj];
+                    acc = fmaf(t, g.w_row0[s][c], acc);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         if (q == 0) {                              // lanes 0..31 of wave 0 hold the per-column products
             for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -161,17 +169,17 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs g) {
     int s = 0;
     while (s + 1 < g.n && (int)blockIdx.x >= g.blk0[s + 1]) ++s;
     const int64_t j = (int64_t)((int)blockIdx.x - g.blk0[s]) * 32 + jj;
-    const int64_t len = g.len[s], n_part = g.n_part[s];
-    const float* part = g.part[s];
+    const int64_t len = g.len[s], n_part = g.n_part[s], ld = g.ld[s];
+    const float* part = g.part[s] + g.col0[s] + j * g.cstride[s];
     float v = 0.f;
     if (j < len) {
         int64_t p = q;
         for (; p + 24 < n_part; p += 32) {
-            const float a0 = part[p * len + j], a1 = part[(p + 8) * len + j];
-            const float a2 = part[(p + 16) * len + j], a3 = part[(p + 24) * len + j];
+            const float a0 = part[p * ld], a1 = part[(p + 8) * ld];
+            const float a2 = part[(p + 16) * ld], a3 = part[(p + 24) * ld];
             v += a0; v += a1; v += a2; v += a3;
         }
-        for (; p < n_part; p += 8) v += part[p * len + j];
+        for (; p < n_part; p += 8) v += part[p * ld];
     }
     sm[q][jj] = v;
     __syncthreads();
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void reduce_segments_kernel(ReduceSegs g) {
         float t = sm[0][jj];
 #pragma unroll
         for (int k = 1; k < 8; ++k) t += sm[k][jj];
-        if (s == 0 && j < g.time_len) t *= g.t;
+        if (g.w_row0[s] && j < g.time_len[s]) t *= g.t;
         g.out[s][j] = t;
     }
 }
@@ -400,26 +408,36 @@ extern "C" int gode_reduce_parts_f32(float* out, const float* part, int64_t n_pa
     return 0;
 }
 
-int gode_reduce_segments_f32(int n_segs, float* const* outs, const float* const* parts, const int64_t* n_parts,
-                             const int64_t* lens, int64_t time_len, float t, const float* w_row0, float* at_out, void* stream) {
-    if (n_segs < 1 || n_segs > 4) return GODE_E_RANGE;
+extern "C" int gode_reduce_segments_f32(const gode_reduce_seg_t* segs, int32_t n_segs, float t, float* at, void* stream) {
+    if (!segs) return GODE_E_NULLPTR;
+    if (n_segs < 1 || n_segs > GODE_MAX_REDUCE_SEGS) return GODE_E_RANGE;
     ReduceSegs g;
     g.n = n_segs;
     int blk = 0;
-    for (int s = 0; s < 4; ++s) { g.out[s] = nullptr; g.part[s] = nullptr; g.n_part[s] = 0; g.len[s] = 0; }
-    for (int s = 0; s < n_segs; ++s) {
-        if (!outs[s] || (n_parts[s] > 0 && !parts[s])) return GODE_E_NULLPTR;
-        if (lens[s] <= 0 || n_parts[s] < 0) return GODE_E_SHAPE;
-        g.out[s] = outs[s]; g.part[s] = parts[s]; g.n_part[s] = n_parts[s]; g.len[s] = lens[s];
-        g.blk0[s] = blk;
-        blk += (int)((lens[s] + 31) / 32);
+    bool any_time = false;
+    for (int s = 0; s < GODE_MAX_REDUCE_SEGS; ++s) {
+        g.out[s] = nullptr; g.part[s] = nullptr; g.w_row0[s] = nullptr;
+        g.n_part[s] = g.ld[s] = g.col0[s] = g.len[s] = g.time_len[s] = 0; g.cstride[s] = 1;
     }
-    for (int s = n_segs; s <= 4; ++s) g.blk0[s] = blk;
-    const bool with_time = at_out != nullptr && time_len > 0;
-    if (with_time && !w_row0) return GODE_E_NULLPTR;
-    g.time_len = with_time ? time_len : 0; g.t = with_time ? t : 1.f; g.w_row0 = w_row0; g.at_out = at_out;
-    if (!with_time) g.blk0[g.n] = -1;               // no block matches: no time-derivative block
-    hipLaunchKernelGGL(reduce_segments_kernel, dim3((unsigned)(blk + (with_time ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, g);
+    for (int s = 0; s < n_segs; ++s) {
+        const gode_reduce_seg_t& q = segs[s];
+        if (!q.out || (q.n_part > 0 && !q.part)) return GODE_E_NULLPTR;
+        if (q.len <= 0 || q.n_part < 0 || q.col_stride < 1 || q.col0 < 0 || q.ld < q.col0 + (q.len - 1) * q.col_stride + 1)
+            return GODE_E_SHAPE;
+        if (q.len > (int64_t)INT32_MAX * 16) return GODE_E_RANGE;
+        g.out[s] = q.out; g.part[s] = q.part; g.n_part[s] = q.n_part; g.ld[s] = q.ld; g.col0[s] = q.col0;
+        g.cstride[s] = q.col_stride; g.len[s] = q.len;
+        if (q.w_row0 && q.time_len > 0) {
+            if (!at || q.time_len > q.len) return q.time_len > q.len ? GODE_E_SHAPE : GODE_E_NULLPTR;
+            g.w_row0[s] = q.w_row0; g.time_len[s] = q.time_len; any_time = true;
+        }
+        g.blk0[s] = blk;
+        blk += (int)((q.len + 31) / 32);
+    }
+    for (int s = n_segs; s <= GODE_MAX_REDUCE_SEGS; ++s) g.blk0[s] = blk;
+    g.time_block = any_time ? blk : -1;
+    g.t = t; g.at_out = at;
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3((unsigned)(blk + (any_time ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, g);
     GODE_LAUNCH_CHECK();
     return 0;
 }
@@ -440,7 +458,7 @@ extern "C" int64_t gode_colsum_scratch_bytes(int64_t n_rows, int64_t d) {
 }
 
 // stage 1 of gode_colsum_f32 alone: block partials into `scratch` (gode_colsum_scratch_bytes), their count in *n_parts
-int gode_colsum_parts_f32(const float* X, int64_t n_rows, int64_t d, float* scratch, int64_t* n_parts, void* stream) {
+extern "C" int gode_colsum_parts_f32(const float* X, int64_t n_rows, int64_t d, float* scratch, int64_t* n_parts, void* stream) {
     if (n_rows < 0 || d <= 0) return GODE_E_SHAPE;
     if (!scratch || !n_parts || (n_rows > 0 && !X)) return GODE_E_NULLPTR;
     if (d > INT32_MAX) return GODE_E_RANGE;

@@ -216,6 +216,7 @@ class _HeadsWork:
         self.pair = torch.empty(2 * H, **f)
         self.heads_scratch = torch.empty(max(lib.gode_gat_heads_scratch_bytes(E, H), 16), **u8)
         self.colsum_scratch = torch.empty(max(lib.gode_colsum_scratch_bytes(n, d), 16), **u8)
+        self.colsum_scratch2 = torch.empty(max(lib.gode_colsum_scratch_bytes(n, 2 * H), 16), **u8)
         self.err_scratch = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), **u8)
         if spec.pad_logits:
             self.A2pad, self.dA2pad = torch.empty(n, d, **f), torch.zeros(n, d, **f)     # columns >= 2H of dA2pad stay 0
@@ -264,7 +265,7 @@ class GatHeadsField(GatOdeField):
             setattr(ws, k, p(getattr(w, k)))
         ws.amax, ws.logits_scratch = p(w.zero), p(w.heads_scratch)          # unused by the heads sequence, must be set
         if adjoint:
-            for k in ("dz", "da", "dPs", "dPt", "dA2", "pair", "gp", "bp", "colsum_scratch"):
+            for k in ("dz", "da", "dPs", "dPt", "dA2", "pair", "gp", "bp", "colsum_scratch", "colsum_scratch2"):
                 setattr(ws, k, p(getattr(w, k)))
             for j in range(3):
                 ws.wp[j] = w.wp[j].data_ptr()
@@ -328,9 +329,15 @@ class GatHeadsAdjointField(GatHeadsField):
         g = s.views(out[3])
         ops.gat_vjp(eg, w.proj, o, w.bf0, w.a, w.zero, w.wgt, w.den, out[0].view(nv, o), w.dz, w.da, w.dPs.view(nv, o),
                     w.dPt.view(nv, o), w.dA2.view(nv, 2), cot_terms=terms[1], cot_scale=-1.0, heads=H)
-        ops.colsum_(g["bf"], w.dPt)                      # biases sit on the target side: column sums of its gradient
-        ops.colsum_(w.ba_grad, w.dA2)
-        g["bw"].copy_(w.ba_grad[1::2])
+        from .gat_ode import MERGED_FINISH_MAX_ROWS
+        merged = n <= MERGED_FINISH_MAX_ROWS and s.groups > 0 and not s.pad_logits      # one reduction launch per stage
+        if merged:
+            n_a = ops.colsum_parts(w.dPt, w.colsum_scratch)
+            n_b = ops.colsum_parts(w.dA2, w.colsum_scratch2)
+        else:
+            ops.colsum_(g["bf"], w.dPt)                  # biases sit on the target side: column sums of its gradient
+            ops.colsum_(w.ba_grad, w.dA2)
+            g["bw"].copy_(w.ba_grad[1::2])
         nb = w.np_b
         affine = s.groups > 0
         Wl, dAl = s.Wlog, w.dA2
@@ -341,12 +348,23 @@ class GatHeadsAdjointField(GatHeadsField):
             ops.gn_time_gemm_bwd(xt, n, d, s.groups, s.eps_gn, s.gamma, Wj, True, dPj, out=out[1],
                                  pre_terms=[(1.0, out[1])] if j else None,
                                  parts=(w.gp[j * nb:(j + 1) * nb], w.bp[j * nb:(j + 1) * nb]) if affine else None)
-        if affine:
+        if affine and not merged:
             ops.reduce_parts2_(g["gamma"], w.gp, g["beta"], w.bp)
-        else:
+        elif not affine:
             g["gamma"].zero_(); g["beta"].zero_()
         for j, dPj in enumerate((w.dPs, w.dPt, dAl)):
             ops.wgrad(xt, n, d, s.groups, s.eps_gn, s.gamma, s.beta, dPj, True, part=w.wp[j])
+        if merged:
+            i, npw = s.i, w.wp[0].shape[0]
+            ops.reduce_segments_([
+                (g["Wsrc"], w.wp[0], npw, i * d, 0, 1, i * d, s.Wsrc[0], d),          # row 0 of each block = its time row
+                (g["Wtgt"], w.wp[1], npw, i * d, 0, 1, i * d, s.Wtgt[0], d),
+                (g["Wlog"], w.wp[2], npw, i * 2 * H, 0, 1, i * 2 * H, s.Wlog[0], 2 * H),
+                (g["bf"], w.colsum_scratch, n_a, d, 0, 1, d, None, 0),
+                (g["bw"], w.colsum_scratch2, n_b, 2 * H, 1, 2, H, None, 0),           # the odd columns of the n x 2H sums
+                (g["gamma"], w.gp, 3 * nb, d, 0, 1, d, None, 0),
+                (g["beta"], w.bp, 3 * nb, d, 0, 1, d, None, 0)], t, out[2])
+            return
         ops.reduce_parts2_(g["Wsrc"].view(-1), w.wp[0], g["Wtgt"].view(-1), w.wp[1])
         if s.pad_logits:
             ops.reduce_parts_(w.gWlog_pad.view(-1), w.wp[2])

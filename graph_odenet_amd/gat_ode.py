@@ -28,6 +28,11 @@ from .gat_layers import edge_graph
 from .solver import Field
 
 
+# launch-bound graphs: the reduction launches that close an adjoint stage run as one (ops.reduce_segments_); larger graphs
+# keep the separate launches (the weight-gradient reduction has a 16-byte form that matters there)
+MERGED_FINISH_MAX_ROWS = 1 << 16
+
+
 class GatOdeSpec:
     def __init__(self, eg, layer, norm):
         self.eg, self.layer, self.norm = eg, layer, norm
@@ -94,6 +99,7 @@ class _Work:
         u8 = dict(dtype=torch.uint8, device=device)
         self.logits_scratch = torch.empty(max(lib.gode_gat_logits_scratch_bytes(E), 16), **u8)
         self.colsum_scratch = torch.empty(max(lib.gode_colsum_scratch_bytes(n, o), 16), **u8)
+        self.colsum_scratch2 = torch.empty(max(lib.gode_colsum_scratch_bytes(n, 2), 16), **u8)
         self.err_scratch = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), **u8)
 
 
@@ -132,7 +138,7 @@ class GatOdeField(Field):
         for k in ("X", "Ps", "Pt", "A2", "a", "amax", "wgt", "den", "logits_scratch"):
             setattr(ws, k, p(getattr(w, k)))
         if adjoint:
-            for k in ("dz", "da", "dPs", "dPt", "dA2", "pair", "gp", "bp", "colsum_scratch"):
+            for k in ("dz", "da", "dPs", "dPt", "dA2", "pair", "gp", "bp", "colsum_scratch", "colsum_scratch2"):
                 setattr(ws, k, p(getattr(w, k)))
             for j in range(3):
                 ws.wp[j] = w.wp[j].data_ptr()
@@ -217,20 +223,36 @@ class GatOdeAdjointField(GatOdeField):
                     cot_terms=terms[1], cot_scale=-1.0)
         # bias gradients: sum over edges of dz / da = sum over nodes of the per-target sums just formed (every edge has
         # exactly one target) - N rows instead of E
-        ops.colsum_(g["bf"], w.dPt)
-        ops.colsum_(g["bw"], w.dA2[:, 1:2].contiguous())
+        merged = n <= MERGED_FINISH_MAX_ROWS and s.groups > 0        # launch-bound: ONE reduction launch closes the stage
+        if merged:
+            n_a = ops.colsum_parts(w.dPt, w.colsum_scratch)
+            n_b = ops.colsum_parts(w.dA2, w.colsum_scratch2)
+        else:
+            ops.colsum_(g["bf"], w.dPt)
+            ops.colsum_(g["bw"], w.dA2[:, 1:2].contiguous())
         nb = w.np_b
         affine = s.groups > 0
         for j, (Wj, dPj) in enumerate(((s.Wsrc, w.dPs), (s.Wtgt, w.dPt), (s.Wlog, w.dA2))):
             ops.gn_time_gemm_bwd(xt, n, o, s.groups, s.eps_gn, s.gamma, Wj, True, dPj, out=out[1],
                                  pre_terms=[(1.0, out[1])] if j else None,
                                  parts=(w.gp[j * nb:(j + 1) * nb], w.bp[j * nb:(j + 1) * nb]) if affine else None)
-        if affine:
+        if affine and not merged:
             ops.reduce_parts2_(g["gamma"], w.gp, g["beta"], w.bp)
-        else:
+        elif not affine:
             g["gamma"].zero_(); g["beta"].zero_()
         for j, dPj in enumerate((w.dPs, w.dPt, w.dA2)):
             ops.wgrad(xt, n, o, s.groups, s.eps_gn, s.gamma, s.beta, dPj, True, part=w.wp[j])
+        if merged:
+            i, npw = s.i, w.wp[0].shape[0]
+            ops.reduce_segments_([
+                (g["Wsrc"], w.wp[0], npw, i * o, 0, 1, i * o, s.Wsrc[0], o),          # row 0 of each block = its time row
+                (g["Wtgt"], w.wp[1], npw, i * o, 0, 1, i * o, s.Wtgt[0], o),
+                (g["Wlog"], w.wp[2], npw, i * 2, 0, 1, i * 2, s.Wlog[0], 2),
+                (g["bf"], w.colsum_scratch, n_a, o, 0, 1, o, None, 0),
+                (g["bw"], w.colsum_scratch2, n_b, 2, 1, 2, 1, None, 0),               # column 1 of the n x 2 sums
+                (g["gamma"], w.gp, 3 * nb, o, 0, 1, o, None, 0),
+                (g["beta"], w.bp, 3 * nb, o, 0, 1, o, None, 0)], t, out[2])
+            return
         ops.reduce_parts2_(g["Wsrc"].view(-1), w.wp[0], g["Wtgt"].view(-1), w.wp[1])
         ops.reduce_parts_(g["Wlog"].view(-1), w.wp[2])
         # a_t' = -a^T df/dt over the three time rows; each row 0 *= t

@@ -304,6 +304,36 @@ def reduce_parts2_(out_a, part_a, out_b, part_b):
                                      stream_ptr()), "gode_reduce_parts2_f32")
 
 
+def colsum_parts(X, scratch):
+    """First half of colsum_: block partials of X.sum(0) into `scratch` (uint8, gode_colsum_scratch_bytes); returns the
+    number of partial rows (each X.shape[1] floats), to be closed by a segment of reduce_segments_."""
+    lib = _lib.load()
+    _need(X, "X")
+    n, d = X.shape
+    if scratch.numel() < lib.gode_colsum_scratch_bytes(n, d):
+        raise ValueError("colsum_parts: scratch too small")
+    npart = ctypes.c_int64(0)
+    check(lib.gode_colsum_parts_f32(ptr(X), n, d, ptr(scratch), ctypes.byref(npart), stream_ptr()), "gode_colsum_parts_f32")
+    return int(npart.value)
+
+
+def reduce_segments_(segs, t=0.0, at=None):
+    """Several block-partial reductions in one launch.  segs: tuples (out, part_tensor_or_ptr, n_part, ld, col0, col_stride,
+    length, w_row0 or None, time_len); see gode_reduce_segments_f32."""
+    lib = _lib.load()
+    arr = (_lib.ReduceSeg * len(segs))()
+    for k, (out, part, n_part, ld, col0, cs, length, w0, tl) in enumerate(segs):
+        _need(out, "out"); _need(w0, "w_row0")
+        if out.numel() < length:
+            raise ValueError("reduce_segments: output %d too short" % k)
+        q = arr[k]
+        q.out, q.part = out.data_ptr(), (part.data_ptr() if torch.is_tensor(part) else int(part))
+        q.n_part, q.ld, q.col0, q.col_stride, q.len = int(n_part), int(ld), int(col0), int(cs), int(length)
+        q.w_row0, q.time_len = (w0.data_ptr() if w0 is not None else None), int(tl)
+    _need(at, "at")
+    check(lib.gode_reduce_segments_f32(arr, len(segs), float(t), ptr(at), stream_ptr()), "gode_reduce_segments_f32")
+
+
 def colsum_(out, X, scale=1.0, accumulate=False):
     """out (+)= scale * X.sum(0)."""
     lib = _lib.load()

@@ -151,6 +151,22 @@ int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin /* host */, int64_t n_ro
                               const gode_lincomb_t* pre /* host, nullable */, float* dx,
                               float* dgamma_part, float* dbeta_part, void* stream);
 
+/* Several block-partial reductions in ONE launch (what closes an adjoint stage on launch-bound graphs: weight-gradient
+ * partials, bias column sums, GroupNorm affine partials, time-row bookkeeping).  Segment s:
+ *   out[j] = sum_p part[p*ld + col0 + j*col_stride]   for j < len  (fixed summation order: deterministic);
+ * with w_row0 (time row): outputs j < time_len are written as t * sum and
+ *   *at = sum over the time-row segments of sum_j<time_len (their unscaled sums)[j] * w_row0[j]   (= -a^T df/dt).
+ * gode_colsum_parts_f32 is the first half of gode_colsum_f32: block partials of the column sums into `scratch`
+ * (*n_parts rows of d floats), to be closed by a segment here. */
+#define GODE_MAX_REDUCE_SEGS 8
+typedef struct gode_reduce_seg {
+    float* out; const float* part;
+    int64_t n_part, ld, col0, col_stride, len;
+    const float* w_row0; int64_t time_len;      /* w_row0 NULL: plain segment */
+} gode_reduce_seg_t;
+int gode_reduce_segments_f32(const gode_reduce_seg_t* segs, int32_t n_segs, float t, float* at /* nullable */, void* stream);
+int gode_colsum_parts_f32(const float* X, int64_t n_rows, int64_t d, float* scratch, int64_t* n_parts /* host */, void* stream);
+
 /* Stand-alone GroupNorm(groups, d) on an n_rows x d matrix (the reference applies nn.GroupNorm to 2-D
  * node-feature tensors: GCN/models.py:88,133-156,565-575) and its backward; block partials of dgamma /
  * dbeta have gode_group_norm_parts(n_rows) rows. */
@@ -392,6 +408,9 @@ typedef struct gode_gat_workspace {
     /* heads > 1 only: A2 / dA2 are n x 2H; pair holds 2H floats; zeros (max(o, 1) floats, all 0, read-only);
      * heads_scratch >= gode_gat_heads_scratch_bytes(n_edges, heads) */
     const float* zeros; void* heads_scratch;
+    /* second column-sum scratch (gode_colsum_scratch_bytes(n, 2 * max(heads, 1))): with it, and up to 65 536 rows, the
+     * reductions that close an adjoint stage run as one launch (gode_reduce_segments_f32); NULL: separate launches */
+    void* colsum_scratch2;
 } gode_gat_workspace_t;
 
 int64_t gode_gat_ode_theta_len(int64_t d);

@@ -208,6 +208,36 @@ def test_gn_time_gemm_fwd_bwd_wgrad(d, groups, n):
     close(gW[0] * t, W.grad[0], tol=2e-5 * max(1, n ** 0.5), what="dW time row")
 
 
+def test_reduce_segments_one_launch():
+    """gode_reduce_segments_f32: several block-partial reductions, a strided column subset, two time rows (scaled by t,
+    their unscaled sums dotted with the weight rows into `at`) and gode_colsum_parts_f32 as a segment source."""
+    from graph_odenet_amd import _lib, ops
+    lib = _lib.load()
+    D = dev()
+    g = torch.Generator().manual_seed(17)
+    pa, pb, pc = torch.randn(37, 300, generator=g), torch.randn(5, 64, generator=g), torch.randn(130, 24, generator=g)
+    wa, wc = torch.randn(40, generator=g), torch.randn(7, generator=g)
+    X = torch.randn(1234, 16, generator=g)
+    outs = [torch.full((k,), 9.0, device=D) for k in (300, 64, 12, 16)]
+    at = torch.zeros(1, device=D)
+    scratch = torch.empty(lib.gode_colsum_scratch_bytes(1234, 16), dtype=torch.uint8, device=D)
+    n_x = ops.colsum_parts(X.to(D), scratch)
+    t = 0.37
+    ops.reduce_segments_([
+        (outs[0], pa.to(D), 37, 300, 0, 1, 300, wa.to(D), 40),
+        (outs[1], pb.to(D), 5, 64, 0, 1, 64, None, 0),
+        (outs[2], pc.to(D), 130, 24, 1, 2, 12, wc.to(D), 7),          # the odd columns of a 24-wide partial
+        (outs[3], scratch, n_x, 16, 0, 1, 16, None, 0)], t, at)
+    sa, sc = pa.double().sum(0), pc.double().sum(0)[1::2]
+    ea = sa.clone(); ea[:40] *= t
+    ec = sc.clone(); ec[:7] *= t
+    close(outs[0], ea, 1e-5, "segment with a time row")
+    close(outs[1], pb.double().sum(0), 1e-5, "plain segment")
+    close(outs[2], ec, 1e-5, "strided segment with a time row")
+    close(outs[3], X.double().sum(0), 1e-5 * 35, "column sums closed by a segment")
+    close(at, ((sa[:40] * wa.double()).sum() + (sc[:7] * wc.double()).sum()).reshape(1), 1e-5 * 10, "time derivative")
+
+
 @pytest.mark.parametrize("d,groups", [(16, 16), (32, 32), (64, 32), (128, 32), (128, 0), (64, 0)])
 @pytest.mark.parametrize("n", [1, 15, 257, 4100, 70001])
 def test_fused_vjp_and_weight_gradient(d, groups, n):
