@@ -558,6 +558,18 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                     dgs[tt].x += dy.x * xh.x; dgs[tt].y += dy.y * xh.y; dgs[tt].z += dy.z * xh.z; dgs[tt].w += dy.w * xh.w;
                     dbs[tt].x += dy.x; dbs[tt].y += dy.y; dbs[tt].z += dy.z; dbs[tt].w += dy.w;
                 }
+                if (CG == 4) {
+                    // four channels per group (the group is this lane's float4): the normalised form
+                    // dx = rstd * (dh - mean(dh) - xh * mean(dh * xh)) - a third fewer vector instructions than
+                    // ATen's algebraic form below, which is kept for the ill-conditioned 1- and 2-channel groups
+                    //  where its rounding is the reference's.  The fp32 matrix instruction shares
+                    // the vector pipe on gfx950, so these instructions are paid in full.
+                    const float m1 = ((dh.x + dh.y) + (dh.z + dh.w)) * 0.25f;
+                    const float m2 = ((dh.x * xh.x + dh.y * xh.y) + (dh.z * xh.z + dh.w * xh.w)) * 0.25f;
+                    const float rs = rstd.x;
+                    out = make_float4(rs * (dh.x - m1 - xh.x * m2), rs * (dh.y - m1 - xh.y * m2),
+                                      rs * (dh.z - m1 - xh.z * m2), rs * (dh.w - m1 - xh.w * m2));
+                } else {
                 // ATen's CPU form (group_norm_kernel.cpp, GroupNormBackward): with ds = sum dy*gamma*x and
                 // db = sum dy*gamma over the group,  c2 = (db*mean - ds)*rstd^3/CG,  c3 = -c2*mean - db*rstd/CG,
                 // dx = rstd*gamma*dy + c2*x + c3.  Same algebra as rstd*(dh - mean(dh) - xh*mean(dh*xh));
@@ -584,6 +596,7 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
                                               -c2.z * mean.z - db.z * rstd.z * sc, -c2.w * mean.w - db.w * rstd.w * sc);
                 out = make_float4(rstd.x * gm.x * dy.x + c2.x * x.x + c3.x, rstd.y * gm.y * dy.y + c2.y * x.y + c3.y,
                                   rstd.z * gm.z * dy.z + c2.z * x.z + c3.z, rstd.w * gm.w * dy.w + c2.w * x.w + c3.w);
+                }
             }
             if (valid) {
                 float4 o = make_float4(out_scale * out.x, out_scale * out.y, out_scale * out.z, out_scale * out.w);
