@@ -17,7 +17,7 @@
 namespace {
 
 constexpr int RB = 8;            // rows per block
-constexpr int WCHUNK = 256;      // rows per weight-gradient partial
+constexpr int WCHUNK = 64;       // rows per weight-gradient partial
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
@@ -47,12 +47,32 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
         for (int rr = 0; rr < RB; ++rr) { ai[rr] = bi; ah[rr] = bh; }
         const float* wi = w_ih + (int64_t)j * h2;
         const float* wh = w_hh + (int64_t)j * h;
-        for (int k = 0; k < h2; ++k) {
+        int k = 0;
+        for (; k + 8 <= h2; k += 8) {                   // 8 weight loads in flight
+            float w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8[u] = wi[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) ai[rr] = fmaf(w8[u], xm[rr * h2 + k + u], ai[rr]);
+        }
+        for (; k < h2; ++k) {
             const float w = wi[k];
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) ai[rr] = fmaf(w, xm[rr * h2 + k], ai[rr]);
         }
-        for (int k = 0; k < h; ++k) {
+        k = 0;
+        for (; k + 8 <= h; k += 8) {
+            float w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8[u] = wh[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) ah[rr] = fmaf(w8[u], xm[rr * h2 + k + u], ah[rr]);
+        }
+        for (; k < h; ++k) {
             const float w = wh[k];
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) ah[rr] = fmaf(w, xm[rr * h2 + k], ah[rr]);
@@ -121,13 +141,34 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         float a[RB];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) a[rr] = k < h ? dxd[rr * h + k] : 0.f;
-        for (int j = 0; j < h3; ++j) {
+        // 16 weight loads in flight per thread: the loop is a chain of L2 round trips otherwise (87 us at N = 450)
+        int j = 0;
+        for (; j + 16 <= h3; j += 16) {
+            float w16[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w16[u] = w_ih[(int64_t)(j + u) * h2 + k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgi[rr * h3 + j + u], w16[u], a[rr]);
+        }
+        for (; j < h3; ++j) {
             const float w = w_ih[(int64_t)j * h2 + k];
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgi[rr * h3 + j], w, a[rr]);
         }
         if (k < h) {
-            for (int j = 0; j < h3; ++j) {
+            j = 0;
+            for (; j + 16 <= h3; j += 16) {
+                float w16[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w16[u] = w_hh[(int64_t)(j + u) * h + k];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgh[rr * h3 + j + u], w16[u], a[rr]);
+            }
+            for (; j < h3; ++j) {
                 const float w = w_hh[(int64_t)j * h + k];
 #pragma unroll
                 for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgh[rr * h3 + j], w, a[rr]);
@@ -154,18 +195,31 @@ __global__ __launch_bounds__(256) void gru_wgrad_kernel(const float* __restrict_
     const int r0 = blockIdx.y * WCHUNK;
     const int r1 = min(n, r0 + WCHUNK);
     float* out = part + ((int64_t)blockIdx.y * h3 + j) * ld;
+    // the chunk's gate derivatives of gate row j, once per block (every thread multiplies the same values)
+    __shared__ float gi_s[WCHUNK], gh_s[WCHUNK];
+    for (int q = threadIdx.x; q < r1 - r0; q += 256) {
+        gi_s[q] = dgi[(int64_t)(r0 + q) * h3 + j];
+        gh_s[q] = dgh[(int64_t)(r0 + q) * h3 + j];
+    }
+    __syncthreads();
+    const int nr = r1 - r0;
     for (int k = threadIdx.x; k < ld; k += 256) {
         float acc = 0.f;
-        if (k < h) {
-            for (int row = r0; row < r1; ++row) acc = fmaf(dgi[(int64_t)row * h3 + j], x[(int64_t)row * h + k], acc);
-        } else if (k < h2) {
-            for (int row = r0; row < r1; ++row) acc = fmaf(dgi[(int64_t)row * h3 + j], m[(int64_t)row * h + (k - h)], acc);
-        } else if (k < h3) {
-            for (int row = r0; row < r1; ++row) acc = fmaf(dgh[(int64_t)row * h3 + j], x[(int64_t)row * h + (k - h2)], acc);
-        } else if (k == h3) {
-            for (int row = r0; row < r1; ++row) acc += dgi[(int64_t)row * h3 + j];
+        if (k < h3) {
+            const float* src = k < h ? x + k : (k < h2 ? m + (k - h) : x + (k - h2));
+            const float* gs = k < h2 ? gi_s : gh_s;
+            int q = 0;
+            for (; q + 8 <= nr; q += 8) {               // 8 loads in flight; rows added in order (deterministic)
+                float v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v8[u] = src[(int64_t)(r0 + q + u) * h];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fmaf(gs[q + u], v8[u], acc);
+            }
+            for (; q < nr; ++q) acc = fmaf(gs[q], src[(int64_t)(r0 + q) * h], acc);
         } else {
-            for (int row = r0; row < r1; ++row) acc += dgh[(int64_t)row * h3 + j];
+            const float* gs = k == h3 ? gi_s : gh_s;
+            for (int q = 0; q < nr; ++q) acc += gs[q];
         }
         out[k] = acc;
     }
