@@ -271,6 +271,31 @@ def main():
     extras = None
     if world == 1 and not args.no_secondary:
         extras = secondary(args, model, x, g, step, barrier)
+        # the dense kernels ALONE: one more step with the two-stream adjoint schedule off (outside the timed region), so
+        # that roofline_dense can be read both ways - as scheduled (above) and per kernel
+        if dense is not None and lib.gode_get_option(b"overlap") == 1:
+            cap2 = 8 * 4 * args.ode_steps + 96
+            prof2 = lib.gode_prof_create(cap2)
+            lib.gode_set_option(b"overlap", 0)
+            try:
+                lib.gode_prof_enable(prof2)
+                step()
+                barrier()
+                lib.gode_prof_enable(None)
+                ms2, dd2, rr2 = (ctypes.c_float * cap2)(), (ctypes.c_int64 * cap2)(), (ctypes.c_int64 * cap2)()
+                kk2 = (ctypes.c_int32 * cap2)()
+                c2 = lib.gode_prof_read(prof2, ms2, dd2, rr2, None, cap2)
+                lib.gode_prof_kinds(prof2, kk2, cap2)
+                alone = {}
+                for kind, nm in names.items():
+                    ix = [i for i in range(max(c2, 0)) if kk2[i] == kind and dd2[i] == args.hidden and rr2[i] == n]
+                    if ix:
+                        avg = sum(ms2[i] for i in ix) / len(ix)
+                        alone[nm] = {"avg_launch_ms": round(avg, 4), "frac": round(flop / (avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+                dense["alone_single_stream"] = alone
+            finally:
+                lib.gode_set_option(b"overlap", 1)
+                lib.gode_prof_destroy(prof2)
         if not args.no_configs:
             # the other BASELINE.json configurations (parity-test cases), timed on this box: tools/config_bench.py
             try:
