@@ -54,3 +54,18 @@ def test_library_sources_launch_no_memset():
         code = re.sub(r"/\*.*?\*/", "", code, flags=re.S)
         for call in ("hipMemsetAsync", "hipMemset(", "hipMemsetD32", "hipMemset2D"):
             assert call not in code, "%s calls %s" % (name, call)
+
+
+def test_header_is_plain_c99():
+    """The boundary is a C ABI: include/graphode.h must compile as C (no C++-isms, no torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc in this environment")
+    hdr = os.path.join(ROOT, "include", "graphode.h")
+    res = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)        # comments may cite torch call sites
+    assert "torch" not in code.lower() and "at::" not in code and "std::" not in code
