@@ -27,8 +27,10 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMaxBlocks = 512;   // 2 blocks per CU
+constexpr int64_t kWgradSplitMinRows = 65536;   // below: the fp32-MFMA weight-gradient kernel (2 blocks per CU, 32 KB of LDS each)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -373,7 +375,6 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_
 // v_mfma_f32_16x16x32_bf16 - 16 cycles per instruction at 8x the K depth: 192 MFMAs x 16 cycles per 16-row tile
 // instead of 256 x 32.  Parity is the same 1e-5 bar (tests/test_gpu_kernels.py runs both variants).
 // ---------------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
     const __bf16 h = (__bf16)x;                               // v_cvt_pk_bf16_f32, round to nearest even
@@ -750,6 +751,208 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(LinComb xin, int n_rows, 
             out[threadIdx.x] = s;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores with fp32-exact operands (d = 128).
+//
+// Measured on gfx950 (tools/dev/mfma_mem2.hip, profiles/r02_mfma_mem.txt): v_mfma_f32_16x16x4_f32 does not overlap
+// with ANYTHING another wave of the SIMD does - VALU work, global loads, stores, loads into LDS all take the SUM of the
+// two times - whereas v_mfma_f32_16x16x32_bf16 overlaps with all of them.  The exact-fp32 kernel above therefore pays
+// matrix time + memory time + GroupNorm time in series (0.43 ms alone, 0.96 ms next to the SpMM stream).
+//
+// Here every fp32 operand is cut EXACTLY into three bf16 pieces by truncation (x = hi + mid + lo: 8 + 8 + 8 significant
+// bits, every piece representable, no rounding anywhere) and a product x*g is accumulated in fp32 from the piece
+// products in increasing order of magnitude.  NT = 8 keeps every product down to 2^-24 of x*g (what is dropped,
+// lo*lo, is below 2^-32 of it: closer to the exact product than an fp32 FMA chain gets); NT = 6 also drops mid*lo
+// and lo*mid (<= 2^-23 of the product).
+//
+// LDS holds the six piece arrays TRANSPOSED, as 16-byte chunks = 8 consecutive rows of one column (the 8 k-values one
+// lane feeds to a 16x16x32 MFMA): chunk(piece, g, c) at ((piece*4 + g)*144 + (c&3)*36 + (c>>2)) - the staging threads
+// (4 rows x 4 columns each) write 8-byte halves at consecutive chunks, the operand reads of 16 lanes cover all 64 banks.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void split3_trunc(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);            // exact: the low 16 bits of x's significand
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));       // exact, at most 8 significant bits: its low half is zero
+}
+// the bf16 halves (upper 16 bits) of four fp32 words -> 8 bytes
+__device__ __forceinline__ uint2 pack_hi16x4(unsigned u0, unsigned u1, unsigned u2, unsigned u3) {
+    return make_uint2(__builtin_amdgcn_perm(u1, u0, 0x07060302u), __builtin_amdgcn_perm(u3, u2, 0x07060302u));
+}
+// one column of a staging thread: its 4 consecutive rows -> the three piece arrays
+__device__ __forceinline__ void stage_col4(char* chunk0 /* piece 0 */, int piece_bytes, float v0, float v1, float v2, float v3) {
+    unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+    split3_trunc(v0, h0, m0, l0); split3_trunc(v1, h1, m1, l1); split3_trunc(v2, h2, m2, l2); split3_trunc(v3, h3, m3, l3);
+    *reinterpret_cast<uint2*>(chunk0) = pack_hi16x4(h0, h1, h2, h3);
+    *reinterpret_cast<uint2*>(chunk0 + piece_bytes) = pack_hi16x4(m0, m1, m2, m3);
+    *reinterpret_cast<uint2*>(chunk0 + 2 * piece_bytes) = pack_hi16x4(l0, l1, l2, l3);
+}
+
+// Wave-specialised, 16 waves per block (one block per CU): waves 0-7 CONSUME (operand reads + MFMAs, 4 x 2 output
+// tiles each) while waves 8-11 and 12-15 PRODUCE alternate tiles (global loads, GroupNorm, the three-way cut, LDS
+// writes) on two LDS buffers, one block barrier per tile.  A producer group requests its next tile as soon as it has
+// staged one, so that request is in flight for two tile periods while the OTHER group stages: two tiles (64 KB) per CU
+// are always on their way, held by different waves.  (Two tiles in flight in ONE wave's registers do not work: hipcc
+// takes the wait count at the loop head as the minimum over all paths and ends up draining the tile just requested;
+// the same happens behind a run-time switch on the term count, hence the template parameter NX.)
+// Block barrier that orders LDS traffic only: __syncthreads() also drains the wave's outstanding GLOBAL loads
+// (s_waitcnt vmcnt(0)), which would turn every barrier into a wait for the tile being prefetched.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CG, int NT, int NX>   // NX = number of terms of x held raw in the prefetch registers (1..4); 0 = any count, combined at load
+__global__ __launch_bounds__(1024, 1) void wgrad_split_kernel(LinComb xin, int n_rows, float eps,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ dS, int has_time,
+                                                             float* __restrict__ dW_part)
+{
+    constexpr int D = 128, NJ = 8, R = 32, NP = 4;
+    constexpr int QS = 36, GRP = 4 * QS, PIECE = 4 * GRP;          // in 16-byte chunks
+    constexpr int PIECE_B = PIECE * 16, BUF_B = 6 * PIECE_B;       // one buffer: X pieces, then dS pieces
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    const bool producer = threadIdx.x >= 512;
+    const int n_tiles = (n_rows + R - 1) / R;
+    const int stride = gridDim.x;
+    const int my_tiles = blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / stride + 1 : 0;   // tiles blockIdx.x + k*stride
+    float* out = dW_part + (int64_t)blockIdx.x * (D + has_time) * D;
+
+    if (producer) {
+        const int grp = (threadIdx.x - 512) >> 8;                  // this group stages the block's tiles k = grp, grp+2, ...
+        const int pt = (threadIdx.x - 512) & 255;
+        const int trow = pt >> 5, tc4 = pt & 31, tcol = 4 * tc4;   // rows 4*trow + p, columns tcol..tcol+3
+        const int st_off = ((trow >> 1) * GRP + tc4) * 16 + (trow & 1) * 8;
+        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gmv = gamma ? ld4(gamma + tcol) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 btv = beta ? ld4(beta + tcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int NXR = NX > 0 ? NX : 1;
+        float4 xr[NXR][NP], gr[NP];
+        // Unconditional loads from clamped rows (a load under a branch would be waited for at the join; rows past the
+        // end and tiles past the block's last one are discarded when the tile is staged).
+        auto prefetch = [&](int k) {
+            const int tile = blockIdx.x + (k < my_tiles ? k : (my_tiles > 0 ? my_tiles - 1 : 0)) * stride;
+            int64_t off[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int row = tile * R + 4 * trow + p;
+                off[p] = (int64_t)(row < n_rows ? row : n_rows - 1) * D + tcol;
+                gr[p] = ld4(dS + off[p]);
+            }
+            if (NX > 0) {
+#pragma unroll
+                for (int j = 0; j < NXR; ++j)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) xr[j][p] = ld4(xin.ptr[j] + off[p]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) xr[0][p] = lc_load4(xin, off[p]);
+            }
+        };
+        auto stage = [&](int k) {                                  // tile k of this block -> buffer k & 1
+            char* Xp = lds + (k & 1) * BUF_B;
+            char* Gp = Xp + 3 * PIECE_B;
+            const int tile = blockIdx.x + k * stride;
+            float4 xn[NP], gn[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const bool valid = tile * R + 4 * trow + p < n_rows;
+                float4 x = xr[0][p];
+                if (NX > 0) {                                   // the term order and arithmetic of lc_load4_n
+                    x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < NXR; ++j) {
+                        const float c = xin.coef[j];
+                        x.x = fmaf(c, xr[j][p].x, x.x); x.y = fmaf(c, xr[j][p].y, x.y);
+                        x.z = fmaf(c, xr[j][p].z, x.z); x.w = fmaf(c, xr[j][p].w, x.w);
+                    }
+                }
+                xn[p] = gn_forward_v<CG>(x, eps, gmv, btv);
+                gn[p] = gr[p];
+                if (!valid) { xn[p] = make_float4(0.f, 0.f, 0.f, 0.f); gn[p] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                csum.x += gn[p].x; csum.y += gn[p].y; csum.z += gn[p].z; csum.w += gn[p].w;
+            }
+            stage_col4(Xp + st_off + 0 * QS * 16, PIECE_B, xn[0].x, xn[1].x, xn[2].x, xn[3].x);
+            stage_col4(Xp + st_off + 1 * QS * 16, PIECE_B, xn[0].y, xn[1].y, xn[2].y, xn[3].y);
+            stage_col4(Xp + st_off + 2 * QS * 16, PIECE_B, xn[0].z, xn[1].z, xn[2].z, xn[3].z);
+            stage_col4(Xp + st_off + 3 * QS * 16, PIECE_B, xn[0].w, xn[1].w, xn[2].w, xn[3].w);
+            stage_col4(Gp + st_off + 0 * QS * 16, PIECE_B, gn[0].x, gn[1].x, gn[2].x, gn[3].x);
+            stage_col4(Gp + st_off + 1 * QS * 16, PIECE_B, gn[0].y, gn[1].y, gn[2].y, gn[3].y);
+            stage_col4(Gp + st_off + 2 * QS * 16, PIECE_B, gn[0].z, gn[1].z, gn[2].z, gn[3].z);
+            stage_col4(Gp + st_off + 3 * QS * 16, PIECE_B, gn[0].w, gn[1].w, gn[2].w, gn[3].w);
+        };
+        prefetch(grp);
+        if (grp == 0 && my_tiles > 0) { stage(0); prefetch(2); }
+        lds_barrier();                                             // tile 0 staged
+        for (int k = 0; k < my_tiles; ++k) {                       // while the consumers multiply tile k: stage tile k+1
+            if (((k + 1) & 1) == grp && k + 1 < my_tiles) { stage(k + 1); prefetch(k + 3); }
+            lds_barrier();
+        }
+        if (has_time) {
+            float* red = smem;   // [16][D]; every consumer is past its last operand read (final barrier above)
+            *reinterpret_cast<float4*>(red + (grp * 8 + trow) * D + tcol) = csum;
+            __syncthreads();                                    // the consumers wait in the matching barrier below
+            if (grp == 0 && pt < D) {
+                float sacc = 0.f;
+                for (int p = 0; p < 16; ++p) sacc += red[p * D + pt];
+                out[pt] = sacc;
+            }
+        }
+        return;
+    }
+
+    // ---- consumers: wave w owns output tiles a = 4(w>>2)..+3 (rows of dW) x b = 2(w&3), 2(w&3)+1 (columns)
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const int a0 = 4 * (wave >> 2), b0 = 2 * (wave & 3);
+    const int rd_off = (g * GRP + (r & 3) * QS + (r >> 2)) * 16;   // lane (r, g), 16-column tile a -> + 64 a bytes
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    lds_barrier();                                     // tile 0 staged
+    for (int k = 0; k < my_tiles; ++k) {
+        const char* Xp = lds + (k & 1) * BUF_B;
+        const char* Gp = Xp + 3 * PIECE_B;
+        bf16x8 B[2][3];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) B[b][pc] = *reinterpret_cast<const bf16x8*>(Gp + pc * PIECE_B + rd_off + (b0 + b) * 64);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bf16x8 A[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) A[pc] = *reinterpret_cast<const bf16x8*>(Xp + pc * PIECE_B + rd_off + (a0 + a) * 64);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x4 c = acc[a][b];
+                if (NT == 8) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[b][2], c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[b][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[b][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[b][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[b][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[b][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[b][0], c, 0, 0, 0);
+                acc[a][b] = c;
+            }
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * (a0 + a) + 4 * g + q;
+                out[(int64_t)(i + has_time) * D + 16 * (b0 + b) + r] = acc[a][b][q];
+            }
+    if (has_time) __syncthreads();                     // pairs with the producers' barrier before their column-sum reduction
 }
 
 // ---------------------------------------------------------------------------------
@@ -1728,6 +1931,25 @@ extern "C" int gode_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t
     const int cg = fast_cg(d_in, d_out, groups);
     const bool al = lincomb_aligned16(xin) && !(((uintptr_t)dS) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15));
+    if ((cg == 0 || cg == 4) && al && d_in == 128 && n_rows > 0 && gode_opt_wgrad_split() &&
+        (n_rows >= kWgradSplitMinRows || gode_opt_wgrad_split_small())) {
+        const size_t lds = (size_t)2 * 6 * 576 * 16;                    // two buffers of six piece arrays: 108 KB, one block per CU
+        const int nt = gode_opt_wgrad_split();
+        const int nx = lc.n <= 2 ? lc.n : 0;            // 128 registers per wave: two raw terms at most
+#define GODE_WGS(CGV, NTV, NXV)                                                                     \
+        { rc = set_lds(wgrad_split_kernel<CGV, NTV, NXV>, lds); if (rc) return rc;                  \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1, GODE_PROF_WGRAD);   \
+          hipLaunchKernelGGL((wgrad_split_kernel<CGV, NTV, NXV>), dim3((unsigned)blocks), dim3(1024), lds, s, \
+                             lc, (int)n_rows, eps, gamma, beta, dS, has_time, dW_part);             \
+          gode_prof_end(s, slot);                                                                   \
+          GODE_LAUNCH_CHECK(); return 0; }
+#define GODE_WGS_NX(CGV, NTV)                                                                       \
+        { if (nx == 1) GODE_WGS(CGV, NTV, 1) else if (nx == 2) GODE_WGS(CGV, NTV, 2) else GODE_WGS(CGV, NTV, 0) }
+        if (nt == 6) { if (cg == 0) GODE_WGS_NX(0, 6) else GODE_WGS_NX(4, 6) }
+        else { if (cg == 0) GODE_WGS_NX(0, 8) else GODE_WGS_NX(4, 8) }
+#undef GODE_WGS_NX
+#undef GODE_WGS
+    }
     if (cg >= 0 && al) {
         const int nj = (int)(d_in / 16);
         const size_t lds = (size_t)2 * 32 * (d_in + 16) * sizeof(float);

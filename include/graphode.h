@@ -55,8 +55,12 @@ typedef struct gode_lincomb {
 
 int         gode_abi_version(void);
 /* run-time tuning switches (process-wide): "gemm_split" (0/1, default 0: exact-fp32 MFMA; 1: split-bf16 x3
- * forward dense product at d = 128, fp32-equivalent), "overlap" (0/1, default 1: two-stream adjoint schedule).
- * Initial values come from GODE_GEMM_SPLIT / GODE_OVERLAP.  Returns 0 or GODE_E_UNSUPPORTED. */
+ * forward dense product at d = 128, fp32-equivalent), "overlap" (0/1, default 1: two-stream adjoint schedule),
+ * "wgrad_split" (8 default / 6 / 0: weight gradient at d = 128 and >= 65 536 rows formed on the bf16 matrix cores
+ * from an EXACT three-way cut of every fp32 operand - 8: all piece products down to 2^-32 of a product, i.e. more
+ * accurate than an fp32 FMA chain; 6: down to 2^-23; 0: fp32-MFMA kernel), "wgrad_split_small" (0/1, default 0: use
+ * that kernel below 65 536 rows too).  Initial values come from GODE_GEMM_SPLIT / GODE_OVERLAP / GODE_WGRAD_SPLIT.
+ * Returns 0 or GODE_E_UNSUPPORTED. */
 int         gode_set_option(const char* name, int value);
 int         gode_get_option(const char* name);
 const char* gode_error_string(int code);   /* host string, static storage */

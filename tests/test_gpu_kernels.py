@@ -419,3 +419,50 @@ def test_split_bf16_forward_product_matches_fp32_path():
     scale = ref.abs().max().item()
     assert e0 <= 1e-5 * scale and e1 <= 1e-5 * scale, (e0, e1, scale)
     assert e1 <= 4 * e0 + 1e-6 * scale        # the split product is as close to the fp64 truth as the fp32 MFMA chain
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 1000, 4097, 70001])
+@pytest.mark.parametrize("groups", [32, 0])
+def test_weight_gradient_from_exact_bf16_pieces(n, groups):
+    """csrc/gemm.hip wgrad_split_kernel (d = 128): every fp32 operand cut exactly into three bf16 pieces, products
+    accumulated in fp32 on the bf16 matrix cores - against float64 and against the fp32-MFMA kernel, for 8 and 6 piece
+    products, 1 / 2 (raw prefetch registers) and 3 / 5 terms (combined at load), with and without the time row, ragged
+    row counts (the last 32-row tile partly empty, fewer tiles than producer groups)."""
+    from graph_odenet_amd import _lib, ops
+    lib = _lib.load()
+    d = 128
+    g = torch.Generator().manual_seed(n * 7 + groups)
+    xs = [torch.randn(n, d, generator=g) * (1.5 if j == 0 else 0.4) + (0.3 if j == 0 else 0.0) for j in range(5)]
+    coef = [1.0, 0.25, -0.125, 0.0625, 0.5]
+    dS = torch.randn(n, d, generator=g) * torch.rand(n, 1, generator=g)
+    gam, bet = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    try:
+        assert lib.gode_set_option(b"wgrad_split_small", 1) == 0
+        for nt in (1, 2, 3, 5):
+            x = sum(c * t.double() for c, t in zip(coef[:nt], xs[:nt]))
+            xn = x
+            if groups:
+                xg = x.view(n, groups, d // groups)
+                xn = ((xg - xg.mean(2, keepdim=True)) / torch.sqrt(xg.var(2, unbiased=False, keepdim=True) + 1e-5)).view(n, d)
+                xn = xn * gam.double() + bet.double()
+            want = torch.cat([dS.double().sum(0, keepdim=True), xn.t() @ dS.double()], 0)
+            scale = want.abs().max().item() + 1e-30
+            terms = [(c, t.to(dev())) for c, t in zip(coef[:nt], xs[:nt])]
+            got = {}
+            for mode in (0, 8, 6):
+                assert lib.gode_set_option(b"wgrad_split", mode) == 0 and lib.gode_get_option(b"wgrad_split") == mode
+                for has_time in (True, False):
+                    part = ops.wgrad(terms, n, d, groups, 1e-5, gam.to(dev()) if groups else torch.ones(d, device=dev()),
+                                     bet.to(dev()) if groups else torch.zeros(d, device=dev()), dS.to(dev()), has_time)
+                    dW = part.double().sum(0).view(d + (1 if has_time else 0), d).cpu()
+                    ref = want if has_time else want[1:]
+                    err = (dW - ref).abs().max().item() / scale
+                    assert err <= 2e-6, (n, groups, nt, mode, has_time, err)
+                    got[(mode, has_time)] = dW
+            for has_time in (True, False):        # the three kernels agree far inside the 1e-5 bar
+                for mode in (8, 6):
+                    assert (got[(mode, has_time)] - got[(0, has_time)]).abs().max().item() <= 2e-6 * scale
+    finally:
+        lib.gode_set_option(b"wgrad_split", 8)
+        lib.gode_set_option(b"wgrad_split_small", 0)
+    assert lib.gode_set_option(b"wgrad_split", 7) != 0            # only 0, 6, 8
