@@ -27,7 +27,7 @@ int env_int(const char* name, int dflt) { const char* e = getenv(name); return e
 int g_gemm_split = -1, g_overlap = -1, g_wgrad_split = -1, g_wgrad_split_small = 0;
 }
 
-int gode_opt_gemm_split() { if (g_gemm_split < 0) g_gemm_split = env_int("GODE_GEMM_SPLIT", 0) != 0; return g_gemm_split; }
+int gode_opt_gemm_split() { if (g_gemm_split < 0) { const int v = env_int("GODE_GEMM_SPLIT", 2); g_gemm_split = (v == 1 || v == 2) ? v : 0; } return g_gemm_split; }
 int gode_opt_wgrad_split() {
     if (g_wgrad_split < 0) { const int v = env_int("GODE_WGRAD_SPLIT", 8); g_wgrad_split = (v == 6 || v == 8) ? v : 0; }
     return g_wgrad_split;
@@ -37,7 +37,7 @@ int gode_opt_overlap() { if (g_overlap < 0) g_overlap = env_int("GODE_OVERLAP", 
 
 extern "C" int gode_set_option(const char* name, int value) {
     if (!name) return GODE_E_NULLPTR;
-    if (!strcmp(name, "gemm_split")) { g_gemm_split = value != 0; return 0; }
+    if (!strcmp(name, "gemm_split")) { if (value < 0 || value > 2) return GODE_E_UNSUPPORTED; g_gemm_split = value; return 0; }
     if (!strcmp(name, "overlap")) { g_overlap = value != 0; return 0; }
     if (!strcmp(name, "wgrad_split_small")) { g_wgrad_split_small = value != 0; return 0; }
     if (!strcmp(name, "wgrad_split")) { if (value != 0 && value != 6 && value != 8) return GODE_E_UNSUPPORTED; g_wgrad_split = value; return 0; }

@@ -370,10 +370,12 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_fwd_kernel(LinComb xin, int n_
 // a VALU wave on one SIMD take the SUM of their times, tools/dev/mfma_valu.hip), so the exact-fp32 kernel above
 // pays MFMA + VALU serially.  Here every fp32 operand is decomposed EXACTLY into three bf16 pieces
 // (x = x_hi + x_mid + x_lo, 8+8+8 significant bits, each piece the round-to-nearest bf16 of the running residual)
-// and the product is accumulated in fp32 from the six piece products whose weight is >= 2^-24 of the result
-// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the dropped ones are < 2^-24 relative) on
-// v_mfma_f32_16x16x32_bf16 - 16 cycles per instruction at 8x the K depth: 192 MFMAs x 16 cycles per 16-row tile
-// instead of 256 x 32.  Parity is the same 1e-5 bar (tests/test_gpu_kernels.py runs both variants).
+// and the product is accumulated in fp32, smallest first, from the eight piece products whose weight is >= 2^-24 of
+// the result (lo*mid, mid*lo, lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi; only lo*lo, < 2^-32 of the product, is
+// left out: every product enters the accumulator more exactly than an fp32 FMA forms it) on
+// v_mfma_f32_16x16x32_bf16 - 16 cycles per instruction at 8x the K depth: 256 MFMAs x 16 cycles per 16-row tile
+// instead of 256 x 32, and - unlike v_mfma_f32_16x16x4_f32 - the other waves of the SIMD keep issuing their memory
+// instructions meanwhile (profiles/r02_mfma_mem.txt).  Parity is the same 1e-5 bar (tests/test_gpu_kernels.py runs both variants).
 // ---------------------------------------------------------------------------------
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) {
@@ -388,7 +390,7 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
     l = bf16_bits(r1 - bf16_val(m));
 }
 
-template <int CG>   // d = 128
+template <int CG, int NX>   // d = 128; NX = 1, 2: that many terms, the NEXT tile's raw loads in flight during the matrix phase; 0: any count
 __global__ __launch_bounds__(512, 2) void gn_gemm_fwd_split_kernel(LinComb xin, int n_rows, float eps,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
@@ -422,11 +424,39 @@ __global__ __launch_bounds__(512, 2) void gn_gemm_fwd_split_kernel(LinComb xin, 
     const int mr = l >> 2, mg = l & 3;         // memory layout
     const int to_m = (mg * 16 + mr) * 4;
     const int n_tiles = (n_rows + 15) / 16;
+    constexpr int NXR = NX > 0 ? NX : 1;
+    float4 raw[NXR][NJ];                       // NX > 0: the raw terms of the tile about to be processed
+    auto request = [&](int tile) {             // unconditional loads from a clamped row (no wait at a branch join)
+        const int rr = tile * 16 + mr;
+        const int64_t base = (int64_t)(rr < n_rows ? rr : n_rows - 1) * D + 4 * mg;
+#pragma unroll
+        for (int t = 0; t < NXR; ++t)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) raw[t][j] = ld4(xin.ptr[t] + base + 16 * j);
+    };
+    if (NX > 0 && blockIdx.x * 8 + wave < n_tiles) request(blockIdx.x * 8 + wave);
     for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
         const int row = tile * 16 + mr;
         const bool valid = row < n_rows;
         float4 xv[NJ];
-        load_tile<NJ, 2>(xin, (int64_t)row * D + 4 * mg, valid, xv);
+        if (NX > 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {     // the term order and arithmetic of load_tile_n
+                xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < NXR; ++t) {
+                    const float c = xin.coef[t];
+                    xv[j].x = fmaf(c, raw[t][j].x, xv[j].x); xv[j].y = fmaf(c, raw[t][j].y, xv[j].y);
+                    xv[j].z = fmaf(c, raw[t][j].z, xv[j].z); xv[j].w = fmaf(c, raw[t][j].w, xv[j].w);
+                }
+                if (!valid) xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const int nt_ = tile + gridDim.x * 8;
+            request(nt_ < n_tiles ? nt_ : tile);
+            __builtin_amdgcn_sched_barrier(0);         // issued HERE, ahead of the cut and the matrix phase, not sunk to the loop end
+        } else {
+            load_tile<NJ, 2>(xin, (int64_t)row * D + 4 * mg, valid, xv);
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             xv[j] = gn_forward_v<CG>(xv[j], eps, ld4(Gs + 16 * j + 4 * mg), ld4(Bs + 16 * j + 4 * mg));
@@ -477,6 +507,8 @@ __global__ __launch_bounds__(512, 2) void gn_gemm_fwd_split_kernel(LinComb xin, 
             }
             const bf16x8 ah = a[sidx & 1][0], am = a[sidx & 1][1], al = a[sidx & 1][2];
             f32x4 c = acc[tt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xp[kb][1], c, 0, 0, 0);      // lo*mid, mid*lo: 2^-24 of the product each
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xp[kb][2], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xp[kb][0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xp[kb][2], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xp[kb][1], c, 0, 0, 0);
@@ -1715,15 +1747,19 @@ extern "C" int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin, int64_t n_r
     const int cg = fast_cg(d_in, d_out, groups);
     const bool al = lincomb_aligned16(xin) && !(((uintptr_t)S) & 15) && !(((uintptr_t)W) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15));
-    if (cg >= 0 && al && d_in == 128 && gode_opt_gemm_split() && !x_out) {
+    if (cg >= 0 && al && d_in == 128 && !x_out && (gode_opt_gemm_split() == 1 || (gode_opt_gemm_split() == 2 && lc.n <= 2 && n_rows >= 65536))) {
         const size_t lds = (size_t)3 * 128 * (128 + 8) * sizeof(unsigned short) + 3 * 128 * sizeof(float);
         int64_t blocks = ((n_rows + 15) / 16 + 7) / 8; if (blocks < 1) blocks = 1; if (blocks > 256) blocks = 256;
-#define GODE_FWDS(CGV) { rc = set_lds(gn_gemm_fwd_split_kernel<CGV>, lds); if (rc) return rc;                \
-          hipLaunchKernelGGL((gn_gemm_fwd_split_kernel<CGV>), dim3((unsigned)blocks), dim3(512), lds, s,     \
+#define GODE_FWDS2(CGV, NXV) { rc = set_lds(gn_gemm_fwd_split_kernel<CGV, NXV>, lds); if (rc) return rc;    \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1, GODE_PROF_GEMM_FWD);          \
+          hipLaunchKernelGGL((gn_gemm_fwd_split_kernel<CGV, NXV>), dim3((unsigned)blocks), dim3(512), lds, s, \
                              lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S);                           \
+          gode_prof_end(s, slot);                                                                             \
           GODE_LAUNCH_CHECK(); return 0; }
+#define GODE_FWDS(CGV) { if (lc.n == 1) GODE_FWDS2(CGV, 1) else if (lc.n == 2) GODE_FWDS2(CGV, 2) else GODE_FWDS2(CGV, 0) }
         if (cg == 0) GODE_FWDS(0) else if (cg == 1) GODE_FWDS(1) else if (cg == 2) GODE_FWDS(2) else GODE_FWDS(4)
 #undef GODE_FWDS
+#undef GODE_FWDS2
     }
     if (cg >= 0 && al) {
         const int nj = (int)(d_in / 16);

@@ -1,6 +1,6 @@
 #pragma once
 // run-time tuning switches (api.hip); initial values from the environment, changeable through gode_set_option
-int gode_opt_gemm_split();   // GODE_GEMM_SPLIT (default 0): split-bf16 forward dense product at d = 128
+int gode_opt_gemm_split();   // GODE_GEMM_SPLIT (default 2): split-bf16 forward dense product at d = 128 - 1 always, 2 launches of <= 2 terms and >= 65 536 rows, 0 never
 int gode_opt_overlap();      // GODE_OVERLAP (default 1): two-stream schedule of the adjoint rk4 driver
 int gode_opt_wgrad_split();  // GODE_WGRAD_SPLIT (default 8): weight gradient at d = 128 from exact bf16 pieces with 8 (or 6) piece products per product; 0 = fp32-MFMA kernel
 int gode_opt_wgrad_split_small();  // wgrad_split_small (default 0): use it below 65 536 rows too (tests)

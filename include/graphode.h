@@ -54,8 +54,10 @@ typedef struct gode_lincomb {
 } gode_lincomb_t;
 
 int         gode_abi_version(void);
-/* run-time tuning switches (process-wide): "gemm_split" (0/1, default 0: exact-fp32 MFMA; 1: split-bf16 x3
- * forward dense product at d = 128, fp32-equivalent), "overlap" (0/1, default 1: two-stream adjoint schedule),
+/* run-time tuning switches (process-wide): "gemm_split" (forward dense product at d = 128 from an exact
+ * three-way bf16 cut of both operands, eight piece products, what is dropped < 2^-32 of a product: 1 always; 2, the
+ * default, for launches of <= 2 terms and >= 65 536 rows - the ones the fp32-MFMA kernel does not run at the memory
+ * rate; 0 never), "overlap" (0/1, default 1: two-stream adjoint schedule),
  * "wgrad_split" (8 default / 6 / 0: weight gradient at d = 128 and >= 65 536 rows formed on the bf16 matrix cores
  * from an EXACT three-way cut of every fp32 operand - 8: all piece products down to 2^-32 of a product, i.e. more
  * accurate than an fp32 FMA chain; 6: down to 2^-23; 0: fp32-MFMA kernel), "wgrad_split_small" (0/1, default 0: use
