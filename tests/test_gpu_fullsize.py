@@ -41,7 +41,14 @@ def test_dense_kernels_full_size_properties():
     assert rel(S12, 2.0 * S1 - 0.5 * S2) < 2e-5
     xo = torch.empty(N, D, device=dev())
     S1b = ops.gn_time_gemm(terms, N, D, 32, 1e-5, gam, bet, W1, True, 0.4, x_out=xo)
-    assert torch.equal(S1b, S1) and rel(xo, x + 0.3 * k1) < 1e-6
+    # two terms without x_out: the bf16-piece kernel (gemm_split 2); with x_out: the fp32-MFMA kernel - same fp32 result
+    assert rel(S1b, S1) < 2e-6 and rel(xo, x + 0.3 * k1) < 1e-6
+    t3 = terms + [(-0.2, torch.randn(N, D, generator=gen, device=dev()))]         # three terms: one kernel either way
+    S3 = ops.gn_time_gemm(t3, N, D, 32, 1e-5, gam, bet, W1, True, 0.4)
+    xo3 = torch.empty(N, D, device=dev())
+    S3b = ops.gn_time_gemm(t3, N, D, 32, 1e-5, gam, bet, W1, True, 0.4, x_out=xo3)
+    assert torch.equal(S3b, S3)
+    del S3, S3b, t3, xo3
     # S is linear in W:  <S(W1), dS> = <W1, dW(dS)>  with dW from the weight-gradient kernel (time row scaled by t)
     dS = torch.randn(N, D, generator=gen, device=dev())
     part = ops.wgrad(terms, N, D, 32, 1e-5, gam, bet, dS, True)
