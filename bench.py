@@ -123,20 +123,22 @@ def secondary(args, model, x, g, step, barrier):
         out["steps_per_s_at_256_evals"] = round(1.0 / (time.perf_counter() - t0), 4)
     finally:
         blk.step_size = old
-    # opt-in lead, NOT the default path and not the contract value: the forward dense product on the bf16 matrix pipe
-    # through an exact three-way operand split with fp32 accumulation
+    # the same step with every dense product on the exact-fp32 MFMA kernels (gemm_split 0, wgrad_split 0), for the A/B
+    # against the default (bf16-piece kernels for the weight gradient and the <= 2-term forward launches)
     from graph_odenet_amd import _lib
     lib = _lib.load()
-    if lib.gode_set_option(b"gemm_split", 1) == 0:
+    was = (lib.gode_get_option(b"gemm_split"), lib.gode_get_option(b"wgrad_split"))
+    if lib.gode_set_option(b"gemm_split", 0) == 0 and lib.gode_set_option(b"wgrad_split", 0) == 0:
         try:
             step()
             barrier()
             t0 = time.perf_counter()
             step()
             barrier()
-            out["steps_per_s_with_optin_split_bf16_forward_product"] = round(1.0 / (time.perf_counter() - t0), 4)
+            out["steps_per_s_with_fp32_mfma_dense_kernels_only"] = round(1.0 / (time.perf_counter() - t0), 4)
         finally:
-            lib.gode_set_option(b"gemm_split", 0)
+            lib.gode_set_option(b"gemm_split", was[0])
+            lib.gode_set_option(b"wgrad_split", was[1])
     return out
 
 
@@ -259,7 +261,12 @@ def main():
         if not ix:
             continue
         if dense is None:
-            dense = {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_launch": flop, "kernels": {}}
+            dense = {"bound": "mfma", "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_launch": flop, "kernels": {},
+                     "note": "one entry per kernel FAMILY (forward / VJP / weight gradient), named after its fp32-MFMA kernel; "
+                             "frac = fp32 flop rate / fp32 matrix peak.  gemm_split=%d: forward launches of <= 2 terms run "
+                             "gn_gemm_fwd_split_kernel; wgrad_split=%d: the weight gradient runs wgrad_split_kernel (both: "
+                             "operands cut exactly into bf16 pieces, products on the bf16 matrix cores, fp32 accumulation; "
+                             "0 = fp32-MFMA kernel)" % (lib.gode_get_option(b"gemm_split"), lib.gode_get_option(b"wgrad_split"))}
         avg = sum(ms[i] for i in ix) / len(ix)
         plain = {1: 2, 2: 3, 3: 2}[kind]                                  # N x d arrays a one-term launch reads + writes
         byts = sum((plain + xx[i]) * nd4 for i in ix) / len(ix)

@@ -13,13 +13,16 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "gpurun_out", "profiles_" + tag)
 os.makedirs(prof, exist_ok=True)
 
-KPAT = re.compile(r"(spmm\w+<\d+>|gn_gemm\w+<\d+, \d+>|wgrad_kernel<\d+, \d+>|reduce_parts_kernel|colsum4?_kernel|lincomb\d_kernel|"
+KPAT = re.compile(r"(spmm\w+<\d+>|gn_gemm\w+<\d+, \d+>|wgrad_split_kernel<\d+, \d+, \d+>|wgrad_kernel<\d+, \d+>|reduce_parts_kernel|colsum4?_kernel|lincomb\d_kernel|"
                   r"ratio_sumsq_kernel<\d>|gat_\w+|edge_matvec\w+|final_\w+)")
 
 
 def short(name):
     m = KPAT.search(name)
-    return m.group(1) if m else name.split("(")[0][-60:]
+    if m:
+        return m.group(1)
+    m = re.search(r"([A-Za-z_]\w*(?:<[^()]*>)?)\((?!anonymous)", name)      # the identifier in front of the parameter list
+    return (m.group(1) if m else name)[:60]
 
 
 # 1) kernel stats
