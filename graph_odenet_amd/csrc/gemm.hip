@@ -669,6 +669,178 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
 }
 
 // ---------------------------------------------------------------------------------
+// VJP on the bf16 matrix cores (d = 128, GroupNorm of 4 channels per group or none): dS and W1 are cut exactly into
+// three bf16 pieces each (as in gn_gemm_fwd_split_kernel: by rounding, eight of the nine piece products, smallest
+// first, fp32 accumulation - every product to 2^-32), the GroupNorm backward and the dgamma / dbeta partials are those
+// of gn_gemm_bwd_kernel.  The point is not the matrix time but what runs beside it: bf16 MFMAs let the partner wave
+// issue its loads and stores, fp32 MFMAs do not (profiles/r02_mfma_mem.txt), and this launch moves three N x d arrays.
+// ---------------------------------------------------------------------------------
+template <int CG>   // 0 or 4
+__global__ __launch_bounds__(512, 2) void gn_gemm_bwd_split_kernel(LinComb xin, int n_rows, float eps,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ W, int has_time,
+                                                                   const float* __restrict__ dS, float out_scale,
+                                                                   LinComb pre, float* __restrict__ dx,
+                                                                   float* __restrict__ dgamma_part,
+                                                                   float* __restrict__ dbeta_part, int n_part)
+{
+    constexpr int D = 128, NJ = 8, NK = 4;          // NK k-blocks of 32
+    constexpr int LDK = D + 8;                      // bf16 elements per row of a piece array (272 B: conflict-free ds_read_b128)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* Wp = reinterpret_cast<unsigned short*>(smem);          // [3][D][LDK]: pieces of W1[i][n] (row i, column n)
+    float* Gs = smem + (3 * D * LDK) / 2;
+    for (int idx = threadIdx.x; idx < D * D / 4; idx += 512) {
+        const int i = idx / (D / 4), n = (idx % (D / 4)) * 4;
+        const float4 w = ld4(W + (int64_t)(i + has_time) * D + n);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+        unsigned short pc[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split3(wv[q], pc[0][q], pc[1][q], pc[2][q]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint2*>(Wp + (p * D + i) * LDK + n) =
+                make_uint2((unsigned)pc[p][0] | ((unsigned)pc[p][1] << 16), (unsigned)pc[p][2] | ((unsigned)pc[p][3] << 16));
+    }
+    fill_vec_lds<D, 512>(Gs, gamma, 1.f);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int r = l & 15, g = l >> 4;          // MFMA layout
+    const int mr = l >> 2, mg = l & 3;         // memory layout
+    const int to_m = (mg * 16 + mr) * 4;
+    const int n_tiles = (n_rows + 15) / 16;
+    float4 dgs[NJ], dbs[NJ];                   // memory layout: channels 16tt + 4mg .. +3 of row mr
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { dgs[j] = make_float4(0.f, 0.f, 0.f, 0.f); dbs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+        const int row = tile * 16 + mr;
+        const bool valid = row < n_rows;
+        const int64_t base = (int64_t)(valid ? row : n_rows - 1) * D + 4 * mg;     // clamped: unconditional loads
+        float4 gv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            gv[j] = ld4(dS + base + 16 * j);
+            if (!valid) gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 xt[NJ];      // x tile (memory layout), requested before the matrix phase
+        if (CG != 0) load_tile<NJ>(xin, base, true, xt);
+        // memory layout -> bf16 MFMA layout (see gn_gemm_fwd_split_kernel): F-lane (r, g) needs dS[row r][32kb + 8g + 4h + c]
+        bf16x8 gp[NK][3];
+#pragma unroll
+        for (int kb = 0; kb < NK; ++kb) {
+            float xf[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int src = (4 * r + 2 * (g & 1) + h) * 4;
+                const float4 a = to_mfma_layout(gv[2 * kb], src), b = to_mfma_layout(gv[2 * kb + 1], src);
+                const float4 v = (g >> 1) ? b : a;
+                xf[4 * h] = v.x; xf[4 * h + 1] = v.y; xf[4 * h + 2] = v.z; xf[4 * h + 3] = v.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned short h, m, lo;
+                split3(xf[e], h, m, lo);
+                gp[kb][0][e] = (short)h; gp[kb][1][e] = (short)m; gp[kb][2][e] = (short)lo;
+            }
+        }
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 a[2][3];
+        {
+            const unsigned short* wr = Wp + r * LDK + 8 * g;
+            a[0][0] = *reinterpret_cast<const bf16x8*>(wr);
+            a[0][1] = *reinterpret_cast<const bf16x8*>(wr + D * LDK);
+            a[0][2] = *reinterpret_cast<const bf16x8*>(wr + 2 * D * LDK);
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < NK * NJ; ++sidx) {
+            const int kb = sidx / NJ, tt = sidx % NJ;
+            if (sidx + 1 < NK * NJ) {
+                const int kb2 = (sidx + 1) / NJ, tt2 = (sidx + 1) % NJ;
+                const unsigned short* wr = Wp + (16 * tt2 + r) * LDK + 32 * kb2 + 8 * g;
+                a[(sidx + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(wr);
+                a[(sidx + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(wr + D * LDK);
+                a[(sidx + 1) & 1][2] = *reinterpret_cast<const bf16x8*>(wr + 2 * D * LDK);
+            }
+            const bf16x8 ah = a[sidx & 1][0], am = a[sidx & 1][1], al = a[sidx & 1][2];
+            f32x4 c = acc[tt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gp[kb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, gp[kb][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gp[kb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gp[kb][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, gp[kb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, gp[kb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gp[kb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gp[kb][0], c, 0, 0, 0);
+            acc[tt] = c;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // acc[tt] (MFMA layout) = dxn[row r][16tt+4g .. +3]  ->  memory layout for GroupNorm backward + store
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            const int c0 = 16 * tt + 4 * mg;
+            const float4 dy = acc_to_mem_layout(acc[tt], to_m);
+            float4 out = dy;
+            if (CG != 0) {                         // four channels per group = this lane's float4 (as gn_gemm_bwd_kernel, CG == 4)
+                const float4 x = xt[tt];
+                float4 mean, rstd;
+                gn_stats<CG>(x, eps, mean, rstd);
+                const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y,
+                                              (x.z - mean.z) * rstd.z, (x.w - mean.w) * rstd.w);
+                const float4 gm = ld4(Gs + c0);
+                const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+                if (valid) {
+                    dgs[tt].x += dy.x * xh.x; dgs[tt].y += dy.y * xh.y; dgs[tt].z += dy.z * xh.z; dgs[tt].w += dy.w * xh.w;
+                    dbs[tt].x += dy.x; dbs[tt].y += dy.y; dbs[tt].z += dy.z; dbs[tt].w += dy.w;
+                }
+                const float m1 = ((dh.x + dh.y) + (dh.z + dh.w)) * 0.25f;
+                const float m2 = ((dh.x * xh.x + dh.y * xh.y) + (dh.z * xh.z + dh.w * xh.w)) * 0.25f;
+                const float rs = rstd.x;
+                out = make_float4(rs * (dh.x - m1 - xh.x * m2), rs * (dh.y - m1 - xh.y * m2),
+                                  rs * (dh.z - m1 - xh.z * m2), rs * (dh.w - m1 - xh.w * m2));
+            }
+            if (valid) {
+                float4 o = make_float4(out_scale * out.x, out_scale * out.y, out_scale * out.z, out_scale * out.w);
+                if (pre.n > 0) {     // fused RK solution combine of the adjoint component
+                    const float4 pv = lc_load4(pre, (int64_t)row * D + c0);
+                    o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+                }
+                *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) = o;
+            }
+        }
+    }
+    if (CG != 0 && dgamma_part) {
+        __syncthreads();                       // every wave is done with the W pieces: reuse LDS for the reduction
+        float* red = smem;                     // [2][8 waves][D]  (Gs lies behind the pieces and is not touched)
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+            float4 a = dgs[tt], b = dbs[tt];
+#pragma unroll
+            for (int o = 4; o < 64; o <<= 1) {  // lanes with equal mg (l & 3) hold the same channels
+                a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+                b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+            }
+            if (mr == 0) {
+                *reinterpret_cast<float4*>(red + wave * D + 16 * tt + 4 * mg) = a;
+                *reinterpret_cast<float4*>(red + (8 + wave) * D + 16 * tt + 4 * mg) = b;
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 512) {
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { sa += red[w * D + c]; sb += red[(8 + w) * D + c]; }
+            dgamma_part[(int64_t)blockIdx.x * D + c] = sa;
+            dbeta_part[(int64_t)blockIdx.x * D + c] = sb;
+        }
+        // the caller's buffers hold gode_gemm_bwd_parts() rows: zero the ones no block owns
+        for (int p = gridDim.x + blockIdx.x; p < n_part; p += gridDim.x)
+            for (int c = threadIdx.x; c < D; c += 512) { dgamma_part[(int64_t)p * D + c] = 0.f; dbeta_part[(int64_t)p * D + c] = 0.f; }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // weight gradient: dW[has_time + i][n] = sum_rows xn[row][i] * dS[row][n]; row 0 (has_time) = sum_rows dS[row][n]
 // (the gradient w.r.t. a unit time column: the caller scales it by t and uses it for dL/dt)
 // one block partial per block.
@@ -1859,6 +2031,19 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
     const bool al = lincomb_aligned16(xin) && lincomb_aligned16(pre) && !(((uintptr_t)dS) & 15) && !(((uintptr_t)dx) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) &&
                     (!dgamma_part || (!(((uintptr_t)dgamma_part) & 15) && !(((uintptr_t)dbeta_part) & 15)));
+    if ((cg == 0 || cg == 4) && al && d_in == 128 && gode_opt_bwd_split() &&
+        (n_rows >= kWgradSplitMinRows || gode_opt_wgrad_split_small())) {
+        const size_t lds = (size_t)3 * 128 * (128 + 8) * sizeof(unsigned short) + 128 * sizeof(float);
+        int64_t blocks = ((n_rows + 15) / 16 + 7) / 8; if (blocks < 1) blocks = 1; if (blocks > 256) blocks = 256;
+#define GODE_BWDS(CGV) { rc = set_lds(gn_gemm_bwd_split_kernel<CGV>, lds); if (rc) return rc;                 \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1 + lpre.n, GODE_PROF_GEMM_BWD);  \
+          hipLaunchKernelGGL((gn_gemm_bwd_split_kernel<CGV>), dim3((unsigned)blocks), dim3(512), lds, s,      \
+                             lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part, (int)n_part); \
+          gode_prof_end(s, slot);                                                                             \
+          GODE_LAUNCH_CHECK(); return 0; }
+        if (cg == 0) GODE_BWDS(0) else GODE_BWDS(4)
+#undef GODE_BWDS
+    }
     if (cg >= 0 && al) {
         const int nj = (int)(d_in / 16);
         size_t lds = ((size_t)d_in * (d_in + 4) + d_in) * sizeof(float);

@@ -61,7 +61,9 @@ int         gode_abi_version(void);
  * "wgrad_split" (8 default / 6 / 0: weight gradient at d = 128 and >= 65 536 rows formed on the bf16 matrix cores
  * from an EXACT three-way cut of every fp32 operand - 8: all piece products down to 2^-32 of a product, i.e. more
  * accurate than an fp32 FMA chain; 6: down to 2^-23; 0: fp32-MFMA kernel), "wgrad_split_small" (0/1, default 0: use
- * that kernel below 65 536 rows too).  Initial values come from GODE_GEMM_SPLIT / GODE_OVERLAP / GODE_WGRAD_SPLIT.
+ * that kernel below 65 536 rows too), "bwd_split" (0 default / 1: the VJP at d = 128 in the same way - parity-green,
+ * measured at -0.45 % of the benchmark step, not a default).  Initial values come from GODE_GEMM_SPLIT / GODE_OVERLAP /
+ * GODE_WGRAD_SPLIT / GODE_BWD_SPLIT.
  * Returns 0 or GODE_E_UNSUPPORTED. */
 int         gode_set_option(const char* name, int value);
 int         gode_get_option(const char* name);
