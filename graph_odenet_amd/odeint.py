@@ -81,7 +81,23 @@ def _check_state(y0):
 
 
 def _times(t):
-    tl = [float(v) for v in (t.tolist() if torch.is_tensor(t) else t)]
+    # The reference's ODEBlock keeps `integration_time` on the device (GCN/models.py:195 `type_as(x)`), so reading it
+    # is a device->host copy = a host synchronisation in the middle of every forward pass (measured at C5: the GPU
+    # then idles ~0.3 ms while the host catches up).  The values are remembered on the tensor object together with its
+    # version counter, so only the first call (and any call after an in-place change) pays for it.
+    if torch.is_tensor(t) and t.is_cuda:
+        hit = getattr(t, "_gode_times", None)
+        if hit is not None and hit[0] == t._version:
+            tl = hit[1]
+        else:
+            tl = [float(v) for v in t.tolist()]
+            try:
+                t._gode_times = (t._version, tl)
+            except Exception:
+                pass
+        tl = list(tl)
+    else:
+        tl = [float(v) for v in (t.tolist() if torch.is_tensor(t) else t)]
     if len(tl) < 2:
         raise ValueError("odeint: t must hold at least two time points")
     return tl
