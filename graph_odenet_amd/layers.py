@@ -22,6 +22,21 @@ from .graph import as_graph
 _SQUARE = (16, 32, 64, 128)
 
 
+def _xt_g(x, g):
+    """x^T g for tall x (n x d) and g (n x c): the weight gradient of a rectangular layer.  The library GEMM of this image
+    runs the reduction over 2^20 rows in ONE workgroup column (1.25 ms for 128 x 16 outputs); as a batched product over
+    256 row blocks plus a sum it takes 0.12 ms (tools/dev/narrow_mm_probe.py)."""
+    n = x.shape[0]
+    if n < 65536 or not (x.is_contiguous() and g.is_contiguous()):
+        return torch.mm(x.t(), g)
+    B = 256
+    m = n // B
+    out = torch.bmm(x[:m * B].view(B, m, x.shape[1]).transpose(1, 2), g[:m * B].view(B, m, g.shape[1])).sum(0)
+    if m * B < n:
+        out += torch.mm(x[m * B:].t(), g[m * B:])
+    return out
+
+
 class _GraphConvFn(torch.autograd.Function):
     """output = A @ (input @ W) + bias   (GCN/layers.py:31-37)."""
 
@@ -59,7 +74,7 @@ class _GraphConvFn(torch.autograd.Function):
                 gw = torch.empty_like(weight)
                 ops.reduce_parts_(gw.view(-1), ops.wgrad([(1.0, x)], n, d, 0, 0.0, None, None, d_support, False))
             else:
-                gw = torch.mm(x.t(), d_support)
+                gw = _xt_g(x, d_support)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = torch.empty_like(weight[0])
             ops.colsum_(gb, g)

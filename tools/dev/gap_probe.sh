@@ -44,6 +44,16 @@ for gi in range(2):
             for r in ends[max(0, i - 5):i + 5]:
                 print("      %s%8.1f us  %s" % (">" if r is ends[i] else " ", (r[1] - r[0]) / 1e3, r[2][:90]))
             break
+import collections, re
+agg = collections.defaultdict(lambda: [0, 0])
+for s_, e_, n_, q_ in sel:
+    if e_ > t1 - 3_000_000:                    # the trailing read-back after the last step
+        continue
+    key = re.sub(r"\(.*", "", n_)[-70:]
+    agg[key][0] += 1; agg[key][1] += e_ - s_
+print("kernels of the last step by total time:")
+for k_, (c_, t_) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+    print("   %8.2f ms  %5d x  %s" % (t_ / 1e6, c_, k_))
 tot = sum(e - s for s, e, n, q in sel)
 print("sum of kernel durations in window %.2f ms (overlap = sum - busy = %.2f ms)" % (tot / 1e6, (tot - busy) / 1e6))
 PY
