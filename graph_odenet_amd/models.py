@@ -195,6 +195,11 @@ class ODEBlock(nn.Module):
         self.integration_time = self.integration_time.type_as(x)
         self.odefunc.set_adj(*graph)
         options = None if self.step_size is None else {"step_size": self.step_size}
+        # the reference keeps `out[1]` of the stack over integration_time (GCN/models.py:200); asking for that state alone
+        # saves three passes over it here and in the backward pass (odeint._OdeintAdjoint, last_only)
+        if self.integration_time.numel() == 2:
+            return odeint(self.odefunc, x, self.integration_time, rtol=self.tol, atol=self.tol,
+                          method=self.method, options=options, _last_only=True)
         return odeint(self.odefunc, x, self.integration_time, rtol=self.tol, atol=self.tol,
                       method=self.method, options=options)[1]
 

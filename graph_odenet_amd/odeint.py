@@ -271,7 +271,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
 
 class _OdeintAdjoint(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, func, tl, rtol, atol, method, options, y0, *params):
+    def forward(ctx, func, tl, rtol, atol, method, options, last_only, y0, *params):
         plan, (fwd, mk_adj, plist) = _plan_for(func, y0, tl, method, options, params)
         stats = Dopri5Stats()
         order, inverse = _rows(fwd)
@@ -301,7 +301,12 @@ class _OdeintAdjoint(torch.autograd.Function):
             if plan is not None:
                 plan.seen_f += 1
         _bump_nfe(func, stats.nfe if getattr(fwd, "fused", False) else 0)
-        if order is None:
+        ctx.last_only = bool(last_only)
+        if last_only:
+            # only y(t[-1]) leaves (what the reference's ODEBlock keeps, GCN/models.py:200 `out[1]`): no copy of y0 into
+            # a stacked result, and the backward pass gets the cotangent of that one state instead of a zero-filled stack
+            ans = ans_p[-1].clone() if order is None else torch.index_select(ans_p[-1], 0, inverse)
+        elif order is None:
             ans = ans_p
         else:
             ans = torch.empty_like(ans_p)
@@ -324,9 +329,21 @@ class _OdeintAdjoint(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         order, inverse = ctx.rows
         back = (lambda g: g) if order is None else (lambda g: g.index_select(0, inverse))
+        last_only = ctx.last_only
+        n_t = len(tl)
 
-        def g_at(i):                                  # dL/dy(tl[i]) in the field's row order (one gather, when asked for)
-            return grad_out[i] if order is None else grad_out[i].index_select(0, order)
+        def g_raw(i):                                 # dL/dy(tl[i]) in the caller's row order, None = zero
+            if last_only:
+                return grad_out if i in (n_t - 1, -1) else None
+            return grad_out[i]
+
+        def g_at(i):                                  # the same in the field's row order (one gather, when asked for)
+            g = g_raw(i)
+            return g if (g is None or order is None) else g.index_select(0, order)
+
+        def add_start(g):                             # + cotangent of the start state, rows already in the caller's order
+            g0 = g_raw(0) if n_t > 1 else None
+            return g if g0 is None else g.add_(g0)
         plan = ctx.plan
         if plan is not None and plan.seen_b >= 1 and plan.gb is None and not plan.no_capture:
             with torch.no_grad():
@@ -336,9 +353,9 @@ class _OdeintAdjoint(torch.autograd.Function):
             with torch.no_grad():
                 vals = [ans[1], g_at(1)] + [None] * (len(plan.gb.inputs) - 2)
                 comps = plan.gb.run(vals)
-                gy0 = back(comps[1]).add_(grad_out[0]) if order is not None else comps[1].add_(grad_out[0])
+                gy0 = add_start(back(comps[1]))
             _bump_nfe(func, plan.gb.nfe)
-            return (None, None, None, None, None, None, gy0, *plan.adj.param_grads(comps))
+            return (None, None, None, None, None, None, None, gy0, *plan.adj.param_grads(comps))
         if plan is not None:
             plan.seen_b += 1
         adj = ctx.mk_adj()
@@ -352,9 +369,9 @@ class _OdeintAdjoint(torch.autograd.Function):
                          torch.zeros(1, dtype=ans.dtype, device=ans.device)]
                 comps += [torch.zeros_like(p) for p in adj.params]
             if order is None:
-                comps[1].copy_(grad_out[-1])
+                comps[1].copy_(g_raw(-1))
             else:
-                torch.index_select(grad_out[-1], 0, order, out=comps[1])
+                torch.index_select(g_raw(-1), 0, order, out=comps[1])
             for i in range(len(tl) - 1, 0, -1):
                 comps[0].copy_(ans[i])
                 if ctx.method != "rk4":
@@ -362,26 +379,30 @@ class _OdeintAdjoint(torch.autograd.Function):
                     # func once more here); a fixed grid never looks at it, so rk4 skips the eval.
                     fwd.eval(tl[i], [[(1.0, ans[i])]], [ctx_tmp])
                     stats.nfe += 1
-                    comps[2].sub_((ctx_tmp * g_at(i)).sum().reshape(1))
+                    gi = g_at(i)
+                    if gi is not None:
+                        comps[2].sub_((ctx_tmp * gi).sum().reshape(1))
                     if getattr(adj, "adaptive", None) is not None:
                         adj.adaptive = True
                         adj.reduce_small(comps[2])      # row-partitioned: a_t is a sum over all rows
                 _integrate(adj, comps, tl[i], tl[i - 1], ctx.rtol, ctx.atol, ctx.method, ctx.options, stats)
-                if i > 1:
+                if i > 1 and g_raw(i - 1) is not None:
                     comps[1].add_(g_at(i - 1))
             # the cotangent of the start state is added after the rows are back in the caller's order: one pass, and
             # no gather of a slice that is all zeros whenever the loss only looks at the end state
-            gy0 = back(comps[1]).add_(grad_out[0]) if order is not None else comps[1].add_(grad_out[0])
+            gy0 = add_start(back(comps[1]))
         _bump_nfe(func, stats.nfe if getattr(adj, "fused", False) else 0)
         pg = adj.param_grads(comps) if hasattr(adj, "param_grads") else comps[3:]
-        return (None, None, None, None, None, None, gy0, *pg)
+        return (None, None, None, None, None, None, None, gy0, *pg)
 
 
-def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):
+def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None, _last_only=False):
+    """torchdiffeq's odeint_adjoint for the two solvers of the hot path.  `_last_only=True` (not part of the reference
+    API; used by models.ODEBlock, which keeps `out[1]` only) returns y(t[-1]) instead of the stack over t."""
     _check_state(y0)
     tl = _times(t)
     method = _method(method)
     if not isinstance(func, torch.nn.Module):
         raise ValueError("odeint_adjoint: func must be an nn.Module")
     params = tuple(p for p in func.parameters() if p.requires_grad)
-    return _OdeintAdjoint.apply(func, tl, float(rtol), float(atol), method, options, y0, *params)
+    return _OdeintAdjoint.apply(func, tl, float(rtol), float(atol), method, options, bool(_last_only), y0, *params)

@@ -761,3 +761,34 @@ def test_integration_times_read_once_per_version():
     t[1] = 2.0
     assert OI._times(t) == [0.0, 2.0]
     assert OI._times(torch.tensor([0.0, 0.5])) == [0.0, 0.5] and OI._times([0, 1]) == [0.0, 1.0]
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_last_state_only_equals_stacked_result(method):
+    """odeint_adjoint(..., _last_only=True) - what models.ODEBlock asks for, since the reference keeps `out[1]` - returns
+    the last slice of the stacked result and the same gradients, bit for bit (same kernels in the same order; only the
+    copies around the solve differ), also with a cotangent on the start state folded in by the caller."""
+    from graph_odenet_amd import models
+    from graph_odenet_amd.odeint import odeint_adjoint
+    n, d = 700, 32
+    torch.manual_seed(5)
+    r = torch.randint(0, n, (6000,)); c = torch.randint(0, n, (6000,))
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), torch.rand(6000) / 8, (n, n)).coalesce().to(dev())
+    f = models.ODEfunc(d).to(dev())
+    f.set_adj(adj)
+    t = torch.tensor([0.0, 1.0], device=dev())
+    opts = {"step_size": 0.25} if method == "rk4" else None
+    x = torch.randn(n, d, device=dev())
+    gout = torch.randn(n, d, device=dev())
+    res = []
+    for last in (False, True):
+        f.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        out = odeint_adjoint(f, xi, t, rtol=1e-5, atol=1e-5, method=method, options=opts, _last_only=last)
+        y1 = out if last else out[1]
+        assert y1.shape == (n, d)
+        (y1 * gout).sum().backward()
+        res.append((y1.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in f.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
