@@ -285,13 +285,13 @@ extern "C" int gode_gru_cell_f32_bwd(const float* x, const float* m, const float
     if (!x || !m || !gates || !dout || !dgi || !dgh || !part) return GODE_E_NULLPTR;
     const size_t lds = (size_t)RB * 7 * h * sizeof(float);
     if (lds > 160 * 1024) return GODE_E_UNSUPPORTED;
+    const int64_t parts = gode_gru_wgrad_parts(n);
+    if (parts > 65535) return GODE_E_RANGE;           // every argument check precedes the first launch
     int rc = gode_set_lds_once((const void*)gru_bwd_kernel, lds); if (rc) return rc;
     const int64_t blocks = (n + RB - 1) / RB;
     hipLaunchKernelGGL(gru_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, x, w_ih, w_hh, gates, dout, (int)n, (int)h,
                        dx, dm, dgi, dgh);
     GODE_LAUNCH_CHECK();
-    const int64_t parts = gode_gru_wgrad_parts(n);
-    if (parts > 65535) return GODE_E_RANGE;
     hipLaunchKernelGGL(gru_wgrad_kernel, dim3((unsigned)h3, (unsigned)parts), dim3(256), 0, s, x, m, dgi, dgh, (int)n, (int)h, part);
     GODE_LAUNCH_CHECK();
     int64_t rb = (h3 * (h3 + 2) + 255) / 256; if (rb > 1024) rb = 1024;

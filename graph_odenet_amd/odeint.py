@@ -84,15 +84,19 @@ def _times(t):
     # The reference's ODEBlock keeps `integration_time` on the device (GCN/models.py:195 `type_as(x)`), so reading it
     # is a device->host copy = a host synchronisation in the middle of every forward pass (measured at C5: the GPU
     # then idles ~0.3 ms while the host catches up).  The values are remembered on the tensor object together with its
-    # version counter, so only the first call (and any call after an in-place change) pays for it.
+    # storage address and version counter, so only the first call (and any call after an in-place change or a
+    # `set_` / `.data =` re-pointing) pays for it.  NOT seen: a write through an alias that bumps no version counter of
+    # this tensor (`t.data.copy_(...)`, a raw kernel): pass the end points as Python floats or a CPU tensor then
+    # (models.ODEBlock re-creates `integration_time` from its own floats on every forward, as the reference does).
     if torch.is_tensor(t) and t.is_cuda:
         hit = getattr(t, "_gode_times", None)
-        if hit is not None and hit[0] == t._version:
+        key = (t.data_ptr(), t._version, tuple(t.shape))
+        if hit is not None and hit[0] == key:
             tl = hit[1]
         else:
             tl = [float(v) for v in t.tolist()]
             try:
-                t._gode_times = (t._version, tl)
+                t._gode_times = (key, tl)
             except Exception:
                 pass
         tl = list(tl)

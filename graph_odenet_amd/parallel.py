@@ -37,6 +37,10 @@ def broadcast_parameters(module, src=0):
         o += n
 
 
+def _capturing(p):
+    return p.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
 class GradBucket:
     """Gradient exchange of data-parallel training: ONE persistent flat fp32 buffer, cut into buckets of about
     `bucket_bytes` in REVERSE registration order (the order backward produces gradients in), each bucket all-reduced
@@ -44,12 +48,23 @@ class GradBucket:
     `.grad` in place), so nothing is copied in or out around the collectives as long as the optimiser keeps them
     (`zero_grad(set_to_none=False)`); a gradient that was dropped or replaced is copied in and re-attached.
 
-    overlap=True (default): a post-accumulate hook on every parameter launches its bucket's all-reduce (async) the
-    moment the bucket's last gradient has been written, i.e. WHILE backward is still computing the earlier layers -
-    SURVEY.md section 8(e): the 57 MB gradient of the QC model is dominated by the edge encoder, whose bucket can travel
-    while the message rounds are still in backward.  One backward per step in this mode (gradient accumulation over
-    several backward calls: overlap=False).  `allreduce_mean()` / `allreduce_sum()` finish the step: they launch what
-    is still pending, wait, and scale.
+    overlap=True (default): a post-accumulate hook on every parameter marks its bucket; a bucket's all-reduce is
+    launched (async) once its last gradient has been written AND every bucket before it has been launched, i.e. WHILE
+    backward is still computing the earlier layers - SURVEY.md section 8(e): the 57 MB gradient of the QC model is
+    dominated by the edge encoder, whose bucket can travel while the message rounds are still in backward.  One
+    backward per step in this mode (gradient accumulation over several backward calls: overlap=False).
+    `allreduce_mean()` / `allreduce_sum()` finish the step: they launch what is still pending, wait, and scale.
+
+    Launch order is the bucket index order ON EVERY RANK, whatever order the gradients arrive in and whichever
+    parameters received none on this rank: RCCL pairs collectives by issue order, so a bucket that is complete here
+    but behind one that is still open (a parameter unused on this rank) waits for `_finish`, which launches the rest
+    in index order.  (Round 2 launched a bucket the moment it completed: ranks with different unused parameters then
+    issued equal-sized buckets in different orders and summed the wrong slices - tests/test_parallel_gloo.py,
+    `test_rank_local_parameter_alone_in_a_middle_bucket`.)
+
+    Inside a HIP-graph capture (qc_step.CapturedQCStep) the hooks only record which parameters were written: no
+    re-pointing of `.grad`, no collective and no host read may be baked into the captured region; the exchange then
+    runs after the replay (`allreduce_mean(assume_all=True)`).
 
     Parameters without a gradient: counted as zero on this rank; a parameter that received no gradient on ANY rank
     gets `.grad = None` back, as in a single-process run (the optimiser then skips it instead of applying weight
@@ -103,6 +118,8 @@ class GradBucket:
         self._seen = [False] * len(self.params)
         self._work = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._next = 0                        # first bucket not launched yet: launches go strictly in index order
+        self.launch_log = []                  # bucket indices in issue order of the current step (tests read it)
 
     def _attach(self, i):
         p, v = self.params[i], self.views[i]
@@ -118,13 +135,14 @@ class GradBucket:
             if _alone() or self._seen[i]:
                 return
             self._seen[i] = True
-            if not self.overlap:
+            if not self.overlap or _capturing(_param):
                 return
             self._attach(i)
             b = self._bucket_of[i]
             self._ready[b] += 1
-            if self._ready[b] == len(self.buckets[b][3]):
-                self._launch(b)
+            # drain: bucket b goes out only once 0 .. b-1 have gone out; a completed bucket behind an open one waits
+            while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next][3]):
+                self._launch(self._next)
         return hook
 
     def _launch(self, b):
@@ -138,7 +156,10 @@ class GradBucket:
         else:
             self.buf[hg:hi].copy_(torch.tensor(flags, dtype=torch.float32))
         chunk = self.buf[lo:hi]
+        assert b == self._next, "bucket all-reduces are issued in index order on every rank"
         self._launched[b] = True
+        self._next = b + 1
+        self.launch_log.append(b)
         if dist.get_backend() == "gloo" and chunk.is_cuda:      # one-box rehearsal: staged through the host
             host = chunk.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -161,9 +182,8 @@ class GradBucket:
             return
         if assume_all:
             self._seen = [p.grad is not None for p in self.params]
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
+        for b in range(self._next, len(self.buckets)):
+            self._launch(b)
         for w in self._work:
             if w is not None:
                 w.wait()

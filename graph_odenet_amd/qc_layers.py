@@ -148,10 +148,18 @@ class _GruUpdateFn(torch.autograd.Function):
         return dx, dm, dw_ih, dw_hh, db_ih, db_hh
 
 
+GRU_MAX_H = 640                  # 8 rows x 8h floats of LDS per block (csrc/gru.hip) must fit 160 KB
+GRU_MAX_ROWS = 65535 * 64        # grid.y of the weight-gradient launch (64-row chunks)
+
+
 def gru_update(cell, x, m):
-    """cell(torch.cat([x, m], 1), x) for cell = nn.GRUCell(2h, h), fused."""
+    """cell(torch.cat([x, m], 1), x) for cell = nn.GRUCell(2h, h), fused.  Outside the fused kernels' limits (h > 640,
+    more than 4.19 M rows) the update is the module's own call on the
+    concatenated input - the reference's line (QC/mpnn.py:30) on the GPU library path - instead of an error."""
     if cell.input_size != 2 * cell.hidden_size or x.shape[1] != cell.hidden_size:
         raise ValueError("gru_update: the update cell must be GRUCell(2h, h) on n x h states")
+    if cell.hidden_size > GRU_MAX_H or x.shape[0] > GRU_MAX_ROWS:
+        return cell(torch.cat([x, m], 1), x)
     return _GruUpdateFn.apply(x, m, cell.weight_ih, cell.weight_hh, getattr(cell, "bias_ih", None),
                               getattr(cell, "bias_hh", None))
 

@@ -17,7 +17,13 @@ DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 or call hipgraph.prefer_safe_graphs() before th
 runs eagerly and `capture_disabled_reason` says why.
 
 With torch.distributed (one rank per GPU) only forward + backward are captured; the gradient all-reduce and the optimiser
-step run eagerly after the replay (`exchange=` callback).
+step run eagerly after the replay (`exchange=` callback, e.g. `lambda: bucket.allreduce_mean(assume_all=True)`).  A
+`parallel.GradBucket` on the same model must not launch anything inside the capture: its hooks notice a capturing
+stream and only record (parallel.py), so either `overlap` setting is safe; the gradients of a captured bucket are
+graph-owned tensors, copied into the exchange buffer by `allreduce_mean` after the replay.
+
+`n_graphs` (optional): number of graphs of the batch including the dummy graph of a padded batch; when omitted it is
+taken from `qc_batch.prepare`'s annotation of `batch`, else read from `batch[-1]` (one host synchronisation per call).
 """
 import torch
 
@@ -66,12 +72,18 @@ class CapturedQCStep:
         qc_layers._cache.clear()
         qc_models._seg_cache.clear()
 
-    def __call__(self, x, ef, Esrc, Etgt, batch, target):
-        key = (tuple(x.shape), tuple(ef.shape), tuple(target.shape))
+    def __call__(self, x, ef, Esrc, Etgt, batch, target, n_graphs=None):
+        # a bucket's static buffers and captured graph are valid for exactly one layout: shapes, the Etgt FORM (dense
+        # N x E matrix or int64[E] index), index dtypes, and the number of graphs incl. the dummy graph of a padded batch
+        if n_graphs is None:
+            n_graphs = getattr(batch, "_gode_n_graphs", None)       # qc_batch.prepare leaves it on the tensor
+        if n_graphs is None:
+            n_graphs = target.shape[0] + (1 if batch.numel() and int(batch[-1]) >= target.shape[0] else 0)
+        key = (tuple(x.shape), tuple(ef.shape), tuple(target.shape), tuple(Etgt.shape), Etgt.dtype, Esrc.dtype,
+               batch.dtype, int(n_graphs))
         b = self.buckets.get(key)
         if b is None:
-            n_graphs = target.shape[0] + (1 if batch.numel() and int(batch[-1]) >= target.shape[0] else 0)
-            b = self.buckets[key] = _Bucket(x, ef, Esrc, Etgt, batch, target, n_graphs)
+            b = self.buckets[key] = _Bucket(x, ef, Esrc, Etgt, batch, target, int(n_graphs))
         b.load(x, ef, Esrc, Etgt, batch, target)
         if b.graph is None:
             if self.capture_disabled_reason is None and b.seen >= self.warmup:

@@ -116,6 +116,8 @@ def new_record(args, hi):
 
 
 def main(argv=None):
+    from . import hipgraph
+    hipgraph.prefer_safe_graphs()                        # an explicit program-level choice, not an import side effect
     args = build_parser().parse_args(argv)
     if args.no_cuda or not torch.cuda.is_available():
         raise SystemExit("graph_odenet_amd.train_layers needs the GPU: the hot path has no CPU implementation")
