@@ -249,8 +249,7 @@ def main():
                 "compulsory_bytes_per_launch": b_min,
                 "frac_with_epilogue_operands": round(tot_bytes / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "epilogue_operand_arrays_per_launch": round(sum(xx[i] for i in sel) / len(sel), 3),
-                "node_order": "renumbered (measured faster: %.3f -> %.3f ms per plain product)" % g.__dict__["_tuned_times"]
-                              if g_run is not g else "as given"}
+                "node_order": dict(g.__dict__["_tuned_info"][(args.hidden, "auto")])}
     # dense kernels (exact-fp32 MFMA): 2*N*d*d flop per launch against the fp32 matrix peak.  Durations are AS
     # SCHEDULED: in the adjoint the VJP runs beside the weight gradient / next forward product on a second stream.
     dense = None

@@ -108,50 +108,76 @@ def _by_ptr(ptr_value, candidates):
     raise RuntimeError("rk4 driver returned an unknown buffer")
 
 
-# ---- node renumbering of large graphs ("operand placement") ---------------------------------
-# The aggregation gathers 512-byte operand rows; which rows are hot is a property of the graph, where they sit in
-# memory is ours to choose.  On the R-MAT benchmark graph the hubs are the ids with few one-bits (0, 1, 2, 4, ...):
-# their rows share their low address bits, and the same product runs 13-15 % faster with the nodes renumbered hubs
-# first (or at random) - tools/dev/relabel_probe.py.  Whether a renumbering pays depends on the graph (it can cost
-# locality a clustered numbering already has), so it is MEASURED once per graph: three launches each way at the ODE
-# block's width, before the first solve.  Results are bit-identical either way (CSRGraph.relabel).
+# ---- node renumbering of large graphs ("Node order of large graphs") --------------------------
+# The aggregation gathers d*4-byte operand rows; which rows are hot is a property of the graph, where they sit in
+# memory is ours to choose.  On the R-MAT benchmark graph the hubs are the ids with few one-bits (0, 1, 2, 4, ...): their
+# rows share their low address bits, and the same product runs 13-15 % faster with the nodes renumbered hubs first
+# (tools/dev/relabel_probe.py; bit-identical state either way: CSRGraph.relabel).
+#
+# Round 2 decided this with a stopwatch (three timed launches each way, 4 % margin, 1 GB of scratch, a host
+# synchronisation) - the same inputs could then integrate on different node orders on different boxes, and parameter
+# gradients (sums over the nodes in row order) differ by 2e-5 between the orders.  Since round 3 the decision is a
+# function of the graph alone, in integer arithmetic:
+#
+#   imbalance(order) = max over residues r of  #{gathers whose operand row id = r  (mod m)}  /  (gathers / m),
+#                      m = 32 KiB / row bytes (64 at d = 128), over the gathers of A and of A^T
+#
+# i.e. how unevenly the gathered rows fall on the address bits just above a row.  R-MAT as generated: 10.8; the same
+# graph hubs-first: 1.14; a uniform random graph: 1.005.  `node_order`:
+#   "auto"   - renumber hubs-first when the operand is past the caches (>= 64 MB, >= 2^21 non-zeros), the given order's
+#              imbalance is >= RELABEL_MIN_IMBALANCE and the hubs-first order at least halves it;
+#   "given"  - never;   "degree" - always (any size).
+# The decision is cached on the graph per (d, node_order) and reported by bench.py.
 RELABEL_MIN_OPERAND_BYTES = 64 << 20      # below this the operand sits in the L2s / the Infinity Cache anyway
 RELABEL_MIN_NNZ = 1 << 21
-RELABEL_MIN_GAIN = 0.04
+RELABEL_MIN_IMBALANCE = 2.0
+NODE_ORDERS = ("auto", "given", "degree")
 
 
-def tuned_graph(graph, d):
+def gather_imbalance(graph, d, inverse=None):
+    """The statistic above for `graph` (square CSR) at row width d, optionally under a renumbering (inverse[old] = new).
+    Exact integer counts -> the same number on every box.  One device->host copy of 2 m counters."""
+    m = max(8, min(4096, (32 << 10) // (4 * d)))
+    col = graph.col.to(torch.int64)
+    rp = graph.rowptr.to(torch.int64)
+    deg = rp[1:] - rp[:-1]                                  # row r is gathered deg(r) times by the product with A^T
+    rows = torch.arange(graph.n_rows, device=col.device)
+    if inverse is not None:
+        col, rows = inverse[col], inverse
+    h_a = torch.bincount(col % m, minlength=m)
+    h_t = torch.zeros(m, dtype=torch.int64, device=col.device).index_add_(0, rows % m, deg)
+    h = torch.stack([h_a, h_t]).tolist()
+    return max(max(hh) * m / max(sum(hh), 1) for hh in h)
+
+
+def tuned_graph(graph, d, node_order="auto"):
     """(graph the ODE block should integrate on, order, inverse) - order is None when the graph is used as given.
-    y' = y[order] are the state rows in the renumbered graph; y = y'[inverse]."""
-    hit = graph.__dict__.get("_tuned")
+    y' = y[order] are the state rows in the renumbered graph; y = y'[inverse].  Deterministic in (graph, d, node_order)."""
+    if node_order not in NODE_ORDERS:
+        raise ValueError("node_order must be one of %s, got %r" % (NODE_ORDERS, node_order))
+    cache = graph.__dict__.setdefault("_tuned", {})
+    hit = cache.get((d, node_order))
     if hit is not None:
         return hit
     res = (graph, None, None)
-    big = graph.n_rows * d * 4 >= RELABEL_MIN_OPERAND_BYTES and graph.n_rows == graph.n_cols and graph.nnz >= RELABEL_MIN_NNZ
-    if big and not getattr(graph, "is_partitioned", False) and not torch.cuda.is_current_stream_capturing():
+    info = {"node_order": node_order, "renumbered": False}
+    square = graph.n_rows == graph.n_cols and not getattr(graph, "is_partitioned", False)
+    big = graph.n_rows * d * 4 >= RELABEL_MIN_OPERAND_BYTES and graph.nnz >= RELABEL_MIN_NNZ
+    if square and node_order != "given" and (node_order == "degree" or big) \
+            and not torch.cuda.is_current_stream_capturing():
         order = graph.degree_order()
-        cand = graph.relabel(order)
-        X = torch.randn(graph.n_rows, d, device=graph.device)
-        Y = torch.empty_like(X)
-
-        def cost(g):
-            for gg in (g, g.transpose()):
-                ops.spmm(gg, X, out=Y)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-            ev[0].record()
-            for _ in range(3):
-                ops.spmm(g, X, out=Y)
-                ops.spmm(g.transpose(), X, out=Y)
-            ev[1].record()
-            ev[1].synchronize()
-            return ev[0].elapsed_time(ev[1])
-        t_given, t_new = cost(graph), cost(cand)
-        graph.__dict__["_tuned_times"] = (t_given / 6, t_new / 6)
-        if t_new < (1.0 - RELABEL_MIN_GAIN) * t_given:
-            inverse = torch.empty_like(order)
-            inverse[order] = torch.arange(graph.n_rows, device=graph.device)
-            res = (cand, order, inverse)
-    graph.__dict__["_tuned"] = res
+        inverse = torch.empty_like(order)
+        inverse[order] = torch.arange(graph.n_rows, device=graph.device)
+        take = node_order == "degree"
+        if not take:
+            given, hubs = gather_imbalance(graph, d), gather_imbalance(graph, d, inverse)
+            info.update(imbalance_given=round(given, 4), imbalance_hubs_first=round(hubs, 4))
+            take = given >= RELABEL_MIN_IMBALANCE and hubs <= 0.5 * given
+        if take:
+            res = (graph.relabel(order), order, inverse)
+            info["renumbered"] = True
+    graph.__dict__.setdefault("_tuned_info", {})[(d, node_order)] = info
+    cache[(d, node_order)] = res
     return res
 
 

@@ -97,6 +97,7 @@ class ODEfunc(nn.Module):
 
     _gode_counts_nfe = True
     layer_cls = FixedGraphConvolution       # variants (dense_paper.py) substitute their own initialisation
+    node_order = "auto"                     # gcn_ode.tuned_graph: "auto" | "given" | "degree" (set by ODEBlock)
 
     def __init__(self, dim):
         super(ODEfunc, self).__init__()
@@ -141,9 +142,10 @@ class ODEfunc(nn.Module):
         order = [names[id(p)] for p in plist]
         if getattr(spec.graph, "is_partitioned", False):
             return GcnOdePartField(spec, sh), (lambda: GcnOdePartAdjointField(spec, sh, order)), tuple(plist)
-        # large graphs: integrate on the renumbering of the graph that was measured faster (gcn_ode.tuned_graph); the
-        # solver permutes the state rows on entry and exit, everything in between is row-local or the SpMM itself
-        spec.graph, rows, inverse = tuned_graph(spec.graph, spec.d)
+        # large graphs whose hot rows crowd a few address residues: integrate on the hubs-first renumbering
+        # (gcn_ode.tuned_graph - a deterministic function of the graph and `node_order`); the solver permutes the
+        # state rows on entry and exit, everything in between is row-local or the SpMM itself
+        spec.graph, rows, inverse = tuned_graph(spec.graph, spec.d, self.node_order)
 
         def mark(field):
             field.row_order, field.row_inverse = rows, inverse
@@ -183,9 +185,14 @@ class ODEfunc2(nn.Module):
 class ODEBlock(nn.Module):
     """y(1) of y' = odefunc(t, y), y(0) = x (reference: GCN/models.py:181-201)."""
 
-    def __init__(self, odefunc, tol=1e-5, method=None, step_size=None):
+    def __init__(self, odefunc, tol=1e-5, method=None, step_size=None, node_order=None):
         super(ODEBlock, self).__init__()
         self.odefunc = odefunc
+        if node_order is not None:            # extension: "auto" (default rule) | "given" | "degree" (gcn_ode.tuned_graph)
+            from .gcn_ode import NODE_ORDERS
+            if node_order not in NODE_ORDERS:
+                raise ValueError("ODEBlock: node_order must be one of %s" % (NODE_ORDERS,))
+            odefunc.node_order = node_order
         self.integration_time = torch.tensor([0, 1]).float()
         self.tol = tol
         self.method = method

@@ -144,33 +144,56 @@ def _numel(field, y, c):
     return g(c, y[c]) if g is not None else y[c].numel()
 
 
-def _rms_scaled(terms_per_comp, y, rtol, atol, field=None):
-    """sqrt( sum_c sum_i (v_ci / (atol + rtol*|y_ci|))^2 / sum_c numel_c )  -> python float (syncs)."""
-    outs = [ops.rk_scaled_sumsq(terms_per_comp[c], y[c], rtol, atol) for c in range(len(y))]
+# Norm of the initial-step heuristic (Hairer-Norsett-Wanner II.4) on a state of several tensors - the adjoint solve's
+# (y, a, a_t, a_theta); a one-tensor forward solve is the same either way:
+#   "per_tensor" (default): d0, d1, d2 are formed per state tensor (RMS each) and combined as
+#                 h0 = 0.01 * max_i(d0_i / d1_i),  h1 = (0.01 / max_i(d1_i, d2_i))^(1/5),  guards on max_i d0_i, max_i d1_i -
+#                 the form torchdiffeq 0.0.x (the reference's era) is publicly understood to use, and consistent with
+#                 its per-tensor error ratio; NOT checkable here (torchdiffeq is absent: oracle/solver_ref.py);
+#   "pooled":     one RMS over all elements of all tensors (rounds 1-2 of this build; what a single flat state gives).
+# The two differ in the FIRST attempted step of an adjoint solve only (tests/test_solver_oracle.py shows a 4-tensor
+# state where they do); every later step is set by the controller from per-tensor error ratios in both.
+INITIAL_STEP_NORM = "per_tensor"
+
+
+def _div(a, b):
+    if b == 0.0:
+        return float("nan") if a == 0.0 else float("inf")
+    return a / b
+
+
+def _rms_groups(terms_per_comp, y, rtol, atol, field, pooled):
+    """RMS of v / (atol + rtol*|y|) per ratio group (per state tensor as torchdiffeq sees it), or one pooled value.
+    -> list of python floats (one device->host sync)."""
+    nc = len(y)
+    outs = [ops.rk_scaled_sumsq(terms_per_comp[c], y[c], rtol, atol) for c in range(nc)]
+    sums = torch.cat(outs).tolist()
     red = getattr(field, "reduce_error_sums", None)
     if red is not None:
-        tot = sum(red(torch.cat(outs).tolist()))
-    else:
-        tot = torch.cat(outs).sum().item()
-    n = sum(_numel(field, y, c) for c in range(len(y)))
-    return math.sqrt(tot / n)
+        sums = red(sums)
+    groups = [list(range(nc))] if pooled else (getattr(field, "ratio_groups", None) or [[c] for c in range(nc)])
+    return [math.sqrt(sum(sums[c] for c in grp) / sum(_numel(field, y, c) for c in grp)) for grp in groups]
 
 
 def _initial_step(field, t0, y, f0, rtol, atol, sgn, scratch_y, scratch_f, stats):
+    if INITIAL_STEP_NORM not in ("per_tensor", "pooled"):
+        raise ValueError("solver.INITIAL_STEP_NORM must be 'per_tensor' or 'pooled'")
+    pooled = INITIAL_STEP_NORM == "pooled"
     nc = len(y)
-    d0 = _rms_scaled([[(1.0, y[c])] for c in range(nc)], y, rtol, atol, field)
-    d1 = _rms_scaled([[(1.0, f0[c])] for c in range(nc)], y, rtol, atol, field)
-    if d0 < 1e-5 or d1 < 1e-5:
+    d0 = _rms_groups([[(1.0, y[c])] for c in range(nc)], y, rtol, atol, field, pooled)
+    d1 = _rms_groups([[(1.0, f0[c])] for c in range(nc)], y, rtol, atol, field, pooled)
+    if max(d0) < 1e-5 or max(d1) < 1e-5:
         h0 = 1e-6
     else:
-        h0 = 0.01 * d0 / d1
+        h0 = 0.01 * max(_div(a, b) for a, b in zip(d0, d1))
     field.eval(t0 + sgn * h0, [[(1.0, y[c]), (sgn * h0, f0[c])] for c in range(nc)], scratch_f)
     stats.nfe += 1
-    d2 = _rms_scaled([[(1.0, scratch_f[c]), (-1.0, f0[c])] for c in range(nc)], y, rtol, atol, field) / h0
-    if d1 <= 1e-15 and d2 <= 1e-15:
+    d2 = [v / h0 for v in _rms_groups([[(1.0, scratch_f[c]), (-1.0, f0[c])] for c in range(nc)], y, rtol, atol, field,
+                                      pooled)]
+    if max(d1) <= 1e-15 and max(d2) <= 1e-15:
         h1 = max(1e-6, h0 * 1e-3)
     else:
-        h1 = (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+        h1 = (0.01 / max(d1 + d2)) ** (1.0 / 5.0)
     return min(100 * h0, h1)
 
 

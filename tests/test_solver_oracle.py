@@ -96,3 +96,56 @@ def test_dopri5_step_equals_scipy_rk45_step():
         assert 0.05 < e_ours / e_scipy < 20
         for s in range(7):
             assert np.abs(k[s][0].numpy() - K[s]).max() < 1e-14
+
+
+def test_initial_step_norm_per_tensor_vs_pooled_on_a_four_tensor_state():
+    """The adjoint solve integrates FOUR tensors (y, a, a_t, a_theta).  The initial-step heuristic's norm is an
+    explicit option: "per_tensor" (default; torchdiffeq 0.0.x as publicly understood: per-tensor
+    RMS values, h0 = 0.01 max_i d0_i/d1_i, h1 = (0.01 / max(d1 + d2))^(1/5)) against "pooled" (one RMS over everything,
+    rounds 1-2).  A state whose tensors differ in size and scale separates them; the expected numbers are formed by
+    hand from the definition.  graph_odenet_amd/solver.py mirrors the same switch (GPU test:
+    tests/test_gpu_gcn.py::test_initial_step_norm_option_matches_oracle)."""
+    rtol = atol = 1e-5
+    # linear field f_i(y) = lam_i * y_i per tensor: f(t0 + h0) - f0 = lam_i * h0 * f0_i, everything in closed form
+    sizes = (1000, 1000, 1, 50)
+    vals = (1.0, 1e-2, 1.0, 0.5)
+    lam = (-0.5, -40.0, -400.0, -2.0)             # the stiff direction sits in the ONE-element tensor (as a_t does)
+    y0 = tuple(torch.full((n,), v, dtype=torch.float64) for n, v in zip(sizes, vals))
+    func = lambda t, ys: tuple(l * y for l, y in zip(lam, ys))          # noqa: E731
+    t0 = torch.tensor(0.0, dtype=torch.float64)
+    f0 = func(t0, y0)
+    got = {nm: S._select_initial_step(func, t0, y0, 4, rtol, atol, f0, norm=nm) for nm in ("per_tensor", "pooled")}
+    # by hand
+    scale = [atol + abs(v) * rtol for v in vals]
+    d0 = [abs(v) / s for v, s in zip(vals, scale)]
+    d1 = [abs(l * v) / s for l, v, s in zip(lam, vals, scale)]
+    h0 = 0.01 * max(a / b for a, b in zip(d0, d1))                          # = 0.01 / min |lam| = 0.02
+    assert abs(h0 - 0.02) < 1e-12
+    d2 = [abs(l * h0 * l * v) / s / h0 for l, v, s in zip(lam, vals, scale)]
+    want_pt = min(100 * h0, (0.01 / max(d1 + d2)) ** 0.2)
+    n_all = sum(sizes)
+    pool = lambda ds: math.sqrt(sum(n * d * d for n, d in zip(sizes, ds)) / n_all)      # noqa: E731
+    p0, p1 = pool(d0), pool(d1)
+    h0p = 0.01 * p0 / p1
+    p2 = pool([abs(l * h0p * l * v) / s for l, v, s in zip(lam, vals, scale)]) / h0p
+    want_pool = min(100 * h0p, (0.01 / max(p1, p2)) ** 0.2)
+    assert abs(got["per_tensor"] - want_pt) < 1e-9 * want_pt
+    assert abs(got["pooled"] - want_pool) < 1e-9 * want_pool
+    assert abs(got["per_tensor"] - got["pooled"]) > 0.2 * got["pooled"]    # they really differ on such a state
+    # one tensor: identical
+    one = (y0[0],)
+    f1 = lambda t, ys: (lam[0] * ys[0],)                                   # noqa: E731
+    a = S._select_initial_step(f1, t0, one, 4, rtol, atol, f1(t0, one), norm="per_tensor")
+    b = S._select_initial_step(f1, t0, one, 4, rtol, atol, f1(t0, one), norm="pooled")
+    assert a == b
+    assert S.INITIAL_STEP_NORM == "per_tensor"
+    # the option reaches the solves: a backward solve over a tuple state takes a different first step
+    seqs = {}
+    for nm in ("per_tensor", "pooled"):
+        S.INITIAL_STEP_NORM, S.TRACE = nm, []
+        try:
+            S.odeint(func, y0, torch.tensor([0.0, 0.3], dtype=torch.float64), rtol, atol)
+            seqs[nm] = S.TRACE[0][0][0]
+        finally:
+            S.INITIAL_STEP_NORM, S.TRACE = "per_tensor", None
+    assert abs(seqs["per_tensor"] - want_pt) < 1e-9 and abs(seqs["pooled"] - want_pool) < 1e-9
