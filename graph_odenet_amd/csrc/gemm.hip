@@ -21,86 +21,15 @@
 #include <mutex>
 #include <utility>
 #include "common.h"
+#include "dense_common.h"
+#include "dense_pc.h"
 #include "options.h"
 #include "prof.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int kMaxBlocks = 512;   // 2 blocks per CU
 constexpr int64_t kWgradSplitMinRows = 65536;   // below: the fp32-MFMA weight-gradient kernel (2 blocks per CU, 32 KB of LDS each)
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// GroupNorm statistics of the 4 values a lane holds.  CG = channels per group.
-// CG = 1,2,4: the group is inside the float4.  CG = 8,16: spread over lane groups
-// g (xor 16 / xor 32).  mean/rstd are returned per component.
-// 1/sqrt(v): v_rsq_f32 (1 ulp) + one Newton step -> within 1 ulp of the correctly rounded value; the
-// IEEE sqrtf + divide sequence it replaces costs ~40 dependent VALU instructions per group.
-__device__ __forceinline__ float rsqrt_nr(float v) {
-    float r = __builtin_amdgcn_rsqf(v);
-    r = r * fmaf(-0.5f * v * r, r, 1.5f);
-    return r;
-}
-
-template <int CG>
-__device__ __forceinline__ void gn_stats(const float4 x, float eps, float4& mean, float4& rstd) {
-    if (CG == 1) {
-        mean = x;
-        const float r = rsqrt_nr(eps);
-        rstd = make_float4(r, r, r, r);
-    } else if (CG == 2) {
-        const float m0 = (x.x + x.y) * 0.5f, m1 = (x.z + x.w) * 0.5f;
-        const float v0 = ((x.x - m0) * (x.x - m0) + (x.y - m0) * (x.y - m0)) * 0.5f;
-        const float v1 = ((x.z - m1) * (x.z - m1) + (x.w - m1) * (x.w - m1)) * 0.5f;
-        const float r0 = rsqrt_nr(v0 + eps), r1 = rsqrt_nr(v1 + eps);
-        mean = make_float4(m0, m0, m1, m1);
-        rstd = make_float4(r0, r0, r1, r1);
-    } else {
-        float s = (x.x + x.y) + (x.z + x.w);
-        if (CG >= 8) s += __shfl_xor(s, 16, 64);
-        if (CG >= 16) s += __shfl_xor(s, 32, 64);
-        const float m = s * (1.0f / CG);
-        const float dx = x.x - m, dy = x.y - m, dz = x.z - m, dw = x.w - m;
-        float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        if (CG >= 8) q += __shfl_xor(q, 16, 64);
-        if (CG >= 16) q += __shfl_xor(q, 32, 64);
-        const float r = rsqrt_nr(q * (1.0f / CG) + eps);
-        mean = make_float4(m, m, m, m);
-        rstd = make_float4(r, r, r, r);
-    }
-}
-
-// y = x*scale + shift with scale = rstd*gamma, shift = beta - mean*scale (ATen's CPU form,
-// aten/src/ATen/native/cpu/group_norm_kernel.cpp), rounded step by step (no contraction).
-__device__ __forceinline__ float gn_apply1(float x, float mean, float rstd, float gam, float bet) {
-    const float scale = __fmul_rn(rstd, gam);
-    const float shift = __fsub_rn(bet, __fmul_rn(mean, scale));
-    return __fadd_rn(__fmul_rn(x, scale), shift);
-}
-
-template <int CG>
-__device__ __forceinline__ float4 gn_forward(const float4 x, float eps, const float* gamma, const float* beta, int c0) {
-    if (CG == 0) return x;
-    float4 mean, rstd;
-    gn_stats<CG>(x, eps, mean, rstd);
-    float4 gm = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gamma) gm = ld4(gamma + c0);
-    if (beta) bt = ld4(beta + c0);
-    return make_float4(gn_apply1(x.x, mean.x, rstd.x, gm.x, bt.x), gn_apply1(x.y, mean.y, rstd.y, gm.y, bt.y),
-                       gn_apply1(x.z, mean.z, rstd.z, gm.z, bt.z), gn_apply1(x.w, mean.w, rstd.w, gm.w, bt.w));
-}
-
-template <int CG>
-__device__ __forceinline__ float4 gn_forward_v(const float4 x, float eps, const float4 gm, const float4 bt) {
-    if (CG == 0) return x;
-    float4 mean, rstd;
-    gn_stats<CG>(x, eps, mean, rstd);
-    return make_float4(gn_apply1(x.x, mean.x, rstd.x, gm.x, bt.x), gn_apply1(x.y, mean.y, rstd.y, gm.y, bt.y),
-                       gn_apply1(x.z, mean.z, rstd.z, gm.z, bt.z), gn_apply1(x.w, mean.w, rstd.w, gm.w, bt.w));
-}
 
 // Block prologue: W1 (d x d, without the time row) -> LDS with row stride d+4, as 16-byte loads that are all
 // in flight together (TRANSPOSE: Wlds[n][i] = W1[i][n] for the VJP); gamma / beta / time row -> LDS vectors.
@@ -975,16 +904,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(LinComb xin, int n_rows, 
 // lane feeds to a 16x16x32 MFMA): chunk(piece, g, c) at ((piece*4 + g)*144 + (c&3)*36 + (c>>2)) - the staging threads
 // (4 rows x 4 columns each) write 8-byte halves at consecutive chunks, the operand reads of 16 lanes cover all 64 banks.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void split3_trunc(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(h);            // exact: the low 16 bits of x's significand
-    m = __float_as_uint(r1) & 0xffff0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m));       // exact, at most 8 significant bits: its low half is zero
-}
-// the bf16 halves (upper 16 bits) of four fp32 words -> 8 bytes
-__device__ __forceinline__ uint2 pack_hi16x4(unsigned u0, unsigned u1, unsigned u2, unsigned u3) {
-    return make_uint2(__builtin_amdgcn_perm(u1, u0, 0x07060302u), __builtin_amdgcn_perm(u3, u2, 0x07060302u));
-}
 // one column of a staging thread: its 4 consecutive rows -> the three piece arrays
 __device__ __forceinline__ void stage_col4(char* chunk0 /* piece 0 */, int piece_bytes, float v0, float v1, float v2, float v3) {
     unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
@@ -1000,11 +919,8 @@ __device__ __forceinline__ void stage_col4(char* chunk0 /* piece 0 */, int piece
 // staged one, so that request is in flight for two tile periods while the OTHER group stages: two tiles (64 KB) per CU
 // are always on their way, held by different waves.  (Two tiles in flight in ONE wave's registers do not work: hipcc
 // takes the wait count at the loop head as the minimum over all paths and ends up draining the tile just requested;
-// the same happens behind a run-time switch on the term count, hence the template parameter NX.)
-// Block barrier that orders LDS traffic only: __syncthreads() also drains the wave's outstanding GLOBAL loads
-// (s_waitcnt vmcnt(0)), which would turn every barrier into a wait for the tile being prefetched.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
+// the same happens behind a run-time switch on the term count, hence the template parameter NX.)  The block barrier
+// is lds_barrier() (dense_common.h): LDS traffic only, outstanding global loads stay in flight across it.
 template <int CG, int NT, int NX>   // NX = number of terms of x held raw in the prefetch registers (1..4); 0 = any count, combined at load
 __global__ __launch_bounds__(1024, 1) void wgrad_split_kernel(LinComb xin, int n_rows, float eps,
                                                              const float* __restrict__ gamma,
@@ -1919,11 +1835,18 @@ extern "C" int gode_gn_time_gemm_xout_f32(const gode_lincomb_t* xin, int64_t n_r
     const int cg = fast_cg(d_in, d_out, groups);
     const bool al = lincomb_aligned16(xin) && !(((uintptr_t)S) & 15) && !(((uintptr_t)W) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15));
+    // producer / consumer form on the bf16 matrix cores (gemm_pc.hip): fwd_pc bit 0 = launches of <= 2 terms, bit 1 = 3
+    // and more terms (with or without x_out)
+    if (cg >= 0 && al && d_in == 128 && (n_rows >= kWgradSplitMinRows || gode_opt_wgrad_split_small()) &&
+        ((lc.n <= 2 && !x_out) ? (gode_opt_fwd_pc() & 1) : (gode_opt_fwd_pc() & 2))) {
+        rc = gode_pc_fwd_launch(lc, n_rows, eps, gamma, beta, W, has_time, t, S, x_out, cg, s);
+        if (rc != GODE_E_UNSUPPORTED) return rc;
+    }
     if (cg >= 0 && al && d_in == 128 && !x_out && (gode_opt_gemm_split() == 1 || (gode_opt_gemm_split() == 2 && lc.n <= 2 && n_rows >= 65536))) {
         const size_t lds = (size_t)3 * 128 * (128 + 8) * sizeof(unsigned short) + 3 * 128 * sizeof(float);
         int64_t blocks = ((n_rows + 15) / 16 + 7) / 8; if (blocks < 1) blocks = 1; if (blocks > 256) blocks = 256;
 #define GODE_FWDS2(CGV, NXV) { rc = set_lds(gn_gemm_fwd_split_kernel<CGV, NXV>, lds); if (rc) return rc;    \
-          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1, GODE_PROF_GEMM_FWD);          \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1, GODE_PROF_GEMM_FWD | GODE_PROF_FORM_SPLIT); \
           hipLaunchKernelGGL((gn_gemm_fwd_split_kernel<CGV, NXV>), dim3((unsigned)blocks), dim3(512), lds, s, \
                              lc, (int)n_rows, eps, gamma, beta, W, has_time, t, S);                           \
           gode_prof_end(s, slot);                                                                             \
@@ -2031,12 +1954,18 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
     const bool al = lincomb_aligned16(xin) && lincomb_aligned16(pre) && !(((uintptr_t)dS) & 15) && !(((uintptr_t)dx) & 15) &&
                     (!gamma || !(((uintptr_t)gamma) & 15)) &&
                     (!dgamma_part || (!(((uintptr_t)dgamma_part) & 15) && !(((uintptr_t)dbeta_part) & 15)));
+    if ((cg == 0 || cg == 4) && al && d_in == 128 && gode_opt_bwd_pc() &&
+        (n_rows >= kWgradSplitMinRows || gode_opt_wgrad_split_small())) {
+        rc = gode_pc_bwd_launch(lc, n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part,
+                                n_part, cg, s);
+        if (rc != GODE_E_UNSUPPORTED) return rc;
+    }
     if ((cg == 0 || cg == 4) && al && d_in == 128 && gode_opt_bwd_split() &&
         (n_rows >= kWgradSplitMinRows || gode_opt_wgrad_split_small())) {
         const size_t lds = (size_t)3 * 128 * (128 + 8) * sizeof(unsigned short) + 128 * sizeof(float);
         int64_t blocks = ((n_rows + 15) / 16 + 7) / 8; if (blocks < 1) blocks = 1; if (blocks > 256) blocks = 256;
 #define GODE_BWDS(CGV) { rc = set_lds(gn_gemm_bwd_split_kernel<CGV>, lds); if (rc) return rc;                 \
-          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1 + lpre.n, GODE_PROF_GEMM_BWD);  \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1 + lpre.n, GODE_PROF_GEMM_BWD | GODE_PROF_FORM_SPLIT); \
           hipLaunchKernelGGL((gn_gemm_bwd_split_kernel<CGV>), dim3((unsigned)blocks), dim3(512), lds, s,      \
                              lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part, (int)n_part); \
           gode_prof_end(s, slot);                                                                             \
@@ -2159,7 +2088,7 @@ extern "C" int gode_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t
         const int nx = lc.n <= 2 ? lc.n : 0;            // 128 registers per wave: two raw terms at most
 #define GODE_WGS(CGV, NTV, NXV)                                                                     \
         { rc = set_lds(wgrad_split_kernel<CGV, NTV, NXV>, lds); if (rc) return rc;                  \
-          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1, GODE_PROF_WGRAD);   \
+          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1, GODE_PROF_WGRAD | GODE_PROF_FORM_PC);   \
           hipLaunchKernelGGL((wgrad_split_kernel<CGV, NTV, NXV>), dim3((unsigned)blocks), dim3(1024), lds, s, \
                              lc, (int)n_rows, eps, gamma, beta, dS, has_time, dW_part);             \
           gode_prof_end(s, slot);                                                                   \

@@ -460,6 +460,12 @@ int gode_gru_cell_f32_bwd(const float* x, const float* m, const float* w_ih, con
 #define GODE_PROF_GEMM_BWD 2
 #define GODE_PROF_WGRAD    3
 #define GODE_PROF_BWD_WGRAD 4
+/* which kernel of the family ran, OR-ed into the kind of a dense launch (kind & 0xff = family, kind >> 8 = form):
+ * exact-fp32 MFMA kernel; bf16-piece kernel, every wave loading + cutting + multiplying; bf16-piece kernel in
+ * producer / consumer form (wgrad_split_kernel, gemm_pc.hip) */
+#define GODE_PROF_FORM_FP32  (0 << 8)
+#define GODE_PROF_FORM_SPLIT (1 << 8)
+#define GODE_PROF_FORM_PC    (2 << 8)
 void* gode_prof_create(int capacity);
 void  gode_prof_destroy(void* prof);
 void  gode_prof_enable(void* prof /* NULL = off */);

@@ -399,8 +399,9 @@ def test_group_norm_2d_vs_cpu_torch(n, c, g):
 def test_split_bf16_forward_product_matches_fp32_path(n, n_terms):
     """Split-bf16 x3 variant of the d=128 forward dense product (exact 3-piece decomposition by rounding, eight piece
     products - what is dropped is below 2^-32 of a product - fp32 accumulation) against the exact-fp32 MFMA path and
-    float64.  gemm_split 1 = always, 2 (the default) = launches of at most two terms and at least 65 536 rows (the
-    others are bandwidth-bound in the fp32 kernel), 0 = never."""
+    float64.  gemm_split 1 = always, 2 = launches of at most two terms and at least 65 536 rows, 0 = never.  (Since
+    round 3 the default route of those launches is the producer / consumer kernel, fwd_pc - switched off here; its own
+    test is test_forward_product_producer_consumer.)"""
     from graph_odenet_amd import _lib, ops
     import torch.nn.functional as F
     lib = _lib.load()
@@ -416,13 +417,16 @@ def test_split_bf16_forward_product_matches_fp32_path(n, n_terms):
     ref = torch.cat([torch.full((n, 1), 0.4).double(), xn * gam.double() + bet.double()], 1) @ W.double()
     terms = [(c, t.to(dev())) for c, t in zip(coef, xs)]
     outs = {}
+    fwd_pc = lib.gode_get_option(b"fwd_pc")
     try:
+        assert lib.gode_set_option(b"fwd_pc", 0) == 0
         for mode in (0, 1, 2):
             assert lib.gode_set_option(b"gemm_split", mode) == 0 and lib.gode_get_option(b"gemm_split") == mode
             outs[mode] = ops.gn_time_gemm(terms, n, d, 32, 1e-5, gam.to(dev()), bet.to(dev()), W.to(dev()), True, 0.4).cpu()
         assert lib.gode_set_option(b"gemm_split", 3) != 0
     finally:
         lib.gode_set_option(b"gemm_split", 2)
+        lib.gode_set_option(b"fwd_pc", fwd_pc)
     scale = ref.abs().max().item()
     for mode in (0, 1, 2):
         e = (outs[mode].double() - ref).abs().max().item()
@@ -431,6 +435,63 @@ def test_split_bf16_forward_product_matches_fp32_path(n, n_terms):
         assert torch.equal(outs[2], outs[0])              # mode 2 left these launches to the fp32 kernel
     else:
         assert torch.equal(outs[2], outs[1])
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 65, 1000, 4097, 70001])
+@pytest.mark.parametrize("groups", [32, 0, 64, 128])
+def test_forward_product_producer_consumer(n, groups):
+    """csrc/gemm_pc.hip gn_gemm_fwd_pc_kernel (d = 128, option fwd_pc, the default route from 65 536 rows on): the
+    operands cut exactly into three bf16 pieces, eight piece products in fp32 on the bf16 matrix cores, consumer waves
+    with the weight slab in registers, producer waves staging 32-row tiles - against float64 and against the fp32-MFMA
+    kernel: 1-5 terms (raw prefetch registers up to 4, combined at load beyond), with and without the time row, with
+    and without x_out (which must be the fp32 path's combined input bit for bit), ragged row counts (a partly empty
+    last tile, fewer tiles than producer groups), 4 / 2 / 1 channels per GroupNorm group and no normalisation."""
+    from graph_odenet_amd import _lib, ops
+    lib = _lib.load()
+    d = 128
+    g = torch.Generator().manual_seed(n * 11 + groups)
+    xs = [torch.randn(n, d, generator=g) * (1.5 if j == 0 else 0.4) + (0.3 if j == 0 else 0.0) for j in range(5)]
+    coef = [1.0, 0.25, -0.125, 0.0625, 0.5]
+    gam, bet = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    W = torch.randn(d + 1, d, generator=g) / d ** 0.5
+    D = dev()
+    cg = d // groups if groups else 0
+    # one or two channels per group: GroupNorm amplifies the rounding of x by rstd (up to 316), in both kernels alike
+    # (SURVEY.md Q4/H5; test_gn_time_gemm_fwd_bwd_wgrad uses the same bars)
+    tol = {0: 2e-6, 4: 2e-6, 2: 4e-5, 1: 4e-4}[cg]
+    saved = lib.gode_get_option(b"fwd_pc")
+    try:
+        assert lib.gode_set_option(b"wgrad_split_small", 1) == 0
+        assert lib.gode_set_option(b"fwd_pc", 4) != 0
+        for nt in (1, 2, 3, 4, 5):
+            x = sum(c * t.double() for c, t in zip(coef[:nt], xs[:nt]))
+            xn = x
+            if groups:
+                xg = x.view(n, groups, d // groups)
+                xn = ((xg - xg.mean(2, keepdim=True)) / torch.sqrt(xg.var(2, unbiased=False, keepdim=True) + 1e-5)).view(n, d)
+                xn = xn * gam.double() + bet.double()
+            terms = [(c, t.to(D)) for c, t in zip(coef[:nt], xs[:nt])]
+            for has_time in (True, False):
+                Wd = W if has_time else W[1:].contiguous()
+                ref = (torch.cat([torch.full((n, 1), 0.4, dtype=torch.float64), xn], 1) @ W.double()) if has_time else xn @ W[1:].double()
+                scale = ref.abs().max().item() + 1e-30
+                for want_xout in (False, True):
+                    got = {}
+                    for mode in (0, 3):
+                        assert lib.gode_set_option(b"fwd_pc", mode) == 0 and lib.gode_get_option(b"fwd_pc") == mode
+                        xo = torch.full((n, d), float("nan"), device=D) if want_xout else None
+                        out = ops.gn_time_gemm(terms, n, d, groups, 1e-5, gam.to(D) if groups else None,
+                                               bet.to(D) if groups else None, Wd.to(D), has_time, 0.4, x_out=xo)
+                        got[mode] = (out.cpu(), xo.cpu() if want_xout else None)
+                        err = (got[mode][0].double() - ref).abs().max().item() / scale
+                        assert err <= tol, (n, groups, nt, has_time, want_xout, mode, err)
+                    assert (got[3][0] - got[0][0]).abs().max().item() <= 2 * tol * scale
+                    if want_xout:
+                        assert torch.equal(got[3][1], got[0][1])
+                        assert (got[3][1].double() - x).abs().max().item() <= 1e-6 * (x.abs().max().item() + 1e-30)
+    finally:
+        lib.gode_set_option(b"fwd_pc", saved)
+        lib.gode_set_option(b"wgrad_split_small", 0)
 
 
 @pytest.mark.parametrize("n", [1, 31, 33, 1000, 4097, 70001])
@@ -480,47 +541,59 @@ def test_weight_gradient_from_exact_bf16_pieces(n, groups):
     assert lib.gode_set_option(b"wgrad_split", 7) != 0            # only 0, 6, 8
 
 
-@pytest.mark.parametrize("n", [1, 33, 1000, 4097, 70001])
+@pytest.mark.parametrize("n", [1, 31, 33, 1000, 4097, 70001])
 @pytest.mark.parametrize("groups", [32, 0])
 def test_vjp_from_exact_bf16_pieces(n, groups):
-    """csrc/gemm.hip gn_gemm_bwd_split_kernel (d = 128, option bwd_split): dS and W1 cut exactly into three bf16 pieces,
-    eight piece products, fp32 accumulation, the GroupNorm backward of the fp32 kernel - against float64 autograd and
-    against the fp32-MFMA kernel: dx (with the fused pre-term and output scale), dgamma, dbeta; ragged row counts."""
+    """The VJP at d = 128 from exact bf16 pieces (dS and W1 cut three ways, eight piece products, fp32 accumulation, the
+    GroupNorm backward of the fp32 kernel) in its two forms - csrc/gemm_pc.hip gn_gemm_bwd_pc_kernel (option bwd_pc, the
+    default from 65 536 rows on: consumer waves with the weight slab in registers, producer waves staging dS) and
+    csrc/gemm.hip gn_gemm_bwd_split_kernel (option bwd_split) - against float64 autograd and against the fp32-MFMA
+    kernel: dx (with the fused pre-term and output scale), dgamma, dbeta; 1 / 2 terms of x in raw registers, 3 combined
+    at load; ragged row counts (a partly empty last 32-row tile, fewer tiles than producer groups)."""
     from graph_odenet_amd import _lib, ops
     import torch.nn.functional as F
     lib = _lib.load()
     d = 128
     g = torch.Generator().manual_seed(n * 5 + groups)
-    y, k1 = torch.randn(n, d, generator=g) * 1.5 + 0.3, torch.randn(n, d, generator=g)
+    ys = [torch.randn(n, d, generator=g) * 1.5 + 0.3, torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)]
+    cf = [1.0, 0.25, -0.5]
     dS, pre = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
     gam = torch.rand(d, generator=g) + 0.5
     W = torch.randn(d + 1, d, generator=g) / d ** 0.5
-    x = (y.double() + 0.25 * k1.double()).requires_grad_(True)
-    g64 = gam.double().requires_grad_(True)
-    b64 = torch.zeros(d, dtype=torch.float64, requires_grad=True)
-    xn = F.group_norm(x, groups, g64, b64, 1e-5) if groups else x
-    S = torch.cat([torch.full((n, 1), 0.4, dtype=torch.float64), xn], 1) @ W.double()
-    S.backward(dS.double())
-    want_dx = pre.double() + 0.5 * x.grad
     D = dev()
-    terms = [(1.0, y.to(D)), (0.25, k1.to(D))]
-    got = {}
+    modes = {"fp32": (0, 0), "split": (1, 0), "pc": (0, 1)}                  # (bwd_split, bwd_pc)
+    saved = lib.gode_get_option(b"bwd_pc")
     try:
         assert lib.gode_set_option(b"wgrad_split_small", 1) == 0
-        for mode in (0, 1):
-            assert lib.gode_set_option(b"bwd_split", mode) == 0 and lib.gode_get_option(b"bwd_split") == mode
-            dx, dg, db = ops.gn_time_gemm_bwd(terms, n, d, groups, 1e-5, gam.to(D), W.to(D), True, dS.to(D), out_scale=0.5,
-                                              pre_terms=[(1.0, pre.to(D))])
-            got[mode] = (dx.double().cpu(), dg.double().sum(0).cpu() if groups else None, db.double().sum(0).cpu() if groups else None)
+        for nt in (1, 2, 3):
+            x = sum(c * t.double() for c, t in zip(cf[:nt], ys[:nt])).requires_grad_(True)
+            g64 = gam.double().requires_grad_(True)
+            b64 = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+            xn = F.group_norm(x, groups, g64, b64, 1e-5) if groups else x
+            S = torch.cat([torch.full((n, 1), 0.4, dtype=torch.float64), xn], 1) @ W.double()
+            S.backward(dS.double())
+            terms = [(c, t.to(D)) for c, t in zip(cf[:nt], ys[:nt])]
+            for with_pre in (True, False):
+                want_dx = (pre.double() if with_pre else 0.0) + 0.5 * x.grad
+                got = {}
+                for name, (split, pc) in modes.items():
+                    assert lib.gode_set_option(b"bwd_split", split) == 0 and lib.gode_get_option(b"bwd_split") == split
+                    assert lib.gode_set_option(b"bwd_pc", pc) == 0 and lib.gode_get_option(b"bwd_pc") == pc
+                    dx, dg, db = ops.gn_time_gemm_bwd(terms, n, d, groups, 1e-5, gam.to(D), W.to(D), True, dS.to(D), out_scale=0.5,
+                                                      pre_terms=[(1.0, pre.to(D))] if with_pre else None)
+                    got[name] = (dx.double().cpu(), dg.double().sum(0).cpu() if groups else None,
+                                 db.double().sum(0).cpu() if groups else None)
+                # a GroupNorm group of four nearly equal values has rstd up to 316 and amplifies every rounding of x by it
+                # in dx (SURVEY.md Q4/H5): the bar is the 2e-5 of test_gn_time_gemm_fwd_bwd_wgrad, for all three kernels
+                sx = want_dx.abs().max().item()
+                for name in modes:
+                    assert (got[name][0] - want_dx).abs().max().item() <= 2e-5 * sx, (name, n, groups, nt)
+                    if groups:
+                        assert (got[name][1] - g64.grad).abs().max().item() <= 3e-6 * max(1.0, g64.grad.abs().max().item()) * max(1, n ** 0.5), (name, nt)
+                        assert (got[name][2] - b64.grad).abs().max().item() <= 3e-6 * max(1.0, b64.grad.abs().max().item()) * max(1, n ** 0.5), (name, nt)
+                for name in ("split", "pc"):
+                    assert (got[name][0] - got["fp32"][0]).abs().max().item() <= 2e-5 * sx
     finally:
         lib.gode_set_option(b"bwd_split", 0)
+        lib.gode_set_option(b"bwd_pc", saved)
         lib.gode_set_option(b"wgrad_split_small", 0)
-    # a GroupNorm group of four nearly equal values has rstd up to 316 and amplifies every rounding of x by it in dx
-    # (SURVEY.md Q4/H5): the bar is the 2e-5 of test_gn_time_gemm_fwd_bwd_wgrad, for both kernels
-    sx = want_dx.abs().max().item()
-    for mode in (0, 1):
-        assert (got[mode][0] - want_dx).abs().max().item() <= 2e-5 * sx, (mode, n, groups)
-        if groups:
-            assert (got[mode][1] - g64.grad).abs().max().item() <= 3e-6 * max(1.0, g64.grad.abs().max().item()) * max(1, n ** 0.5)
-            assert (got[mode][2] - b64.grad).abs().max().item() <= 3e-6 * max(1.0, b64.grad.abs().max().item()) * max(1, n ** 0.5)
-    assert (got[1][0] - got[0][0]).abs().max().item() <= 2e-5 * sx
