@@ -109,6 +109,10 @@ SIGNATURES = {
     "gode_group_norm_parts": (c_i64, [c_i64]),
     "gode_group_norm_f32_fwd": (c_i, [c_p, c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p]),
     "gode_group_norm_f32_bwd": (c_i, [c_p, c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "gode_rect_gemm_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
+    "gode_rect_gemm_nt_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
+    "gode_rect_wgrad_parts": (c_i64, [c_i64]),
+    "gode_rect_wgrad_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p]),
     "gode_wgrad_parts": (c_i64, [c_i64]),
     "gode_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
                              c_p, c_i64, c_i, c_p, c_p]),

@@ -3,6 +3,8 @@
     gn_time_linear(x, t, W, gamma, beta, groups, eps)   S = [t | GroupNorm(x)] @ W     (GCN/models.py:175-177 + layers.py:70)
     graph_aggregate(graph, S, bias, relu)                relu?(A @ S + bias)             (GCN/layers.py:71-75, models.py:178)
 
+    dense(x, W, bias)                                    x @ W (+ bias)                  (torch.mm / nn.Linear call sites)
+
 Used by modules that are not covered by a fused ODE field (ODEfunc2, stand-alone calls).
 """
 import torch
@@ -44,6 +46,33 @@ class _GnTimeLinearFn(torch.autograd.Function):
 
 def gn_time_linear(x, t, W, gamma=None, beta=None, groups=0, eps=1e-5, has_time=True):
     return _GnTimeLinearFn.apply(x, float(t), W, gamma, beta, int(groups), float(eps), bool(has_time))
+
+
+class _DenseFn(torch.autograd.Function):
+    """y = x @ W for any (K x M) weight on the fp32-MFMA kernels of csrc/rect.hip, with its autograd (dy W^T, x^T dy):
+    the `torch.mm(input, self.weight)` / nn.Linear call sites of the reference's layers outside the fused paths
+    (GCN/layers.py:32, GCN-mlp-sum/layers.py, GAT/layers.py:43-45 split per node, QC/layers.py:143)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x, W = x.contiguous(), W.contiguous()
+        ctx.save_for_backward(x, W)
+        return ops.rect_gemm(x, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        gx = ops.rect_gemm_nt(dy, W) if ctx.needs_input_grad[0] else None
+        gw = ops.rect_wgrad(x, dy) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def dense(x, W, bias=None):
+    """x @ W (+ bias): W is (in, out).  For an nn.Linear pass `lin.weight.t()` (the transposed view is made contiguous
+    once per call: weights are small next to the activations)."""
+    y = _DenseFn.apply(x, W)
+    return y if bias is None else y + bias
 
 
 class _GraphAggregateFn(torch.autograd.Function):

@@ -123,7 +123,8 @@ def _heads_forward(layer, x, src, tgt, Mtgt):
         return torch.cat([hd(x, src, tgt, Mtgt) for hd in layer.heads], 1)
     eg = edge_graph(src, tgt, Mtgt)
     Wsrc, Wtgt, Wlog, bf, ba = layer.packed()
-    Ps, Pt, A2 = torch.mm(x, Wsrc), torch.mm(x, Wtgt) + bf, torch.mm(x, Wlog) + ba
+    from .functional import dense
+    Ps, Pt, A2 = dense(x, Wsrc), dense(x, Wtgt, bf), dense(x, Wlog, ba)
     if eg.E == 0:
         return torch.zeros(x.shape[0], layer.out_features, dtype=x.dtype, device=x.device) + 0.0 * (Ps.sum() + Pt.sum() + A2.sum())
     return _EdgeAttentionHeadsFn.apply(heads_graph(eg, layer.n_heads), layer.n_heads, Ps, Pt, A2, layer.eps)

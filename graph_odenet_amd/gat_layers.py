@@ -137,8 +137,9 @@ def _gat_forward(layer, x, src, tgt, Mtgt):
     i, o = layer.in_features, layer.out_features
     Wf, ww = layer.f.weight, layer.w.weight                      # (o, 2i), (1, 2i)
     # node-level projections (dense GEMMs), split by role: message parts by source / target, logit parts
-    Ps, Pt = torch.mm(x, Wf[:, :i].t()), torch.mm(x, Wf[:, i:].t())
-    A2 = torch.mm(x, torch.stack([ww[0, :i], ww[0, i:]], 1))
+    from .functional import dense
+    Ps, Pt = dense(x, Wf[:, :i].t()), dense(x, Wf[:, i:].t())
+    A2 = dense(x, torch.stack([ww[0, :i], ww[0, i:]], 1))
     if eg.E == 0:                                                # no edges: every node is 0 / eps = 0
         return torch.zeros(x.shape[0], o, dtype=x.dtype, device=x.device) + 0.0 * (Ps.sum() + Pt.sum() + A2.sum())
     return _EdgeAttentionFn.apply(eg, Ps, Pt, A2, layer.f.bias, layer.w.bias, layer.eps)

@@ -21,20 +21,51 @@ from .graph import as_graph
 
 _SQUARE = (16, 32, 64, 128)
 
+# ---- the feature x weight product of a layer (GCN/layers.py:32 `support = torch.mm(input, self.weight)`) --------------
+# Three own kernels, no library GEMM:
+#   * square weights of the widths the fused ODE kernels cover: the MFMA kernels of csrc/gemm.hip (no GroupNorm, no
+#     time row);
+#   * a feature matrix that is mostly zeros (Cora's bag-of-words X is 98.7 % zero: 124 MFLOP of dense product for
+#     49 216 non-zeros): X is converted ONCE per tensor object to CSR and X W runs on the aggregation
+#     kernel with W as the dense operand (gode_spmm_csr_f32), X^T dS on its transpose.  Taken from the SECOND time the
+#     same tensor object arrives (a freshly dropped-out copy per step, as GCN-dense-paper makes, never pays for a
+#     conversion), for inputs that need no gradient, have >= SPARSE_MIN_FEATURES columns and <= SPARSE_MAX_DENSITY
+#     non-zeros;
+#   * everything else: the rectangular fp32-MFMA kernels of csrc/rect.hip.
+# Output widths that are not a multiple of 4 (Cora's 7 classes) are zero-padded to the next multiple, so that the
+# aggregation that follows runs on the 16-byte SpMM kernel instead of the scalar one; the layer returns the first
+# out_features columns.
+SPARSE_MIN_FEATURES = 64
+SPARSE_MAX_DENSITY = 0.25
+_feat_seen = {}            # id(tensor) -> [weakref, version, sightings, CSRGraph | False | None]
 
-def _xt_g(x, g):
-    """x^T g for tall x (n x d) and g (n x c): the weight gradient of a rectangular layer.  The library GEMM of this image
-    runs the reduction over 2^20 rows in ONE workgroup column (1.25 ms for 128 x 16 outputs); as a batched product over
-    256 row blocks plus a sum it takes 0.12 ms (tools/dev/narrow_mm_probe.py)."""
-    n = x.shape[0]
-    if n < 65536 or not (x.is_contiguous() and g.is_contiguous()):
-        return torch.mm(x.t(), g)
-    B = 256
-    m = n // B
-    out = torch.bmm(x[:m * B].view(B, m, x.shape[1]).transpose(1, 2), g[:m * B].view(B, m, g.shape[1])).sum(0)
-    if m * B < n:
-        out += torch.mm(x[m * B:].t(), g[m * B:])
-    return out
+
+def _feat_evict(key):
+    _feat_seen.pop(key, None)
+
+
+def sparse_features(x):
+    """CSRGraph of a mostly-zero feature matrix, or None (dense path).  See the comment above."""
+    import weakref
+    if x.requires_grad or x.dim() != 2 or x.shape[1] < SPARSE_MIN_FEATURES or x.shape[0] == 0:
+        return None
+    key = id(x)
+    rec = _feat_seen.get(key)
+    if rec is None or rec[0]() is not x or rec[1] != x._version:
+        try:
+            _feat_seen[key] = [weakref.ref(x, lambda _r, k=key: _feat_evict(k)), x._version, 1, None]
+        except TypeError:
+            pass
+        return None
+    rec[2] += 1
+    if rec[3] is None:                                       # second sighting: decide once (one host synchronisation)
+        dens = float(torch.count_nonzero(x)) / x.numel()
+        rec[3] = as_graph(x) if dens <= SPARSE_MAX_DENSITY else False
+    return rec[3] or None
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
 
 
 class _GraphConvFn(torch.autograd.Function):
@@ -42,42 +73,58 @@ class _GraphConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, graph, x, weight, bias):
-        # square layers of the widths the fused kernels cover run X W on the exact-fp32 MFMA kernel of the ODE function
-        # (no GroupNorm, no time row): 0.43 ms at 2^20 x 128 x 128 against 1.9 ms for the library GEMM of this image
-        ctx.square = (x.shape[1] == weight.shape[1] and weight.shape[0] in _SQUARE and x.shape[0] >= 4096
-                      and weight.is_contiguous())
+        n, f = x.shape
+        c = weight.shape[1]
+        cp = _pad4(c)
+        ctx.square = (f == c and weight.shape[0] in _SQUARE and n >= 4096 and weight.is_contiguous())
+        ctx.xs = None
+        w = weight.contiguous()
         if ctx.square:
-            support = ops.gn_time_gemm([(1.0, x)], x.shape[0], x.shape[1], 0, 0.0, None, None, weight, False, 0.0)
+            # 0.43 ms at 2^20 x 128 x 128 against 1.9 ms for the library GEMM of this image
+            support = ops.gn_time_gemm([(1.0, x)], n, f, 0, 0.0, None, None, w, False, 0.0)
         else:
-            support = torch.mm(x, weight).contiguous()       # plain dense GEMM (rocBLAS); see DESIGN.md
-        out = ops.spmm(graph, support, bias=bias, relu=False)
+            ctx.xs = sparse_features(x)
+            if ctx.xs is not None:
+                support = ops.spmm(ctx.xs, w if cp == c else torch.nn.functional.pad(w, (0, cp - c)))
+            else:
+                support = ops.rect_gemm(x, w, pad_to=cp)
+        b = bias
+        if bias is not None and cp != c:
+            b = torch.nn.functional.pad(bias, (0, cp - c))
+        out = ops.spmm(graph, support, bias=b, relu=False)
         ctx.graph = graph
         ctx.has_bias = bias is not None
+        ctx.c = c
         ctx.save_for_backward(x, weight)
-        return out
+        return out if cp == c else out[:, :c]
 
     @staticmethod
     def backward(ctx, grad_out):
         x, weight = ctx.saved_tensors
-        g = grad_out.contiguous()
-        d_support = ops.spmm(ctx.graph.transpose(), g)       # A^T dY
+        c, cp = ctx.c, _pad4(ctx.c)
+        g = grad_out.contiguous() if cp == c else torch.nn.functional.pad(grad_out, (0, cp - c))
+        d_support = ops.spmm(ctx.graph.transpose(), g)       # A^T dY   (n x cp; the pad columns stay zero)
         gx = gw = gb = None
         n, d = x.shape
+        w = weight.contiguous()
         if ctx.needs_input_grad[1]:
             if ctx.square:
-                gx, _, _ = ops.gn_time_gemm_bwd([(1.0, x)], n, d, 0, 0.0, None, weight, False, d_support,
+                gx, _, _ = ops.gn_time_gemm_bwd([(1.0, x)], n, d, 0, 0.0, None, w, False, d_support,
                                                 want_affine_grads=False)
             else:
-                gx = torch.mm(d_support, weight.t())
+                gx = ops.rect_gemm_nt(d_support[:, :c], w)
         if ctx.needs_input_grad[2]:
             if ctx.square:
-                gw = torch.empty_like(weight)
+                gw = torch.empty_like(w)
                 ops.reduce_parts_(gw.view(-1), ops.wgrad([(1.0, x)], n, d, 0, 0.0, None, None, d_support, False))
+            elif ctx.xs is not None:
+                gw = ops.spmm(ctx.xs.transpose(), d_support)           # X^T dS on the transposed CSR of X
+                gw = gw if cp == c else gw[:, :c].contiguous()
             else:
-                gw = _xt_g(x, d_support)
+                gw = ops.rect_wgrad(x, d_support[:, :c])
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            gb = torch.empty_like(weight[0])
-            ops.colsum_(gb, g)
+            gb = torch.empty(c, dtype=torch.float32, device=g.device)
+            ops.colsum_(gb, grad_out.contiguous())
         return None, gx, gw, gb
 
 

@@ -1,6 +1,6 @@
 """The GCN-mlp-sum variant of the reference (GCN-mlp-sum/layers.py, models.py): the graph layer aggregates an MLP of
 the features,  out = A @ (relu(x W1 + b1) W2 + b2)  with both widths equal to out_features and no bias after the
-aggregation; the model zoo is GCN/models.py's.  The two dense products stay PyTorch GEMMs, the aggregation is
+aggregation; the model zoo is GCN/models.py's.  The two dense products run on the rectangular fp32-MFMA kernels (functional.dense, csrc/rect.hip), the aggregation is
 gode_spmm_csr_f32; the ODE functions of this variant take the solver's generic (autograd) field."""
 import math
 
@@ -35,8 +35,8 @@ class MyLinear(Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def forward(self, input):
-        out = torch.mm(input, self.weight)
-        return out + self.bias if self.bias is not None else out
+        from .functional import dense
+        return dense(input, self.weight, self.bias)
 
 
 class NonLinear(Module):

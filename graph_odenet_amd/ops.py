@@ -244,6 +244,71 @@ def wgrad(x_terms, n_rows, d_in, groups, eps, gamma, beta, dS, has_time, part=No
     return part
 
 
+def _need_rows(t, name):
+    """A row-major matrix view: unit column stride, any leading dimension (a column block of a padded matrix)."""
+    if not t.is_cuda:
+        raise RuntimeError("graph_odenet_amd: %s must live on the GPU (got %s); there is no CPU path" % (name, t.device))
+    if t.dtype != torch.float32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or t.stride(0) < t.shape[1]:
+        raise ValueError("graph_odenet_amd: %s must be a float32 row-major matrix (unit column stride)" % name)
+    return t.stride(0)
+
+
+def rect_gemm(x, W, pad_to=None):
+    """S = x @ W for a rectangular W (K x M) on the fp32 MFMA kernel of csrc/rect.hip (GCN/layers.py:32).  pad_to:
+    leading dimension of the result (>= M): returns an n x pad_to tensor whose columns M.. are zero."""
+    lib = _lib.load()
+    _need(W, "W")
+    ldx = _need_rows(x, "x")
+    n, K = x.shape
+    M = W.shape[1]
+    if W.shape[0] != K:
+        raise ValueError("rect_gemm: x is %s, W is %s" % (tuple(x.shape), tuple(W.shape)))
+    lds = M if pad_to is None else int(pad_to)
+    out = torch.empty(n, lds, dtype=torch.float32, device=x.device)
+    check(lib.gode_rect_gemm_f32(ptr(x), ldx, n, K, ptr(W), M, ptr(out), lds, stream_ptr()), "gode_rect_gemm_f32")
+    return out
+
+
+def rect_gemm_nt(dS, W):
+    """dX = dS[:, :M] @ W^T for W (K x M); dS may be a column block of a wider (padded) matrix."""
+    lib = _lib.load()
+    _need(W, "W")
+    ldds = _need_rows(dS, "dS")
+    n = dS.shape[0]
+    K, M = W.shape
+    if dS.shape[1] != M:
+        raise ValueError("rect_gemm_nt: dS is %s, W is %s" % (tuple(dS.shape), tuple(W.shape)))
+    out = torch.empty(n, K, dtype=torch.float32, device=dS.device)
+    check(lib.gode_rect_gemm_nt_f32(ptr(dS), ldds, n, M, ptr(W), K, ptr(out), K, stream_ptr()), "gode_rect_gemm_nt_f32")
+    return out
+
+
+def rect_wgrad(x, dS):
+    """dW = x^T @ dS (K x M): block partials by csrc/rect.hip, summed by reduce_parts_ (fixed order)."""
+    lib = _lib.load()
+    ldx, ldds = _need_rows(x, "x"), _need_rows(dS, "dS")
+    n, K = x.shape
+    M = dS.shape[1]
+    if dS.shape[0] != n:
+        raise ValueError("rect_wgrad: x is %s, dS is %s" % (tuple(x.shape), tuple(dS.shape)))
+    out = torch.empty(K, M, dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out.zero_()
+    n_part = lib.gode_rect_wgrad_parts(n)
+    for m0 in range(0, M, 128):                       # the kernel takes up to 128 output columns per call
+        mw = min(128, M - m0)
+        part = torch.empty(n_part, K * mw, dtype=torch.float32, device=x.device)
+        check(lib.gode_rect_wgrad_f32(ptr(x), ldx, n, K, dS.data_ptr() + 4 * m0, ldds, mw, ptr(part), stream_ptr()),
+              "gode_rect_wgrad_f32")
+        if mw == M:
+            reduce_parts_(out.view(-1), part)
+        else:
+            blk = torch.empty(K * mw, dtype=torch.float32, device=x.device)
+            reduce_parts_(blk, part)
+            out[:, m0:m0 + mw] = blk.view(K, mw)
+    return out
+
+
 def gn_time_gemm_bwd_wgrad(x_terms, n_rows, d, groups, eps, gamma, beta, W, has_time, dS, out_scale=1.0, out=None,
                            pre_terms=None, dW=None, dgamma=None, dbeta=None):
     """VJP and weight gradient in one pass (gode_gn_time_gemm_bwd_wgrad_f32).  Returns (dx, dW, dgamma, dbeta), or

@@ -205,7 +205,8 @@ class EdgeGraphConvolution(Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def forward(self, input, Esrc, Etgt, edge_data):
-        support = torch.mm(input, self.weight)
+        from .functional import dense
+        support = dense(input, self.weight)
         output = edge_message(support, Esrc, Etgt, edge_data)
         if self.bias is not None:
             return output + self.bias

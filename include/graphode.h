@@ -20,6 +20,8 @@
  *   gode_gn_time_gemm_f32        GCN/models.py:175-177 GroupNorm, [t|x] concat; GCN/layers.py:70 torch.mm
  *   gode_gn_time_gemm_bwd_f32    autograd of the three sites above
  *   gode_wgrad_f32               autograd of GCN/layers.py:70 w.r.t. weight
+ *   gode_rect_gemm_f32 / _nt_ / gode_rect_wgrad_f32   GCN/layers.py:32 torch.mm(input, self.weight) of a layer with
+ *                                in_features != out_features, and its autograd (dY W^T, X^T dY)
  *   gode_lincomb_f32             torchdiffeq RK stage input / solution combine (call site GCN/models.py:192)
  *   gode_rk_errnorm_f32          torchdiffeq dopri5 mixed-tolerance error ratio (same call site)
  *   gode_gat_*                   GAT/layers.py:40-55 (and :104-120)
@@ -207,6 +209,22 @@ int gode_gn_time_gemm_bwd_wgrad_f32(const gode_lincomb_t* xin /* host */, int64_
                                     float eps, const float* gamma, const float* beta, const float* W, int has_time,
                                     const float* dS, float out_scale, const gode_lincomb_t* pre /* host, nullable */,
                                     float* dx, float* part, float* dW, float* dgamma, float* dbeta, void* stream);
+
+/* The rectangular dense products of GraphConvolution (GCN/layers.py:32 `support = torch.mm(input, self.weight)` with
+ * in_features != out_features, and its autograd), exact fp32 (v_mfma_f32_16x16x4_f32).  Row-major operands with leading
+ * dimensions; any K, M >= 1; rows 16-byte aligned with ld % 4 == 0 take the vector path.
+ *   gode_rect_gemm_f32:    S[n x M] = X[n x K] W[K x M]; columns M .. lds-1 of S are written as zeros (a caller pads
+ *                          M = 7 to lds = 8 so that the aggregation that follows runs on the 16-byte SpMM kernel);
+ *   gode_rect_gemm_nt_f32: dX[n x K] = dS[n x M] W[K x M]^T;
+ *   gode_rect_wgrad_f32:   part[p][K x M], p < gode_rect_wgrad_parts(n): block partials of X^T dS, summed by
+ *                          gode_reduce_parts_f32 (M <= 128 per call). */
+int gode_rect_gemm_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, const float* W, int64_t M,
+                       float* S, int64_t lds, void* stream);
+int gode_rect_gemm_nt_f32(const float* dS, int64_t ldds, int64_t n_rows, int64_t M, const float* W, int64_t K,
+                          float* dX, int64_t lddx, void* stream);
+int64_t gode_rect_wgrad_parts(int64_t n_rows);
+int gode_rect_wgrad_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, const float* dS, int64_t ldds,
+                        int64_t M, float* part, void* stream);
 
 /* out[j] (+)= scale * sum_p part[p*len + j]   (accumulate != 0 adds to out) */
 int gode_reduce_parts_f32(float* out, const float* part, int64_t n_part, int64_t len,

@@ -507,7 +507,7 @@ def test_native_rk4_driver_matches_python_driver():
             res[native] = (out.detach(), xi.grad, [p.grad.clone() for p in blk.parameters()], blk.nfe)
         finally:
             OI.NATIVE_RK4 = True
-    assert res[True][3] == res[False][3] == 64
+    assert res[True][3] == res[False][3] == 32 + 33      # 32 forward + 32 adjoint evaluations + torchdiffeq's dL/dt one (odeint.py)
     close(res[True][0], res[False][0], 1e-6, "state")
     close(res[True][1], res[False][1], 1e-6, "gx")
     for a, b in zip(res[True][2], res[False][2]):
@@ -904,3 +904,49 @@ def test_last_state_only_equals_stacked_result(method):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+
+
+def test_graph_convolution_sparse_features_and_padded_classes():
+    """A1 without a library GEMM: the rectangular X W / dY W^T / X^T dY of GraphConvolution run on
+    csrc/rect.hip; a mostly-zero feature matrix takes the CSR(X) path from the second time the same tensor object
+    arrives (graph_odenet_amd/layers.py: X W on the aggregation kernel with W as the dense operand); 7 output classes
+    are padded to 8 columns so that the aggregation runs on the 16-byte kernel.  All three routes against the oracle
+    layer (GCN/layers.py:31-37) on a Cora-shaped problem: 2708 x 1433 features with 1.3 % non-zeros, 16 and 7 outputs."""
+    from graph_odenet_amd import layers as L
+    from oracle import layers_ref as R
+    torch.manual_seed(5)
+    n, f = 2708, 1433
+    x = (torch.rand(n, f) < 0.013).float()
+    x = x / x.sum(1, keepdim=True).clamp_min(1)
+    r, c = torch.randint(0, n, (13264,)), torch.randint(0, n, (13264,))
+    v = torch.rand(13264) + 0.1
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n))
+    for cout, needs_gx in ((16, False), (7, False), (7, True)):
+        lay = L.GraphConvolution(f, cout)
+        w, b = lay.weight.detach().clone().requires_grad_(True), lay.bias.detach().clone().requires_grad_(True)
+        xr = x.clone().requires_grad_(needs_gx)
+        ref = R.graph_convolution(xr, adj, w, b)
+        gout = torch.randn(n, cout)
+        ref.backward(gout)
+        lay = lay.to(dev())
+        xd, ad = x.to(dev()).requires_grad_(needs_gx), adj.to(dev())
+        routes = []
+        for sighting in range(3):                        # 1st: rectangular MFMA kernels; 2nd, 3rd: CSR(X) (unless x needs a gradient)
+            lay.zero_grad()
+            if xd.grad is not None:
+                xd.grad = None
+            out = lay(xd, ad)
+            out.backward(gout.to(dev()))
+            routes.append(L.sparse_features(xd) is not None if sighting else False)
+            close(out, ref, 1e-5, "out (%d classes, sighting %d)" % (cout, sighting))
+            close(lay.weight.grad, w.grad, 2e-5, "dW"); close(lay.bias.grad, b.grad, 2e-5, "db")
+            if needs_gx:
+                close(xd.grad, xr.grad, 2e-5, "dx")
+        assert routes[1:] == [not needs_gx, not needs_gx], routes
+    # a dense feature matrix stays on the rectangular kernels however often it arrives
+    xdense = torch.randn(300, 200, device=dev())
+    lay = L.GraphConvolution(200, 16).to(dev())
+    a2 = torch.eye(300).to_sparse().to(dev())
+    for _ in range(3):
+        lay(xdense, a2)
+    assert L.sparse_features(xdense) is None

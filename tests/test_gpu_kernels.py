@@ -597,3 +597,36 @@ def test_vjp_from_exact_bf16_pieces(n, groups):
         lib.gode_set_option(b"bwd_split", 0)
         lib.gode_set_option(b"bwd_pc", saved)
         lib.gode_set_option(b"wgrad_split_small", 0)
+
+
+@pytest.mark.parametrize("n", [1, 17, 1000, 70001])
+@pytest.mark.parametrize("K,M", [(16, 7), (128, 16), (1433, 16), (500, 16), (3, 3), (100, 40), (64, 200), (130, 129)])
+def test_rectangular_products_vs_float64(n, K, M):
+    """csrc/rect.hip: the dense products of a GraphConvolution with in_features != out_features (GCN/layers.py:32
+    `torch.mm(input, self.weight)` and its autograd) on the exact fp32 matrix instruction - X W (with the output padded
+    to a multiple of four columns, pad = exact zeros), dS W^T (dS a column block of the padded matrix), X^T dS (block
+    partials + fixed-order sum) - against float64; aligned rows take the 16-byte path, K % 4 != 0 the scalar one."""
+    from graph_odenet_amd import ops
+    if n * K > 40_000_000:
+        pytest.skip("operand larger than the test needs")
+    g = torch.Generator().manual_seed(n * 3 + K * 5 + M)
+    x = torch.randn(n, K, generator=g)
+    W = torch.randn(K, M, generator=g) / K ** 0.5
+    D = dev()
+    ref = x.double() @ W.double()
+    scale = ref.abs().max().item() + 1e-30
+    got = ops.rect_gemm(x.to(D), W.to(D)).cpu()
+    assert got.shape == (n, M) and (got.double() - ref).abs().max().item() <= 2e-6 * scale
+    mp = (M + 3) // 4 * 4
+    gotp = ops.rect_gemm(x.to(D), W.to(D), pad_to=mp).cpu()
+    assert gotp.shape == (n, mp) and torch.equal(gotp[:, :M], got) and bool((gotp[:, M:] == 0).all())
+    dSp = torch.zeros(n, mp)
+    dSp[:, :M] = torch.randn(n, M, generator=g)
+    dSd = dSp.to(D)
+    want_dx = dSp[:, :M].double() @ W.double().t()
+    dx = ops.rect_gemm_nt(dSd[:, :M], W.to(D)).cpu()
+    assert (dx.double() - want_dx).abs().max().item() <= 2e-6 * (want_dx.abs().max().item() + 1e-30)
+    want_dw = x.double().t() @ dSp[:, :M].double()
+    dw = ops.rect_wgrad(x.to(D), dSd[:, :M]).cpu()
+    assert dw.shape == (K, M)
+    assert (dw.double() - want_dw).abs().max().item() <= 3e-6 * (want_dw.abs().max().item() + 1e-30) * max(1.0, (n / 4096) ** 0.5)
