@@ -80,6 +80,16 @@ class GatWorkspace(ctypes.Structure):
                 ("zeros", ctypes.c_void_p), ("heads_scratch", ctypes.c_void_p), ("colsum_scratch2", ctypes.c_void_p)]
 
 
+GODE_ADAM_MAX_TENSORS = 64
+
+
+class AdamArgs(ctypes.Structure):
+    """Mirror of gode_adam_args_t."""
+    _fields_ = [("param", ctypes.c_void_p * GODE_ADAM_MAX_TENSORS), ("grad", ctypes.c_void_p * GODE_ADAM_MAX_TENSORS),
+                ("exp_avg", ctypes.c_void_p * GODE_ADAM_MAX_TENSORS), ("exp_avg_sq", ctypes.c_void_p * GODE_ADAM_MAX_TENSORS),
+                ("len", ctypes.c_int64 * GODE_ADAM_MAX_TENSORS)]
+
+
 c_i64 = ctypes.c_int64
 c_p = ctypes.c_void_p
 c_f = ctypes.c_float
@@ -113,12 +123,13 @@ SIGNATURES = {
     "gode_rect_gemm_nt_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "gode_rect_wgrad_parts": (c_i64, [c_i64]),
     "gode_rect_wgrad_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p]),
+    "gode_gemm_f32": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p, c_i64, c_p]),
+    "gode_adam_chunk": (c_i64, []),
+    "gode_adam_tick_f32": (c_i, [c_p, c_f, c_f, c_p]),
+    "gode_adam_f32": (c_i, [ctypes.POINTER(AdamArgs), ctypes.c_int32, c_p, c_i64, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),
     "gode_wgrad_parts": (c_i64, [c_i64]),
     "gode_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
                              c_p, c_i64, c_i, c_p, c_p]),
-    "gode_bwd_wgrad_parts": (c_i64, [c_i64]),
-    "gode_gn_time_gemm_bwd_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_i,
-                                              c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p, c_p, c_p]),
     "gode_reduce_parts_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
     "gode_reduce_parts2_f32": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_f, c_i, c_p]),
     "gode_reduce_segments_f32": (c_i, [ctypes.POINTER(ReduceSeg), ctypes.c_int32, c_f, c_p, c_p]),

@@ -598,178 +598,6 @@ __global__ __launch_bounds__(256, 2) void gn_gemm_bwd_kernel(LinComb xin, int n_
 }
 
 // ---------------------------------------------------------------------------------
-// VJP on the bf16 matrix cores (d = 128, GroupNorm of 4 channels per group or none): dS and W1 are cut exactly into
-// three bf16 pieces each (as in gn_gemm_fwd_split_kernel: by rounding, eight of the nine piece products, smallest
-// first, fp32 accumulation - every product to 2^-32), the GroupNorm backward and the dgamma / dbeta partials are those
-// of gn_gemm_bwd_kernel.  The point is not the matrix time but what runs beside it: bf16 MFMAs let the partner wave
-// issue its loads and stores, fp32 MFMAs do not (profiles/r02_mfma_mem.txt), and this launch moves three N x d arrays.
-// ---------------------------------------------------------------------------------
-template <int CG>   // 0 or 4
-__global__ __launch_bounds__(512, 2) void gn_gemm_bwd_split_kernel(LinComb xin, int n_rows, float eps,
-                                                                   const float* __restrict__ gamma,
-                                                                   const float* __restrict__ W, int has_time,
-                                                                   const float* __restrict__ dS, float out_scale,
-                                                                   LinComb pre, float* __restrict__ dx,
-                                                                   float* __restrict__ dgamma_part,
-                                                                   float* __restrict__ dbeta_part, int n_part)
-{
-    constexpr int D = 128, NJ = 8, NK = 4;          // NK k-blocks of 32
-    constexpr int LDK = D + 8;                      // bf16 elements per row of a piece array (272 B: conflict-free ds_read_b128)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned short* Wp = reinterpret_cast<unsigned short*>(smem);          // [3][D][LDK]: pieces of W1[i][n] (row i, column n)
-    float* Gs = smem + (3 * D * LDK) / 2;
-    for (int idx = threadIdx.x; idx < D * D / 4; idx += 512) {
-        const int i = idx / (D / 4), n = (idx % (D / 4)) * 4;
-        const float4 w = ld4(W + (int64_t)(i + has_time) * D + n);
-        const float wv[4] = {w.x, w.y, w.z, w.w};
-        unsigned short pc[3][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) split3(wv[q], pc[0][q], pc[1][q], pc[2][q]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            *reinterpret_cast<uint2*>(Wp + (p * D + i) * LDK + n) =
-                make_uint2((unsigned)pc[p][0] | ((unsigned)pc[p][1] << 16), (unsigned)pc[p][2] | ((unsigned)pc[p][3] << 16));
-    }
-    fill_vec_lds<D, 512>(Gs, gamma, 1.f);
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int r = l & 15, g = l >> 4;          // MFMA layout
-    const int mr = l >> 2, mg = l & 3;         // memory layout
-    const int to_m = (mg * 16 + mr) * 4;
-    const int n_tiles = (n_rows + 15) / 16;
-    float4 dgs[NJ], dbs[NJ];                   // memory layout: channels 16tt + 4mg .. +3 of row mr
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) { dgs[j] = make_float4(0.f, 0.f, 0.f, 0.f); dbs[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
-
-    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
-        const int row = tile * 16 + mr;
-        const bool valid = row < n_rows;
-        const int64_t base = (int64_t)(valid ? row : n_rows - 1) * D + 4 * mg;     // clamped: unconditional loads
-        float4 gv[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            gv[j] = ld4(dS + base + 16 * j);
-            if (!valid) gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4 xt[NJ];      // x tile (memory layout), requested before the matrix phase
-        if (CG != 0) load_tile<NJ>(xin, base, true, xt);
-        // memory layout -> bf16 MFMA layout (see gn_gemm_fwd_split_kernel): F-lane (r, g) needs dS[row r][32kb + 8g + 4h + c]
-        bf16x8 gp[NK][3];
-#pragma unroll
-        for (int kb = 0; kb < NK; ++kb) {
-            float xf[8];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int src = (4 * r + 2 * (g & 1) + h) * 4;
-                const float4 a = to_mfma_layout(gv[2 * kb], src), b = to_mfma_layout(gv[2 * kb + 1], src);
-                const float4 v = (g >> 1) ? b : a;
-                xf[4 * h] = v.x; xf[4 * h + 1] = v.y; xf[4 * h + 2] = v.z; xf[4 * h + 3] = v.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                unsigned short h, m, lo;
-                split3(xf[e], h, m, lo);
-                gp[kb][0][e] = (short)h; gp[kb][1][e] = (short)m; gp[kb][2][e] = (short)lo;
-            }
-        }
-        f32x4 acc[NJ];
-#pragma unroll
-        for (int tt = 0; tt < NJ; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 a[2][3];
-        {
-            const unsigned short* wr = Wp + r * LDK + 8 * g;
-            a[0][0] = *reinterpret_cast<const bf16x8*>(wr);
-            a[0][1] = *reinterpret_cast<const bf16x8*>(wr + D * LDK);
-            a[0][2] = *reinterpret_cast<const bf16x8*>(wr + 2 * D * LDK);
-        }
-#pragma unroll
-        for (int sidx = 0; sidx < NK * NJ; ++sidx) {
-            const int kb = sidx / NJ, tt = sidx % NJ;
-            if (sidx + 1 < NK * NJ) {
-                const int kb2 = (sidx + 1) / NJ, tt2 = (sidx + 1) % NJ;
-                const unsigned short* wr = Wp + (16 * tt2 + r) * LDK + 32 * kb2 + 8 * g;
-                a[(sidx + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(wr);
-                a[(sidx + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(wr + D * LDK);
-                a[(sidx + 1) & 1][2] = *reinterpret_cast<const bf16x8*>(wr + 2 * D * LDK);
-            }
-            const bf16x8 ah = a[sidx & 1][0], am = a[sidx & 1][1], al = a[sidx & 1][2];
-            f32x4 c = acc[tt];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gp[kb][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, gp[kb][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, gp[kb][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gp[kb][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, gp[kb][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, gp[kb][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gp[kb][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, gp[kb][0], c, 0, 0, 0);
-            acc[tt] = c;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // acc[tt] (MFMA layout) = dxn[row r][16tt+4g .. +3]  ->  memory layout for GroupNorm backward + store
-#pragma unroll
-        for (int tt = 0; tt < NJ; ++tt) {
-            const int c0 = 16 * tt + 4 * mg;
-            const float4 dy = acc_to_mem_layout(acc[tt], to_m);
-            float4 out = dy;
-            if (CG != 0) {                         // four channels per group = this lane's float4 (as gn_gemm_bwd_kernel, CG == 4)
-                const float4 x = xt[tt];
-                float4 mean, rstd;
-                gn_stats<CG>(x, eps, mean, rstd);
-                const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y,
-                                              (x.z - mean.z) * rstd.z, (x.w - mean.w) * rstd.w);
-                const float4 gm = ld4(Gs + c0);
-                const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
-                if (valid) {
-                    dgs[tt].x += dy.x * xh.x; dgs[tt].y += dy.y * xh.y; dgs[tt].z += dy.z * xh.z; dgs[tt].w += dy.w * xh.w;
-                    dbs[tt].x += dy.x; dbs[tt].y += dy.y; dbs[tt].z += dy.z; dbs[tt].w += dy.w;
-                }
-                const float m1 = ((dh.x + dh.y) + (dh.z + dh.w)) * 0.25f;
-                const float m2 = ((dh.x * xh.x + dh.y * xh.y) + (dh.z * xh.z + dh.w * xh.w)) * 0.25f;
-                const float rs = rstd.x;
-                out = make_float4(rs * (dh.x - m1 - xh.x * m2), rs * (dh.y - m1 - xh.y * m2),
-                                  rs * (dh.z - m1 - xh.z * m2), rs * (dh.w - m1 - xh.w * m2));
-            }
-            if (valid) {
-                float4 o = make_float4(out_scale * out.x, out_scale * out.y, out_scale * out.z, out_scale * out.w);
-                if (pre.n > 0) {     // fused RK solution combine of the adjoint component
-                    const float4 pv = lc_load4(pre, (int64_t)row * D + c0);
-                    o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
-                }
-                *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) = o;
-            }
-        }
-    }
-    if (CG != 0 && dgamma_part) {
-        __syncthreads();                       // every wave is done with the W pieces: reuse LDS for the reduction
-        float* red = smem;                     // [2][8 waves][D]  (Gs lies behind the pieces and is not touched)
-#pragma unroll
-        for (int tt = 0; tt < NJ; ++tt) {
-            float4 a = dgs[tt], b = dbs[tt];
-#pragma unroll
-            for (int o = 4; o < 64; o <<= 1) {  // lanes with equal mg (l & 3) hold the same channels
-                a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
-                b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
-            }
-            if (mr == 0) {
-                *reinterpret_cast<float4*>(red + wave * D + 16 * tt + 4 * mg) = a;
-                *reinterpret_cast<float4*>(red + (8 + wave) * D + 16 * tt + 4 * mg) = b;
-            }
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < D; c += 512) {
-            float sa = 0.f, sb = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { sa += red[w * D + c]; sb += red[(8 + w) * D + c]; }
-            dgamma_part[(int64_t)blockIdx.x * D + c] = sa;
-            dbeta_part[(int64_t)blockIdx.x * D + c] = sb;
-        }
-        // the caller's buffers hold gode_gemm_bwd_parts() rows: zero the ones no block owns
-        for (int p = gridDim.x + blockIdx.x; p < n_part; p += gridDim.x)
-            for (int c = threadIdx.x; c < D; c += 512) { dgamma_part[(int64_t)p * D + c] = 0.f; dbeta_part[(int64_t)p * D + c] = 0.f; }
-    }
-}
-
-// ---------------------------------------------------------------------------------
 // weight gradient: dW[has_time + i][n] = sum_rows xn[row][i] * dS[row][n]; row 0 (has_time) = sum_rows dS[row][n]
 // (the gradient w.r.t. a unit time column: the caller scales it by t and uses it for dL/dt)
 // one block partial per block.
@@ -1073,248 +901,6 @@ __global__ __launch_bounds__(1024, 1) void wgrad_split_kernel(LinComb xin, int n
                 out[(int64_t)(i + has_time) * D + 16 * (b0 + b) + r] = acc[a][b][q];
             }
     if (has_time) __syncthreads();                     // pairs with the producers' barrier before their column-sum reduction
-}
-
-// ---------------------------------------------------------------------------------
-// VJP and weight gradient in ONE pass over dS and x (the adjoint stage reads both N x d arrays once instead of twice).
-//
-//   dxn = dS * W1^T ; dx = GN'(x)^T dxn             (as gn_gemm_bwd_kernel)
-//   M   = xh^T dS   with xh = (x - mean) * rstd       (the normalised input WITHOUT its affine part)
-//   c   = colsum(dS)
-// and everything else follows from the D x D matrix M and the vector c in a small finishing launch:
-//   dW1[i][n] = gamma_i M[i][n] + beta_i c[n]         (= xn^T dS with xn = gamma xh + beta)
-//   dW[0][n]  = c[n]                                   (time row)
-//   dgamma_i  = sum_rows dxn[row][i] xh[row][i] = sum_n W1[i][n] M[i][n]
-//   dbeta_i   = sum_rows dxn[row][i]            = sum_n W1[i][n] c[n]
-// so the per-row loop carries no dgamma / dbeta accumulators at all.
-//
-// STATUS (round 2, measured at 2^20 x 128, tools/kbench.py): 0.92 ms against 0.42 + 0.43 ms for the two separate
-// launches - NOT used by the ODE drivers.  The whole D x D accumulator per wave (256 registers) forces one wave per
-// SIMD, where every LDS / scratch wait is exposed and the ~5 000 non-matrix instructions of a tile (GroupNorm forward
-// and backward, layout permutes, staging) run strictly in series with its 512 matrix instructions; the bytes saved
-// (1 GB of 3) do not matter to a kernel that is not bandwidth-bound.  Kept as a tested entry point: the variant that
-// could win splits M between two waves of a pair (two waves per SIMD) - DESIGN.md section 8.
-//
-// A wave owns 16-row tiles end to end and keeps the WHOLE D x D accumulator of M (NJ*NJ 16x16 tiles: 256 registers
-// at d = 128) for its rows; no block barrier in the main loop.  Per tile: the x / dS tiles arrive in memory layout
-// (prefetched one tile ahead), dS is permuted into the MFMA layout for the first product (W1^T from LDS), both tiles
-// are staged into the wave's private LDS region (row stride D + 16: conflict-free operand reads) for the second.
-// One block per CU (W^T + 4 staging regions = 142 KB of LDS at d = 128), one wave per SIMD.
-// ---------------------------------------------------------------------------------
-template <int NJ, int CG>
-__global__ __launch_bounds__(256, 1) void gn_gemm_bwd_wgrad_kernel(LinComb xin, int n_rows, float eps,
-                                                                   const float* __restrict__ W, int has_time,
-                                                                   const float* __restrict__ dS, float out_scale,
-                                                                   LinComb pre, float* __restrict__ dx,
-                                                                   const float* __restrict__ gamma,
-                                                                   float* __restrict__ part /* [grid][D*D + D] */)
-{
-    constexpr int D = 16 * NJ;
-    constexpr int LDW = D + 4;
-    constexpr int LDT = D + 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wt = smem;                               // Wt[n][i] = W1[i][n]
-    float* Gs = smem + D * LDW;                     // gamma
-    float* stage = Gs + D;                          // [4 waves][2][16][LDT]
-    fill_w_lds<D, 256, true>(Wt, W, has_time);
-    fill_vec_lds<D, 256>(Gs, gamma, 1.f);
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int r = l & 15, g = l >> 4;          // MFMA layout
-    const int mr = l >> 2, mg = l & 3;         // memory layout
-    const int to_f = (4 * r + g) * 4, to_m = (mg * 16 + mr) * 4;
-    float* Xs = stage + wave * 2 * 16 * LDT;
-    float* Ds = Xs + 16 * LDT;
-    const int n_tiles = (n_rows + 15) / 16;
-    const int stride = gridDim.x * 4;
-
-    f32x4 mac[NJ][NJ];                         // M accumulator: mac[a][b][q] = M[16a + 4g + q][16b + r]
-#pragma unroll
-    for (int a = 0; a < NJ; ++a)
-#pragma unroll
-        for (int b = 0; b < NJ; ++b) mac[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float cs[(D + 63) / 64];                   // column sums of dS: lane l owns columns l, l + 64, ...
-#pragma unroll
-    for (int q = 0; q < (D + 63) / 64; ++q) cs[q] = 0.f;
-
-    int tile = blockIdx.x * 4 + wave;
-    float4 ngv[NJ], nxt[NJ];
-    {
-        const int row = tile * 16 + mr;
-        const bool valid = tile < n_tiles && row < n_rows;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) ngv[j] = valid ? ld4(dS + (int64_t)row * D + 16 * j + 4 * mg) : make_float4(0.f, 0.f, 0.f, 0.f);
-        load_tile<NJ>(xin, (int64_t)row * D + 4 * mg, valid, nxt);
-    }
-    for (; tile < n_tiles; tile += stride) {
-        const int row = tile * 16 + mr;
-        const bool valid = row < n_rows;
-        // Register budget (one wave per SIMD, 256 accumulator registers): the prefetched tiles become the current ones
-        // by renaming; the NEXT tile's loads are issued only after the first product, so that during it the live set
-        // is {dS in MFMA layout, x, 8 accumulators}; GroupNorm statistics are recomputed where they are used
-        // instead of being kept (64 registers).
-        float4 xt[NJ], gf[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            xt[j] = nxt[j];
-            float4 xh = xt[j];
-            if (CG != 0) {
-                float4 mean, rstd;
-                gn_stats<CG>(xt[j], eps, mean, rstd);
-                xh = make_float4((xt[j].x - mean.x) * rstd.x, (xt[j].y - mean.y) * rstd.y,
-                                 (xt[j].z - mean.z) * rstd.z, (xt[j].w - mean.w) * rstd.w);
-                if (!valid) xh = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            // staged for the second product (rows beyond n_rows are zero: the loads returned zeros)
-            *reinterpret_cast<float4*>(Xs + mr * LDT + 16 * j + 4 * mg) = xh;
-            *reinterpret_cast<float4*>(Ds + mr * LDT + 16 * j + 4 * mg) = ngv[j];
-            gf[j] = to_mfma_layout(ngv[j], to_f);
-        }
-        // first product: dxn = dS W1^T
-        f32x4 acc[NJ];
-#pragma unroll
-        for (int tt = 0; tt < NJ; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mfma_panel<NJ>(Wt + 4 * g * LDW + r, gf, acc);
-#pragma unroll
-        for (int tt = 0; tt < NJ; ++tt) {
-            const int c0 = 16 * tt + 4 * mg;
-            const float4 dy = acc_to_mem_layout(acc[tt], to_m);
-            float4 out = dy;
-            if (CG != 0) {
-                const float4 x = xt[tt];
-                float4 mn, rs;
-                gn_stats<CG>(x, eps, mn, rs);
-                const float4 gm = ld4(Gs + c0);
-                const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
-                const float4 px = make_float4(dh.x * x.x, dh.y * x.y, dh.z * x.z, dh.w * x.w);
-                float4 ds, db;
-                if (CG == 1) {
-                    ds = px; db = dh;
-                } else if (CG == 2) {
-                    ds = make_float4(px.x + px.y, px.x + px.y, px.z + px.w, px.z + px.w);
-                    db = make_float4(dh.x + dh.y, dh.x + dh.y, dh.z + dh.w, dh.z + dh.w);
-                } else {
-                    const float a = (px.x + px.y) + (px.z + px.w);
-                    const float b = (dh.x + dh.y) + (dh.z + dh.w);
-                    ds = make_float4(a, a, a, a); db = make_float4(b, b, b, b);
-                }
-                constexpr float sc = 1.0f / (CG > 0 ? CG : 1);
-                const float4 r3 = make_float4(rs.x * rs.x * rs.x * sc, rs.y * rs.y * rs.y * sc, rs.z * rs.z * rs.z * sc,
-                                              rs.w * rs.w * rs.w * sc);
-                const float4 c2 = make_float4((db.x * mn.x - ds.x) * r3.x, (db.y * mn.y - ds.y) * r3.y,
-                                              (db.z * mn.z - ds.z) * r3.z, (db.w * mn.w - ds.w) * r3.w);
-                const float4 c3 = make_float4(-c2.x * mn.x - db.x * rs.x * sc, -c2.y * mn.y - db.y * rs.y * sc,
-                                              -c2.z * mn.z - db.z * rs.z * sc, -c2.w * mn.w - db.w * rs.w * sc);
-                out = make_float4(rs.x * gm.x * dy.x + c2.x * x.x + c3.x, rs.y * gm.y * dy.y + c2.y * x.y + c3.y,
-                                  rs.z * gm.z * dy.z + c2.z * x.z + c3.z, rs.w * gm.w * dy.w + c2.w * x.w + c3.w);
-            }
-            if (valid) {
-                float4 o = make_float4(out_scale * out.x, out_scale * out.y, out_scale * out.z, out_scale * out.w);
-                if (pre.n > 0) {
-                    const float4 pv = lc_load4(pre, (int64_t)row * D + c0);
-                    o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
-                }
-                *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) = o;
-            }
-        }
-        {   // the next tile of this wave: its loads fly during the second product (8 192 matrix cycles)
-            const int nrow = row + stride * 16;
-            const bool nvalid = (tile + stride < n_tiles) && nrow < n_rows;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                ngv[j] = nvalid ? ld4(dS + (int64_t)nrow * D + 16 * j + 4 * mg) : make_float4(0.f, 0.f, 0.f, 0.f);
-            load_tile<NJ>(xin, (int64_t)nrow * D + 4 * mg, nvalid, nxt);
-        }
-        // second product out of the wave's staging region: M += xh^T dS over the 16 rows (4 k-steps of 4 rows)
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float av[NJ], bv[NJ];
-#pragma unroll
-            for (int a = 0; a < NJ; ++a) av[a] = Xs[(4 * kk + g) * LDT + 16 * a + r];
-#pragma unroll
-            for (int b = 0; b < NJ; ++b) bv[b] = Ds[(4 * kk + g) * LDT + 16 * b + r];
-#pragma unroll
-            for (int a = 0; a < NJ; ++a)
-#pragma unroll
-                for (int b = 0; b < NJ; ++b)
-                    mac[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], mac[a][b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (has_time) {
-#pragma unroll
-            for (int q = 0; q < (D + 63) / 64; ++q) {
-                const int c = l + 64 * q;
-                if (c < D) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int rr = 0; rr < 16; ++rr) s += Ds[rr * LDT + c];
-                    cs[q] += s;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();       // the next tile's staging writes follow these reads in program order
-    }
-    // block partial: the four waves add their accumulators through LDS in wave order (fixed order: deterministic)
-    __syncthreads();
-    float* red = smem;                         // D*D + D floats (Wt is no longer needed)
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int a = 0; a < NJ; ++a)
-#pragma unroll
-                for (int b = 0; b < NJ; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int idx = (16 * a + 4 * g + q) * D + 16 * b + r;
-                        red[idx] = (w == 0 ? 0.f : red[idx]) + mac[a][b][q];
-                    }
-#pragma unroll
-            for (int q = 0; q < (D + 63) / 64; ++q) {
-                const int c = l + 64 * q;
-                if (c < D) red[D * D + c] = (w == 0 ? 0.f : red[D * D + c]) + cs[q];
-            }
-        }
-        __syncthreads();
-    }
-    float* out = part + (int64_t)blockIdx.x * (D * D + D);
-    for (int idx = threadIdx.x * 4; idx < D * D + D; idx += 1024)
-        *reinterpret_cast<float4*>(out + idx) = *reinterpret_cast<const float4*>(red + idx);
-}
-
-// Finishing launch of the fused pass: block i reduces row i of M over the block partials (fixed order) and forms
-// dW row i + 1, dgamma_i, dbeta_i; block D writes the time row.
-__global__ __launch_bounds__(256) void bwd_wgrad_finish_kernel(const float* __restrict__ part, int n_part, int D,
-                                                               const float* __restrict__ W, int has_time,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float* __restrict__ dW, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta)
-{
-    __shared__ float sg[256], sb[256];
-    const int i = blockIdx.x;
-    const int64_t ps = (int64_t)D * D + D;
-    float ag = 0.f, ab = 0.f;
-    for (int n = threadIdx.x; n < D; n += 256) {
-        float c = 0.f;
-        for (int p = 0; p < n_part; ++p) c += part[p * ps + (int64_t)D * D + n];
-        if (i == D) { if (has_time) dW[n] = c; continue; }
-        float m = 0.f;
-        for (int p = 0; p < n_part; ++p) m += part[p * ps + (int64_t)i * D + n];
-        const float gi = gamma ? gamma[i] : 1.f, bi = beta ? beta[i] : 0.f;
-        dW[(int64_t)(i + has_time) * D + n] = gi * m + bi * c;
-        const float w = W[(int64_t)(i + has_time) * D + n];
-        ag = fmaf(w, m, ag); ab = fmaf(w, c, ab);
-    }
-    if (i == D || (!dgamma && !dbeta)) return;
-    sg[threadIdx.x] = ag; sb[threadIdx.x] = ab;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-        const int nt = D < 256 ? D : 256;
-        for (int t = 0; t < nt; ++t) { a += sg[t]; b += sb[t]; }
-        if (dgamma) dgamma[i] = a;
-        if (dbeta) dbeta[i] = b;
-    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1960,19 +1546,6 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
                                 n_part, cg, s);
         if (rc != GODE_E_UNSUPPORTED) return rc;
     }
-    if ((cg == 0 || cg == 4) && al && d_in == 128 && gode_opt_bwd_split() &&
-        (n_rows >= kWgradSplitMinRows || gode_opt_wgrad_split_small())) {
-        const size_t lds = (size_t)3 * 128 * (128 + 8) * sizeof(unsigned short) + 128 * sizeof(float);
-        int64_t blocks = ((n_rows + 15) / 16 + 7) / 8; if (blocks < 1) blocks = 1; if (blocks > 256) blocks = 256;
-#define GODE_BWDS(CGV) { rc = set_lds(gn_gemm_bwd_split_kernel<CGV>, lds); if (rc) return rc;                 \
-          const int slot = gode_prof_begin(s, d_in, n_rows, (int64_t)lc.n - 1 + lpre.n, GODE_PROF_GEMM_BWD | GODE_PROF_FORM_SPLIT); \
-          hipLaunchKernelGGL((gn_gemm_bwd_split_kernel<CGV>), dim3((unsigned)blocks), dim3(512), lds, s,      \
-                             lc, (int)n_rows, eps, gamma, W, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part, (int)n_part); \
-          gode_prof_end(s, slot);                                                                             \
-          GODE_LAUNCH_CHECK(); return 0; }
-        if (cg == 0) GODE_BWDS(0) else GODE_BWDS(4)
-#undef GODE_BWDS
-    }
     if (cg >= 0 && al) {
         const int nj = (int)(d_in / 16);
         size_t lds = ((size_t)d_in * (d_in + 4) + d_in) * sizeof(float);
@@ -2010,56 +1583,6 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
     hipLaunchKernelGGL(gn_gemm_bwd_generic, dim3((unsigned)blocks), dim3(256), lds, s, lc, (int)n_rows, (int)d_in,
                        (int)groups, eps, gamma, W, (int)d_out, has_time, dS, out_scale, lpre, dx, dgamma_part, dbeta_part,
                        (int)n_part);
-    GODE_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int64_t gode_bwd_wgrad_parts(int64_t n_rows) {
-    // one block per CU keeps a whole D x D accumulator per wave; fewer blocks when there are fewer 16-row tiles
-    int64_t b = ((n_rows + 15) / 16 + 3) / 4;
-    if (b < 1) b = 1;
-    if (b > 256) b = 256;
-    return b;
-}
-
-extern "C" int gode_gn_time_gemm_bwd_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups,
-                                               float eps, const float* gamma, const float* beta, const float* W,
-                                               int has_time, const float* dS, float out_scale, const gode_lincomb_t* pre,
-                                               float* dx, float* part, float* dW, float* dgamma, float* dbeta, void* stream)
-{
-    int rc = check_common(xin, n_rows, d, groups, d); if (rc) return rc;
-    if (n_rows == 0) return GODE_E_UNSUPPORTED;
-    if (!W || !dS || !dx || !part || !dW) return GODE_E_NULLPTR;
-    if (pre && pre->n > 0) { rc = check_lincomb(pre, true); if (rc) return rc; } else pre = nullptr;
-    has_time = has_time ? 1 : 0;
-    const int cg = fast_cg(d, d, groups);
-    const bool al = lincomb_aligned16(xin) && lincomb_aligned16(pre) &&
-                    !((((uintptr_t)dS) | ((uintptr_t)dx) | ((uintptr_t)part) | ((uintptr_t)W)) & 15) &&
-                    (!gamma || !(((uintptr_t)gamma) & 15));
-    if (cg < 0 || !al) return GODE_E_UNSUPPORTED;          // the caller takes the two-launch path
-    hipStream_t s = (hipStream_t)stream;
-    LinComb lc = make_lincomb(xin);
-    LinComb lpre = make_lincomb(pre);
-    const int nj = (int)(d / 16);
-    const int64_t blocks = gode_bwd_wgrad_parts(n_rows);
-    const size_t lds = ((size_t)d * (d + 4) + d + (size_t)4 * 2 * 16 * (d + 16)) * sizeof(float);
-#define GODE_BWG(NJV, CGV)                                                                          \
-    { rc = set_lds(gn_gemm_bwd_wgrad_kernel<NJV, CGV>, lds); if (rc) return rc;                     \
-      const int slot = gode_prof_begin(s, d, n_rows, (int64_t)lc.n - 1 + lpre.n, GODE_PROF_BWD_WGRAD); \
-      hipLaunchKernelGGL((gn_gemm_bwd_wgrad_kernel<NJV, CGV>), dim3((unsigned)blocks), dim3(256), lds, s, \
-                         lc, (int)n_rows, eps, W, has_time, dS, out_scale, lpre, dx, gamma, part);  \
-      gode_prof_end(s, slot);                                                                       \
-      GODE_LAUNCH_CHECK(); goto finish; }
-    // instantiated for the GroupNorm(min(32, d), d) of the reference's ODE functions (and no normalisation) only
-    GODE_DISPATCH_NJ_CG(1, 0, GODE_BWG) GODE_DISPATCH_NJ_CG(1, 1, GODE_BWG) GODE_DISPATCH_NJ_CG(2, 0, GODE_BWG)
-    GODE_DISPATCH_NJ_CG(2, 1, GODE_BWG) GODE_DISPATCH_NJ_CG(4, 0, GODE_BWG) GODE_DISPATCH_NJ_CG(4, 2, GODE_BWG)
-    GODE_DISPATCH_NJ_CG(8, 0, GODE_BWG) GODE_DISPATCH_NJ_CG(8, 4, GODE_BWG)
-#undef GODE_BWG
-    return GODE_E_UNSUPPORTED;
-finish:
-    hipLaunchKernelGGL(bwd_wgrad_finish_kernel, dim3((unsigned)(d + 1)), dim3(256), 0, s, (const float*)part, (int)blocks, (int)d,
-                       W, has_time, groups > 0 ? gamma : nullptr, groups > 0 ? beta : nullptr, dW,
-                       groups > 0 ? dgamma : nullptr, groups > 0 ? dbeta : nullptr);
     GODE_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,241 @@
+// mlp.hip — the dense products of the QC edge encoder and its update step, gfx950.
+//
+// Replaces, for the hot path of the QC models (the EdgeEncoderMLP half):
+//   * QC/layers.py:46-86  EdgeEncoderMLP = TransitionMLP(5 -> 2667 -> 5329): `self.f(self.linear(input))`,
+//     `torch.mm(input, self.weight) + self.bias` on E ~ 760 edge rows, and their autograd - the largest products of a
+//     QM9 training step (2 x 760 x 2667 x 5329 = 21.6 GFLOP each: H W2, dA W2^T, H^T dA);
+//   * QC/train_egcn.py's `optimizer.step()` (torch.optim.Adam over 14.3 M parameters) as ONE launch.
+//
+// gode_gemm_f32: C = op(A) op(B) on the exact fp32 matrix instruction (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered
+// fmaf chain), 128 x 128 x 16 block tiles staged k-major in LDS (conflict-free operand reads), 4 waves of 64 x 64 each,
+// next tile's global loads in registers while the current one multiplies; arbitrary M, N, K and leading dimensions
+// (2667 and 5329 floats per row: rows are not 16-byte aligned, so operands are loaded as dwords; they live in L2 /
+// Infinity Cache - 8, 16 and 57 MB - and the kernel is matrix-bound, not load-bound).  Fused epilogue: + bias[col],
+// relu, or * (mask[row][col] > 0) (the relu mask of the hidden layer in dH = (dA W2^T) * [H > 0]).
+// Bound: fp32 MFMA (157.3 TFLOP/s): 0.14 ms per product at the peak.
+//
+// gode_adam_f32: one launch over a table of (param, grad, exp_avg, exp_avg_sq, length) - torch.optim.Adam's update
+// (L2 weight decay folded into the gradient, bias corrections from a device-resident step counter so that the launch
+// can sit inside a HIP graph).  Bound: HBM (16 B read + 12 B written per parameter).
+#include "common.h"
+#include "dense_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;    // BM: the tall variant; the flat one has 64 rows
+constexpr int LDT = 128 + 4;                 // floats per k-row of a staged tile (k-major): +4 keeps the transposing stores at 2-way
+
+// Loads this thread's ROWS/16 elements of a (ROWS x 16) operand tile into registers / stores them k-major into LDS.
+//   KCONTIG: source is [row][k] with k contiguous (A of C = A B; A and B of C = A B^T)
+//   !KCONTIG: source is [k][row] with row contiguous (B of C = A B; A and B of C = A^T B)
+// Thread t, element j:  KCONTIG: row = (t >> 2) + 64 (j >> 2), k = 4 (t & 3) + (j & 3)  - 2-way LDS store conflicts (free)
+//                       else   : row = (t & 31) + 32 (j % (ROWS/32)), k = (t >> 5) + 8 (j / (ROWS/32))  - coalesced, conflict-free
+template <bool KCONTIG, int ROWS>
+__device__ __forceinline__ void tile_coords(int j, int& row, int& k) {
+    const int t = threadIdx.x;
+    if (KCONTIG) { row = (t >> 2) + 64 * (j >> 2); k = 4 * (t & 3) + (j & 3); }
+    else { row = (t & 31) + 32 * (j % (ROWS / 32)); k = (t >> 5) + 8 * (j / (ROWS / 32)); }
+}
+template <bool KCONTIG, int ROWS>
+__device__ __forceinline__ void tile_load(const float* __restrict__ src, int64_t ld, int row0, int n_rows, int k0, int n_k,
+                                          float (&v)[ROWS / 16]) {
+#pragma unroll
+    for (int j = 0; j < ROWS / 16; ++j) {
+        int row, k;
+        tile_coords<KCONTIG, ROWS>(j, row, k);
+        // unconditional loads from clamped coordinates (a load under a branch is waited for at the join, which would
+        // put the wait in front of the matrix phase); out-of-range elements are zeroed afterwards
+        const bool ok = row0 + row < n_rows && k0 + k < n_k;
+        const int rr = row0 + row < n_rows ? row0 + row : n_rows - 1, kk = k0 + k < n_k ? k0 + k : n_k - 1;
+        const int64_t off = KCONTIG ? (int64_t)rr * ld + kk : (int64_t)kk * ld + rr;
+        const float x = src[off];
+        v[j] = ok ? x : 0.f;
+    }
+}
+template <bool KCONTIG, int ROWS>
+__device__ __forceinline__ void tile_store(float* tile /* [BK][LDT] */, const float (&v)[ROWS / 16]) {
+#pragma unroll
+    for (int j = 0; j < ROWS / 16; ++j) {
+        int row, k;
+        tile_coords<KCONTIG, ROWS>(j, row, k);
+        tile[k * LDT + row] = v[j];
+    }
+}
+
+// C[M x N] = opA(A) opB(B):  A_KC: A given as [M][K] (else [K][M]);  B_KC: B given as [N][K] (else [K][N]).
+// MT = 32-row tiles per wave: 2 -> 128 x 128 block tile, 1 -> 64 x 128 (products with few row tiles: fills the chip)
+template <bool A_KC, bool B_KC, int MT>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb,
+                                                          float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                          const float* __restrict__ bias, int relu,
+                                                          const float* __restrict__ mask, int64_t ldmask)
+{
+    constexpr int TM = 64 * MT;                                   // block tile rows
+    __shared__ float As[2][BK * LDT];
+    __shared__ float Bs[2][BK * LDT];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int wm = (wave >> 1) * 32 * MT, wn = (wave & 1) * 64;   // this wave's (32 MT) x 64 part of the block tile
+    const int li = l & 31, lk = l >> 5;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * BN;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    float ra[TM / 16], rb[BN / 16];
+    tile_load<A_KC, TM>(A, lda, m0, M, 0, K, ra);
+    tile_load<B_KC, BN>(B, ldb, n0, N, 0, K, rb);
+    tile_store<A_KC, TM>(As[0], ra);
+    tile_store<B_KC, BN>(Bs[0], rb);
+    __syncthreads();
+    const int n_kt = (K + BK - 1) / BK;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int cur = kt & 1;
+        tile_load<A_KC, TM>(A, lda, m0, M, (kt + 1) * BK, K, ra);     // next tile (zeros past K): in flight during the
+        tile_load<B_KC, BN>(B, ldb, n0, N, (kt + 1) * BK, K, rb);     // matrix phase
+        const float* as = As[cur] + lk * LDT + wm + li;
+        const float* bs = Bs[cur] + lk * LDT + wn + li;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float av[MT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) av[a] = as[2 * ks * LDT + 32 * a];
+            const float b0 = bs[2 * ks * LDT], b1 = bs[2 * ks * LDT + 32];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], b0, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], b1, acc[a][1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < n_kt) {
+            tile_store<A_KC, TM>(As[cur ^ 1], ra);                // the other buffer: last read in iteration kt - 1,
+            tile_store<B_KC, BN>(Bs[cur ^ 1], rb);                // which every wave left through the barrier below
+        }
+        __syncthreads();
+    }
+    // D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wn + 32 * b + li;
+            const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (row < M && col < N) {
+                    float v = acc[a][b][e] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (mask) v = mask[(int64_t)row * ldmask + col] > 0.f ? v : 0.f;
+                    C[(int64_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
+// ---- Adam -----------------------------------------------------------------------------------------------------------
+struct AdamChunk { int32_t tensor; int32_t pad; int64_t start; };   // 16 B per chunk of kAdamChunk elements
+constexpr int kAdamChunk = 8192;
+
+__global__ void adam_tick_kernel(float* state /* [step, 1/bc1, 1/sqrt(bc2)] */, float beta1, float beta2) {
+    const float step = state[0] + 1.f;
+    state[0] = step;
+    // bias corrections in double: 1 - beta^t loses every digit in float for small t * (1 - beta)
+    state[1] = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
+    state[2] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+}
+
+// torch.optim.Adam (no amsgrad, no maximize), single-tensor formula: g += wd * p; m.lerp_(g, 1 - b1);
+// v = b2 v + (1 - b2) g g; p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps).
+// The tensor table travels BY VALUE in the kernel arguments (2.5 KB): nothing to upload when a gradient tensor was
+// re-allocated, and a captured launch carries the addresses it was captured with.
+__global__ __launch_bounds__(256) void adam_kernel(gode_adam_args_t a, const AdamChunk* __restrict__ chunks,
+                                                   const float* __restrict__ state, float lr, float beta1, float beta2,
+                                                   float eps, float wd)
+{
+    const AdamChunk ch = chunks[blockIdx.x];
+    float* p = a.param[ch.tensor];
+    const float* g = a.grad[ch.tensor];
+    float* m = a.exp_avg[ch.tensor];
+    float* v = a.exp_avg_sq[ch.tensor];
+    const int64_t len = a.len[ch.tensor];
+    const float step_size = lr * state[1], inv_bc2_sqrt = state[2];
+    const int64_t end = ch.start + kAdamChunk < len ? ch.start + kAdamChunk : len;
+    for (int64_t i = ch.start + threadIdx.x; i < end; i += 256) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        float mi = m[i];
+        mi = mi + (gi - mi) * (1.f - beta1);
+        const float vi = fmaf(1.f - beta2, gi * gi, beta2 * v[i]);
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                             const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
+                             const float* mask, int64_t ldmask, void* stream)
+{
+    if (M < 0 || N < 0 || K < 0) return GODE_E_SHAPE;
+    if (M == 0 || N == 0) return 0;
+    if (K == 0) return GODE_E_SHAPE;
+    if (!A || !B || !C) return GODE_E_NULLPTR;
+    if (M > INT32_MAX - 256 || N > INT32_MAX - 256 || K > INT32_MAX - 256) return GODE_E_RANGE;
+    // A is M x K (trans_a = 0, row-major, lda >= K) or K x M (trans_a = 1, lda >= M); B is K x N (trans_b = 0, ldb >= N)
+    // or N x K (trans_b = 1, ldb >= K)
+    if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N || (mask && ldmask < N)) return GODE_E_SHAPE;
+    // 128 x 128 block tiles; 64 x 128 when that leaves fewer than one block per CU (the 760-row products of a QM9 batch)
+    const int64_t nb = (N + BN - 1) / BN;
+    const bool small = ((M + BM - 1) / BM) * nb < 256;
+    const int64_t tm = small ? 64 : BM;
+    const dim3 grid((unsigned)nb, (unsigned)((M + tm - 1) / tm));
+    if (grid.y > 65535) return GODE_E_RANGE;
+    hipStream_t s = (hipStream_t)stream;
+#define GODE_GEMM2(AKC, BKC, MTV) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, MTV>), grid, dim3(256), 0, s, A, lda, B, ldb, \
+                                                     C, ldc, (int)M, (int)N, (int)K, bias, relu ? 1 : 0, mask, ldmask)
+#define GODE_GEMM(AKC, BKC) { if (small) GODE_GEMM2(AKC, BKC, 1); else GODE_GEMM2(AKC, BKC, 2); }
+    if (!trans_a && !trans_b) GODE_GEMM(true, false)
+    else if (!trans_a && trans_b) GODE_GEMM(true, true)
+    else if (trans_a && !trans_b) GODE_GEMM(false, false)
+    else GODE_GEMM(false, true)
+#undef GODE_GEMM
+#undef GODE_GEMM2
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t gode_adam_chunk(void) { return kAdamChunk; }
+
+extern "C" int gode_adam_tick_f32(float* state, float beta1, float beta2, void* stream)
+{
+    if (!state) return GODE_E_NULLPTR;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_adam_f32(const gode_adam_args_t* args, int32_t n_tensors, const void* chunks, int64_t n_chunks,
+                             const float* state, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             void* stream)
+{
+    if (n_chunks < 0 || n_tensors < 0 || n_tensors > GODE_ADAM_MAX_TENSORS) return GODE_E_SHAPE;
+    if (!state || !args) return GODE_E_NULLPTR;
+    if (n_chunks == 0) return 0;
+    if (!chunks) return GODE_E_NULLPTR;
+    if (n_chunks > INT32_MAX) return GODE_E_RANGE;
+    for (int i = 0; i < n_tensors; ++i)
+        if (args->len[i] > 0 && (!args->param[i] || !args->grad[i] || !args->exp_avg[i] || !args->exp_avg_sq[i])) return GODE_E_NULLPTR;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, *args,
+                       (const AdamChunk*)chunks, state, lr, beta1, beta2, eps, weight_decay);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}

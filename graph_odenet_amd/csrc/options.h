@@ -4,6 +4,5 @@ int gode_opt_gemm_split();   // GODE_GEMM_SPLIT (default 2): split-bf16 forward 
 int gode_opt_overlap();      // GODE_OVERLAP (default 1): two-stream schedule of the adjoint rk4 driver
 int gode_opt_wgrad_split();  // GODE_WGRAD_SPLIT (default 8): weight gradient at d = 128 from exact bf16 pieces with 8 (or 6) piece products per product; 0 = fp32-MFMA kernel
 int gode_opt_wgrad_split_small();  // wgrad_split_small (default 0): use it below 65 536 rows too (tests)
-int gode_opt_bwd_split();    // GODE_BWD_SPLIT (default 0: measured at -0.45 % of the step): VJP at d = 128 from exact bf16 pieces (eight piece products)
 int gode_opt_bwd_pc();       // GODE_BWD_PC (default 1): VJP at d = 128, >= 65 536 rows in producer / consumer form on the bf16 matrix cores (gemm_pc.hip)
 int gode_opt_fwd_pc();       // GODE_FWD_PC (default 3): forward product likewise; bit 0 = launches of <= 2 terms, bit 1 = launches of >= 3 terms or with x_out

@@ -3,7 +3,8 @@
     gn_time_linear(x, t, W, gamma, beta, groups, eps)   S = [t | GroupNorm(x)] @ W     (GCN/models.py:175-177 + layers.py:70)
     graph_aggregate(graph, S, bias, relu)                relu?(A @ S + bias)             (GCN/layers.py:71-75, models.py:178)
 
-    dense(x, W, bias)                                    x @ W (+ bias)                  (torch.mm / nn.Linear call sites)
+    dense(x, W, bias)                                    x @ W (+ bias), tall and skinny (torch.mm call sites of the graph layers)
+    affine / linear / Linear / mlp2                      x @ W + b of any shape on the tiled GEMM (QC/layers.py MyLinear, nn.Linear, TransitionMLP)
 
 Used by modules that are not covered by a fused ODE field (ODEfunc2, stand-alone calls).
 """
@@ -73,6 +74,92 @@ def dense(x, W, bias=None):
     once per call: weights are small next to the activations)."""
     y = _DenseFn.apply(x, W)
     return y if bias is None else y + bias
+
+
+class _AffineFn(torch.autograd.Function):
+    """y = x @ op(W) + b on csrc/mlp.hip's tiled fp32-MFMA GEMM (any shape): W is (in, out) with w_out_in False
+    (QC/layers.py MyLinear: torch.mm(input, self.weight) + self.bias) or (out, in) as nn.Linear stores it."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, w_out_in):
+        x, W = x.contiguous(), W.contiguous()
+        ctx.w_out_in = w_out_in
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return ops.gemm(x, W, trans_b=w_out_in, bias=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.gemm(dy, W, trans_b=not ctx.w_out_in)
+        if ctx.needs_input_grad[1]:
+            gw = ops.gemm(dy, x, trans_a=True) if ctx.w_out_in else ops.gemm(x, dy, trans_a=True)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+            ops.colsum_(gb, dy)
+        return gx, gw, gb, None
+
+
+def affine(x, W, bias=None):
+    """x @ W + bias, W stored (in, out)."""
+    return _AffineFn.apply(x, W, bias, False)
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear on own kernels: weight stored (out, in)."""
+    return _AffineFn.apply(x, weight, bias, True)
+
+
+class Linear(torch.nn.Linear):
+    """nn.Linear (same parameters and state_dict keys) whose 2-D GPU path runs on gode_gemm_f32."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32:
+            return linear(x, self.weight, self.bias)
+        return super().forward(x)
+
+
+class _Mlp2Fn(torch.autograd.Function):
+    """y = relu(x W1 + b1) W2 + b2 - the TransitionMLP of QC/layers.py:67-77, in particular the edge encoder
+    (5 -> 2667 -> 5329 on the ~760 edge rows of a QM9 batch: QC/layers.py:79-86) - as two launches forward and five
+    backward of gode_gemm_f32 with bias / relu / relu-mask fused into the epilogues:
+        H = relu(x W1 + b1);  y = H W2 + b2
+        dW2 = H^T dy;  db2 = colsum(dy);  dH = (dy W2^T) * [H > 0];  dW1 = x^T dH;  db1 = colsum(dH);  dx = dH W1^T"""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        x, W1, W2 = x.contiguous(), W1.contiguous(), W2.contiguous()
+        H = ops.gemm(x, W1, bias=b1, relu=True)
+        y = ops.gemm(H, W2, bias=b2)
+        ctx.save_for_backward(x, H, W1, W2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, H, W1, W2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        f = dict(dtype=torch.float32, device=dy.device)
+        gW2 = ops.gemm(H, dy, trans_a=True) if need[3] else None
+        gb2 = ops.colsum_(torch.empty(dy.shape[1], **f), dy) if (ctx.has_bias[1] and need[4]) else None
+        gx = gW1 = gb1 = None
+        if need[0] or need[1] or need[2]:
+            dH = ops.gemm(dy, W2, trans_b=True, mask=H)
+            if need[1]:
+                gW1 = ops.gemm(x, dH, trans_a=True)
+            if ctx.has_bias[0] and need[2]:
+                gb1 = ops.colsum_(torch.empty(dH.shape[1], **f), dH)
+            if need[0]:
+                gx = ops.gemm(dH, W1, trans_b=True)
+        return gx, gW1, gb1, gW2, gb2
+
+
+def mlp2(x, W1, b1, W2, b2):
+    return _Mlp2Fn.apply(x, W1, b1, W2, b2)
 
 
 class _GraphAggregateFn(torch.autograd.Function):

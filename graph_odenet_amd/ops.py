@@ -309,40 +309,34 @@ def rect_wgrad(x, dS):
     return out
 
 
-def gn_time_gemm_bwd_wgrad(x_terms, n_rows, d, groups, eps, gamma, beta, W, has_time, dS, out_scale=1.0, out=None,
-                           pre_terms=None, dW=None, dgamma=None, dbeta=None):
-    """VJP and weight gradient in one pass (gode_gn_time_gemm_bwd_wgrad_f32).  Returns (dx, dW, dgamma, dbeta), or
-    None when the shape is outside the fused path (use gn_time_gemm_bwd + wgrad then)."""
+def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, mask=None, out=None):
+    """C = op(A) @ op(B) (+ bias) (relu) (* [mask > 0]) on csrc/mlp.hip's fp32-MFMA GEMM (row-major matrices with unit
+    column stride; any leading dimension)."""
     lib = _lib.load()
-    _need(W, "W"); _need(gamma, "gamma"); _need(beta, "beta"); _need(dS, "dS")
-    if _need_terms(x_terms, "x") != n_rows * d:
-        raise ValueError("gn_time_gemm_bwd_wgrad: x terms have wrong size")
-    k = d + (1 if has_time else 0)
-    if tuple(W.shape) != (k, d) or dS.numel() != n_rows * d:
-        raise ValueError("gn_time_gemm_bwd_wgrad: W must be (%d, %d) and dS n x d" % (k, d))
-    f = dict(dtype=torch.float32, device=W.device)
-    out = torch.empty(n_rows, d, **f) if out is None else out
-    dW = torch.empty(k, d, **f) if dW is None else dW
-    if groups > 0:
-        dgamma = torch.empty(d, **f) if dgamma is None else dgamma
-        dbeta = torch.empty(d, **f) if dbeta is None else dbeta
-    for t, nm in ((out, "out"), (dW, "dW"), (dgamma, "dgamma"), (dbeta, "dbeta")):
-        _need(t, nm)
-    part = torch.empty(lib.gode_bwd_wgrad_parts(n_rows) * (d * d + d), **f)
-    lc = lincomb(x_terms)
-    pre = None
-    if pre_terms is not None:
-        if _need_terms(pre_terms, "pre") != n_rows * d:
-            raise ValueError("gn_time_gemm_bwd_wgrad: pre terms have wrong size")
-        pre = lincomb(pre_terms)
-    rc = lib.gode_gn_time_gemm_bwd_wgrad_f32(ctypes.byref(lc), n_rows, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(W),
-                                             1 if has_time else 0, ptr(dS), float(out_scale),
-                                             ctypes.byref(pre) if pre is not None else None, ptr(out), ptr(part), ptr(dW),
-                                             ptr(dgamma), ptr(dbeta), stream_ptr())
-    if rc == -5:                         # GODE_E_UNSUPPORTED
-        return None
-    check(rc, "gode_gn_time_gemm_bwd_wgrad_f32")
-    return out, dW, dgamma, dbeta
+    lda, ldb = _need_rows(A, "A"), _need_rows(B, "B")
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != K2:
+        raise ValueError("gemm: inner dimensions differ (%d vs %d)" % (K, K2))
+    _need(bias, "bias")
+    if bias is not None and bias.numel() != N:
+        raise ValueError("gemm: bias must have %d elements" % N)
+    ldm = 0
+    if mask is not None:
+        ldm = _need_rows(mask, "mask")
+        if tuple(mask.shape) != (M, N):
+            raise ValueError("gemm: mask must be %d x %d" % (M, N))
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    ldc = _need_rows(out, "out")
+    if tuple(out.shape) != (M, N):
+        raise ValueError("gemm: out must be %d x %d" % (M, N))
+    if K == 0:
+        out.zero_()
+        return out if bias is None else out.add_(bias)
+    check(lib.gode_gemm_f32(1 if trans_a else 0, 1 if trans_b else 0, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
+                            ptr(bias), 1 if relu else 0, ptr(mask), ldm, stream_ptr()), "gode_gemm_f32")
+    return out
 
 
 def reduce_parts_(out, part, scale=1.0, accumulate=False):

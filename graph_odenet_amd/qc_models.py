@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .functional import GroupNorm
+from .functional import Linear as GodeLinear
 from .graph import RECORDS_MIN_NNZ, CSRGraph, incidence_from_index
 from .qc_layers import EdgeGraphConvolution, MPNN_enn_edge
 
@@ -31,6 +32,9 @@ class MyLinear(nn.Module):
                 self.bias.uniform_(-bound, bound)
 
     def forward(self, x):
+        if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32:
+            from .functional import affine
+            return affine(x, self.weight, self.bias)          # gode_gemm_f32 (+ bias epilogue), own autograd
         y = torch.mm(x, self.weight)
         return y if self.bias is None else y + self.bias
 
@@ -64,6 +68,11 @@ class TransitionMLP(nn.Module):
         self.mlp = MLP(in_features, [(in_features + out_features) // 2], out_features, bias=bias)
 
     def forward(self, x):
+        first, last = self.mlp.layers[0], self.mlp.layers[1]
+        if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and first.f is F.relu:
+            # both layers, their biases and the relu (and, backward, its mask) on gode_gemm_f32: functional.mlp2
+            from .functional import mlp2
+            return mlp2(x, first.linear.weight, first.linear.bias, last.weight, last.bias)
         return self.mlp(x)
 
 
@@ -237,11 +246,11 @@ class MPNN_ENN_K_Sum(_QCBase):
     def __init__(self, node_features=None, edge_features=None, target_features=1, hidden_features=73, num_layers=3,
                  s2s_processing_steps=12, type="regression", dropout=0.5, **kwargs):
         super().__init__()
-        self.input = nn.Linear(node_features, hidden_features)
+        self.input = GodeLinear(node_features, hidden_features)
         self.ee = EdgeEncoderMLP(edge_features, hidden_features)
         self.mpnn = MPNN_enn_edge(edge_features, hidden_features)
         self.mpnn.set_T(num_layers)
-        self.output = nn.Linear(hidden_features, target_features)
+        self.output = GodeLinear(hidden_features, target_features)
         self._finish(type, target_features)
 
     def forward(self, node_features, edge_features, Esrc, Etgt, batch):
@@ -253,12 +262,12 @@ class MPNN_ENN_K_Set2Set(_QCBase):
     def __init__(self, node_features=None, edge_features=None, target_features=1, hidden_features=73, num_layers=3,
                  s2s_processing_steps=12, type="regression", dropout=0.5, **kwargs):
         super().__init__()
-        self.input = nn.Linear(node_features, hidden_features)
+        self.input = GodeLinear(node_features, hidden_features)
         self.ee = EdgeEncoderMLP(edge_features, hidden_features)
         self.mpnn = MPNN_enn_edge(edge_features, hidden_features)
         self.mpnn.set_T(num_layers)
         self.s2s = Set2Set(hidden_features, s2s_processing_steps, num_layers=1)
-        self.output = nn.Linear(hidden_features, target_features)
+        self.output = GodeLinear(hidden_features, target_features)
         self._finish(type, target_features)
 
     def forward(self, node_features, edge_features, Esrc, Etgt, batch):
@@ -368,10 +377,10 @@ class MPNN_ENN_Sum(_Fixed):
     def __init__(self, node_features, edge_features, hidden_features, out_features, processing_steps=12,
                  type="regression", **kwargs):
         super().__init__()
-        self.input = nn.Linear(node_features, hidden_features)
+        self.input = GodeLinear(node_features, hidden_features)
         self.ee = EdgeEncoderMLP(edge_features, hidden_features)
         self.mpnn = MPNN_enn_edge(edge_features, hidden_features)
-        self.output = nn.Linear(hidden_features, out_features)
+        self.output = GodeLinear(hidden_features, out_features)
         self.type = type
 
     def forward(self, node_features, edge_features, Esrc, Etgt, batch):
@@ -385,11 +394,11 @@ class MPNN_ENN_Set2Set(_Fixed):
     def __init__(self, node_features, edge_features, hidden_features, out_features, processing_steps=12,
                  type="regression", **kwargs):
         super().__init__()
-        self.input = nn.Linear(node_features, hidden_features)
+        self.input = GodeLinear(node_features, hidden_features)
         self.ee = EdgeEncoderMLP(edge_features, hidden_features)
         self.mpnn = MPNN_enn_edge(edge_features, hidden_features)
         self.s2s = Set2Set(hidden_features, processing_steps, num_layers=1)
-        self.output = nn.Linear(hidden_features, out_features)
+        self.output = GodeLinear(hidden_features, out_features)
         self.type = type
 
     def forward(self, node_features, edge_features, Esrc, Etgt, batch):

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from . import models
 from .data import load_captured, load_planetoid
+from .optim import Adam
 from .parallel import shard_range
 from .train_res import accuracy
 
@@ -92,7 +93,7 @@ class Sweep:
     def one_run(self, model, nlayers, rec, run):
         """Trains one model; fills rec[...][nlayers, run] and returns (epochs used, test accuracy)."""
         a = self.args
-        opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
+        opt = Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
         for ep in range(a.epochs):
             lv, av = self.epoch(model, opt)
             rec["layer_val_loss"][nlayers, run, ep] = lv

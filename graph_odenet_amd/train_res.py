@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from . import gat_models, models
 from .data import load_captured, load_captured_gat, load_planetoid, load_planetoid_gat
+from .optim import Adam
 from .parallel import shard_range
 
 def _model_dict(mod):
@@ -88,7 +89,7 @@ class Trainer:
             from . import gat_heads
             table = _model_dict(gat_heads.zoo(a.heads))
         model = table[a.model](**kw).to(self.device)
-        opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
+        opt = Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)       # optim.py: torch.optim.Adam's update, one launch
         return model, opt
 
     # hooks of the row-partitioned trainer below
@@ -182,7 +183,7 @@ class PartitionedTrainer(Trainer):
         if self.is_ode:
             kw.update(method=a.method, step_size=a.step_size, tol=a.tol)
         model = VARIANTS[a.variant][a.model](**kw).to(self.device)       # same seed on every rank: same initial weights
-        opt = torch.optim.Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)
+        opt = Adam(model.parameters(), lr=a.lr, weight_decay=a.weight_decay)       # optim.py: torch.optim.Adam's update, one launch
         self._bucket_of = {id(model): self._GradBucket(model)}
         return model, opt
 

@@ -24,6 +24,8 @@
  *                                in_features != out_features, and its autograd (dY W^T, X^T dY)
  *   gode_lincomb_f32             torchdiffeq RK stage input / solution combine (call site GCN/models.py:192)
  *   gode_rk_errnorm_f32          torchdiffeq dopri5 mixed-tolerance error ratio (same call site)
+ *   gode_gemm_f32                QC/layers.py:46-86 EdgeEncoderMLP (torch.mm + bias + relu on the edge rows) and its autograd
+ *   gode_adam_f32                optimizer.step() of QC/train_egcn.py, GCN/train_res.py:97 (torch.optim.Adam)
  *   gode_gat_*                   GAT/layers.py:40-55 (and :104-120)
  *   gode_edge_matvec_*           QC/mpnn.py:27-29, QC/layers.py:143-145
  */
@@ -63,9 +65,11 @@ int         gode_abi_version(void);
  * "wgrad_split" (8 default / 6 / 0: weight gradient at d = 128 and >= 65 536 rows formed on the bf16 matrix cores
  * from an EXACT three-way cut of every fp32 operand - 8: all piece products down to 2^-32 of a product, i.e. more
  * accurate than an fp32 FMA chain; 6: down to 2^-23; 0: fp32-MFMA kernel), "wgrad_split_small" (0/1, default 0: use
- * that kernel below 65 536 rows too), "bwd_split" (0 default / 1: the VJP at d = 128 in the same way - parity-green,
- * measured at -0.45 % of the benchmark step, not a default).  Initial values come from GODE_GEMM_SPLIT / GODE_OVERLAP /
- * GODE_WGRAD_SPLIT / GODE_BWD_SPLIT.
+ * the bf16-piece kernels below 65 536 rows too), "bwd_pc" (1 default / 0: the VJP at d = 128 and >= 65 536 rows in the
+ * same exact bf16-piece arithmetic, producer / consumer form, csrc/gemm_pc.hip; 0: fp32-MFMA kernel), "fwd_pc" (3
+ * default: the forward product likewise - bit 0: launches of <= 2 terms, bit 1: launches of >= 3 terms or with x_out;
+ * 0: the round-2 selection by "gemm_split").  Initial values come from GODE_GEMM_SPLIT / GODE_OVERLAP /
+ * GODE_WGRAD_SPLIT / GODE_BWD_PC / GODE_FWD_PC.
  * Returns 0 or GODE_E_UNSUPPORTED. */
 int         gode_set_option(const char* name, int value);
 int         gode_get_option(const char* name);
@@ -197,19 +201,6 @@ int gode_wgrad_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t
                    const float* dS, int64_t d_out, int has_time,
                    float* dW_part, void* stream);
 
-/* VJP and weight gradient of S = [t | GroupNorm(x)] W in ONE pass over dS and x (square W, d in {16, 32, 64, 128},
- * GroupNorm with 1, 2 or 4 channels per group or none; 16-byte aligned operands) - what an adjoint stage needs from
- * autograd of GCN/models.py:175-177 + GCN/layers.py:70:
- *   dx = out_scale * GN'(x)^T (dS W1^T) (+ sum pre),  dW ((d+has_time) x d; row 0 = colsum(dS) with has_time),
- *   dgamma, dbeta (d each; nullable; written when groups > 0).
- * `part`: gode_bwd_wgrad_parts(n_rows) * (d*d + d) floats of scratch.  Returns GODE_E_UNSUPPORTED for shapes outside
- * this path (the caller then uses gode_gn_time_gemm_bwd_f32 + gode_wgrad_f32). */
-int64_t gode_bwd_wgrad_parts(int64_t n_rows);
-int gode_gn_time_gemm_bwd_wgrad_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d, int32_t groups,
-                                    float eps, const float* gamma, const float* beta, const float* W, int has_time,
-                                    const float* dS, float out_scale, const gode_lincomb_t* pre /* host, nullable */,
-                                    float* dx, float* part, float* dW, float* dgamma, float* dbeta, void* stream);
-
 /* The rectangular dense products of GraphConvolution (GCN/layers.py:32 `support = torch.mm(input, self.weight)` with
  * in_features != out_features, and its autograd), exact fp32 (v_mfma_f32_16x16x4_f32).  Row-major operands with leading
  * dimensions; any K, M >= 1; rows 16-byte aligned with ld % 4 == 0 take the vector path.
@@ -225,6 +216,32 @@ int gode_rect_gemm_nt_f32(const float* dS, int64_t ldds, int64_t n_rows, int64_t
 int64_t gode_rect_wgrad_parts(int64_t n_rows);
 int gode_rect_wgrad_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, const float* dS, int64_t ldds,
                         int64_t M, float* part, void* stream);
+
+/* C[M x N] = op(A) op(B) (+ bias[col]) (relu) (* [mask[row][col] > 0]) on the exact fp32 matrix instruction: the dense
+ * products of the QC edge encoder (QC/layers.py:46-86: relu(e W1 + b1) W2 + b2 on the edge rows of a batch, and their
+ * autograd dA W2^T * [H > 0], H^T dA, e^T dH).  trans_a = 0: A is M x K row-major (lda >= K); 1: A is K x M (lda >= M).
+ * trans_b = 0: B is K x N (ldb >= N); 1: B is N x K (ldb >= K).  bias, mask nullable.  Any sizes / leading dimensions. */
+int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                  const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
+                  const float* mask, int64_t ldmask, void* stream);
+
+/* torch.optim.Adam's update (no amsgrad; L2 weight decay) of up to GODE_ADAM_MAX_TENSORS tensors in ONE launch - the
+ * `optimizer.step()` of QC/train_egcn.py / GCN/train_res.py:97.  args (host; copied into the kernel arguments): device
+ * addresses and lengths of the tensors; chunks (device): n_chunks x {int32 tensor, int32 0, int64 start}, the work
+ * list, one entry per gode_adam_chunk() elements of a tensor; state (device): 3 floats {step, 1/(1-beta1^step),
+ * 1/sqrt(1-beta2^step)}, advanced once per optimizer step by gode_adam_tick_f32 (a kernel: capturable). */
+#define GODE_ADAM_MAX_TENSORS 64
+typedef struct gode_adam_args {
+    float*       param[GODE_ADAM_MAX_TENSORS];
+    const float* grad[GODE_ADAM_MAX_TENSORS];
+    float*       exp_avg[GODE_ADAM_MAX_TENSORS];
+    float*       exp_avg_sq[GODE_ADAM_MAX_TENSORS];
+    int64_t      len[GODE_ADAM_MAX_TENSORS];
+} gode_adam_args_t;
+int64_t gode_adam_chunk(void);
+int gode_adam_tick_f32(float* state, float beta1, float beta2, void* stream);
+int gode_adam_f32(const gode_adam_args_t* args /* host */, int32_t n_tensors, const void* chunks, int64_t n_chunks,
+                  const float* state, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* out[j] (+)= scale * sum_p part[p*len + j]   (accumulate != 0 adds to out) */
 int gode_reduce_parts_f32(float* out, const float* part, int64_t n_part, int64_t len,
@@ -472,12 +489,11 @@ int gode_gru_cell_f32_bwd(const float* x, const float* m, const float* w_ih, con
  * per-launch milliseconds, feature width d, record count (SpMM) or row count (dense) and `extra` = number of
  * additional n_rows x d operand arrays the launch read or wrote besides its plain operands (SpMM: pre terms +
  * cotangent terms + Y2; dense: stage terms beyond the first, + x_out, + pre terms).
- * gode_prof_kinds: what each launch was - GODE_PROF_SPMM / _GEMM_FWD / _GEMM_BWD / _WGRAD / _BWD_WGRAD. */
+ * gode_prof_kinds: what each launch was - GODE_PROF_SPMM / _GEMM_FWD / _GEMM_BWD / _WGRAD. */
 #define GODE_PROF_SPMM     0
 #define GODE_PROF_GEMM_FWD 1
 #define GODE_PROF_GEMM_BWD 2
 #define GODE_PROF_WGRAD    3
-#define GODE_PROF_BWD_WGRAD 4
 /* which kernel of the family ran, OR-ed into the kind of a dense launch (kind & 0xff = family, kind >> 8 = form):
  * exact-fp32 MFMA kernel; bf16-piece kernel, every wave loading + cutting + multiplying; bf16-piece kernel in
  * producer / consumer form (wgrad_split_kernel, gemm_pc.hip) */

@@ -205,7 +205,8 @@ def test_c4_full_size_training_steps_match_reference(golden, name):
                                  s2s_processing_steps=12, dropout=0.0)
     assert sum(p.numel() for p in m.parameters()) == int(g[name + "__n_params"])
     m = fill_by_name(m).to(dev()).train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    from graph_odenet_amd.optim import Adam
+    opt = Adam(m.parameters(), lr=1e-3)                              # the product's one-launch Adam against the reference's torch.optim.Adam steps
     losses = []
     for _ in range(3):
         opt.zero_grad()
@@ -277,7 +278,8 @@ def test_captured_qc_step_matches_eager(name):
         torch.manual_seed(3)
         m = getattr(qc_models, name)(node_features=13, edge_features=5, target_features=12, hidden_features=24,
                                      num_layers=2, s2s_processing_steps=3, dropout=0.0).to(dev())
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+        from graph_odenet_amd.optim import Adam
+        opt = Adam(m.parameters(), lr=1e-3)
         losses = []
         if captured:
             step = CapturedQCStep(m, opt, F.mse_loss, warmup=1)
@@ -446,7 +448,7 @@ def test_gat_fused_field_matches_autograd_path(golden, method, opts):
     for k in res[True][2]:
         close(res[True][2][k], res[False][2][k], tol * 5, "grad " + k)
     if method == "rk4":
-        assert res[True][3] == res[False][3] == 32
+        assert res[True][3] == res[False][3] == 16 + 17         # the adjoint count includes torchdiffeq's dL/dt evaluation (odeint.py)
 
 
 @pytest.mark.parametrize("name", ["MPNN_ENN_K_Sum", "MPNN_ENN_K_Set2Set", "EdgeGCN_K_Sum", "EdgeGCN_K_Set2Set",

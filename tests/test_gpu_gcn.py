@@ -590,7 +590,7 @@ def test_hip_graph_captured_solves_match_eager(native, d):
         finally:
             OI.NATIVE_RK4 = True
             OI.GRAPH_CAPTURE_MAX_ELEMS = old
-    assert res[True][1] == res[False][1] == 4 * 2 * 16
+    assert res[True][1] == res[False][1] == 4 * (16 + 17)     # 17: the adjoint's count includes torchdiffeq's dL/dt evaluation (odeint.py)
     for (o1, g1, p1), (o2, g2, p2) in zip(res[True][0], res[False][0]):
         assert torch.equal(o1, o2) and torch.equal(g1, g2)
         for a, b in zip(p1, p2):

@@ -82,7 +82,8 @@ def test_training_trajectory_matches_reference(golden, variant, name):
     assert set(sd) == set(m.state_dict().keys())
     m.load_state_dict(sd)
     m = m.to(dev)
-    opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=5e-4)
+    from graph_odenet_amd.optim import Adam
+    opt = Adam(m.parameters(), lr=0.01, weight_decay=5e-4)            # the product's optimiser (one launch), against the reference's torch.optim.Adam trajectory
     losses = []
     for _ in range(10):
         m.train(); opt.zero_grad()
@@ -121,7 +122,8 @@ def test_qc_training_trajectory_matches_reference(golden, name):
     pre = name + "__sd__"
     m.load_state_dict({k[len(pre):].replace("__", "."): torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(pre)})
     m = m.to(dev).train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    from graph_odenet_amd.optim import Adam
+    opt = Adam(m.parameters(), lr=1e-3)
     losses = []
     for _ in range(5):
         opt.zero_grad()

@@ -238,49 +238,6 @@ def test_reduce_segments_one_launch():
     close(at, ((sa[:40] * wa.double()).sum() + (sc[:7] * wc.double()).sum()).reshape(1), 1e-5 * 10, "time derivative")
 
 
-@pytest.mark.parametrize("d,groups", [(16, 16), (32, 32), (64, 32), (128, 32), (128, 0), (64, 0)])
-@pytest.mark.parametrize("n", [1, 15, 257, 4100, 70001])
-def test_fused_vjp_and_weight_gradient(d, groups, n):
-    """gode_gn_time_gemm_bwd_wgrad_f32 (one pass over dS and x: dx, dW, dgamma, dbeta) against autograd of the plain
-    torch CPU ops, with a two-term input, an output scale and accumulated pre-terms as the rk4 adjoint uses them."""
-    from graph_odenet_amd import ops
-    import torch.nn.functional as F
-    if n == 1 and groups == d:
-        pytest.skip("torch's own group_norm refuses one value per group at batch 1")
-    torch.manual_seed(d * 11 + n)
-    y, k1 = torch.randn(n, d), torch.randn(n, d)
-    h = 0.3
-    x = (y + h * k1).requires_grad_(True)
-    gam = (torch.rand(d) + 0.5).requires_grad_(True)
-    bet = (torch.rand(d) - 0.5).requires_grad_(True)
-    W = (torch.randn(d + 1, d) / d ** 0.5).requires_grad_(True)
-    t = 0.37
-    xn = F.group_norm(x, groups, gam, bet, 1e-5) if groups else x
-    S = torch.cat([torch.full((n, 1), t), xn], 1) @ W
-    dS = torch.randn(n, d)
-    S.backward(dS)
-    D = dev()
-    terms = [(1.0, y.to(D)), (h, k1.to(D))]
-    g_, b_ = (gam.detach().to(D), bet.detach().to(D)) if groups else (None, None)
-    p0 = torch.randn(n, d)
-    res = ops.gn_time_gemm_bwd_wgrad(terms, n, d, groups, 1e-5, g_, b_, W.detach().to(D), True, dS.to(D), out_scale=0.7,
-                                     pre_terms=[(2.0, p0.to(D))])
-    assert res is not None, "shape should be on the fused path"
-    dx, gW, dg, db = res
-    cg = d // groups if groups else 0
-    close(dx, 2.0 * p0 + 0.7 * x.grad, tol={0: TOL, 1: 2e-3, 2: 1e-4}.get(cg, 2e-5), what="dx")
-    rt = max(1, n ** 0.5)
-    tol = {0: TOL, 1: 2e-4, 2: 2e-5}.get(cg, TOL)
-    close(gW[1:], W.grad[1:], tol=max(tol, 2e-5) * rt, what="dW")
-    close(gW[0] * t, W.grad[0], tol=2e-5 * rt, what="dW time row")
-    if groups:
-        close(dg, gam.grad, tol=(2e-3 if cg == 1 else 2e-5) * rt, what="dgamma")
-        close(db, bet.grad, tol=2e-5 * rt, what="dbeta")
-    # shapes outside the path are refused, not mis-computed
-    assert ops.gn_time_gemm_bwd_wgrad([(1.0, torch.randn(8, 24, device=D))], 8, 24, 0, 1e-5, None, None,
-                                      torch.randn(25, 24, device=D), True, torch.randn(8, 24, device=D)) is None
-
-
 @pytest.mark.parametrize("d,dout,groups", [(16, 34, 16), (64, 130, 32), (128, 258, 32), (24, 7, 0)])
 def test_gn_time_gemm_rectangular(d, dout, groups):
     """d_out != d_in (the GAT node-level projection is d x (2o+2)): generic kernels, same parity bar."""
@@ -545,10 +502,9 @@ def test_weight_gradient_from_exact_bf16_pieces(n, groups):
 @pytest.mark.parametrize("groups", [32, 0])
 def test_vjp_from_exact_bf16_pieces(n, groups):
     """The VJP at d = 128 from exact bf16 pieces (dS and W1 cut three ways, eight piece products, fp32 accumulation, the
-    GroupNorm backward of the fp32 kernel) in its two forms - csrc/gemm_pc.hip gn_gemm_bwd_pc_kernel (option bwd_pc, the
-    default from 65 536 rows on: consumer waves with the weight slab in registers, producer waves staging dS) and
-    csrc/gemm.hip gn_gemm_bwd_split_kernel (option bwd_split) - against float64 autograd and against the fp32-MFMA
-    kernel: dx (with the fused pre-term and output scale), dgamma, dbeta; 1 / 2 terms of x in raw registers, 3 combined
+    GroupNorm backward of the fp32 kernel): csrc/gemm_pc.hip gn_gemm_bwd_pc_kernel (option bwd_pc, the default from
+    65 536 rows on: consumer waves with the weight slab in registers, producer waves staging dS) against float64
+    autograd and against the fp32-MFMA kernel: dx (with the fused pre-term and output scale), dgamma, dbeta; 1 / 2 terms of x in raw registers, 3 combined
     at load; ragged row counts (a partly empty last 32-row tile, fewer tiles than producer groups)."""
     from graph_odenet_amd import _lib, ops
     import torch.nn.functional as F
@@ -561,7 +517,7 @@ def test_vjp_from_exact_bf16_pieces(n, groups):
     gam = torch.rand(d, generator=g) + 0.5
     W = torch.randn(d + 1, d, generator=g) / d ** 0.5
     D = dev()
-    modes = {"fp32": (0, 0), "split": (1, 0), "pc": (0, 1)}                  # (bwd_split, bwd_pc)
+    modes = {"fp32": 0, "pc": 1}                                             # bwd_pc
     saved = lib.gode_get_option(b"bwd_pc")
     try:
         assert lib.gode_set_option(b"wgrad_split_small", 1) == 0
@@ -576,8 +532,7 @@ def test_vjp_from_exact_bf16_pieces(n, groups):
             for with_pre in (True, False):
                 want_dx = (pre.double() if with_pre else 0.0) + 0.5 * x.grad
                 got = {}
-                for name, (split, pc) in modes.items():
-                    assert lib.gode_set_option(b"bwd_split", split) == 0 and lib.gode_get_option(b"bwd_split") == split
+                for name, pc in modes.items():
                     assert lib.gode_set_option(b"bwd_pc", pc) == 0 and lib.gode_get_option(b"bwd_pc") == pc
                     dx, dg, db = ops.gn_time_gemm_bwd(terms, n, d, groups, 1e-5, gam.to(D), W.to(D), True, dS.to(D), out_scale=0.5,
                                                       pre_terms=[(1.0, pre.to(D))] if with_pre else None)
@@ -591,10 +546,8 @@ def test_vjp_from_exact_bf16_pieces(n, groups):
                     if groups:
                         assert (got[name][1] - g64.grad).abs().max().item() <= 3e-6 * max(1.0, g64.grad.abs().max().item()) * max(1, n ** 0.5), (name, nt)
                         assert (got[name][2] - b64.grad).abs().max().item() <= 3e-6 * max(1.0, b64.grad.abs().max().item()) * max(1, n ** 0.5), (name, nt)
-                for name in ("split", "pc"):
-                    assert (got[name][0] - got["fp32"][0]).abs().max().item() <= 2e-5 * sx
+                assert (got["pc"][0] - got["fp32"][0]).abs().max().item() <= 2e-5 * sx
     finally:
-        lib.gode_set_option(b"bwd_split", 0)
         lib.gode_set_option(b"bwd_pc", saved)
         lib.gode_set_option(b"wgrad_split_small", 0)
 
@@ -630,3 +583,108 @@ def test_rectangular_products_vs_float64(n, K, M):
     dw = ops.rect_wgrad(x.to(D), dSd[:, :M]).cpu()
     assert dw.shape == (K, M)
     assert (dw.double() - want_dw).abs().max().item() <= 3e-6 * (want_dw.abs().max().item() + 1e-30) * max(1.0, (n / 4096) ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(760, 5329, 2667), (760, 2667, 5), (5, 2667, 760), (1, 1, 1), (129, 130, 17), (64, 128, 16), (300, 73, 200)])
+def test_tiled_gemm_all_operand_layouts_and_epilogues(M, N, K):
+    """csrc/mlp.hip gode_gemm_f32 (the dense products of the QC edge encoder, QC/layers.py:46-86): C = op(A) op(B) for the
+    four operand layouts, ragged sizes (rows of 2667 / 5329 floats are not 16-byte aligned), leading dimensions, and
+    the fused epilogues (+ bias, relu, * [mask > 0]) against float64."""
+    from graph_odenet_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / max(K, 1) ** 0.5
+    bias, mask = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    D = dev()
+    ref = A.double() @ B.double()
+    scale = ref.abs().max().item() + 1e-30
+    tol = 3e-6 * scale
+    for ta in (False, True):
+        for tb in (False, True):
+            a = (A.t().contiguous() if ta else A).to(D)
+            b = (B.t().contiguous() if tb else B).to(D)
+            got = ops.gemm(a, b, trans_a=ta, trans_b=tb).cpu()
+            assert (got.double() - ref).abs().max().item() <= tol, (ta, tb)
+    a, b = A.to(D), B.to(D)
+    got = ops.gemm(a, b, bias=bias.to(D), relu=True).cpu()
+    assert (got.double() - torch.relu(ref + bias.double())).abs().max().item() <= tol
+    got = ops.gemm(a, b, mask=mask.to(D)).cpu()
+    assert (got.double() - ref * (mask > 0).double()).abs().max().item() <= tol
+    # operands and result as column blocks of wider matrices (leading dimensions)
+    wide_a, wide_b = torch.randn(M, K + 3, device=D), torch.randn(K, N + 5, device=D)
+    wide_a[:, :K], wide_b[:, :N] = a, b
+    out = torch.full((M, N + 2), 7.0, device=D)
+    ops.gemm(wide_a[:, :K], wide_b[:, :N], out=out[:, :N])
+    assert (out[:, :N].cpu().double() - ref).abs().max().item() <= tol and bool((out[:, N:] == 7.0).all())
+
+
+def test_transition_mlp_and_linear_vs_float64_autograd():
+    """functional.mlp2 / affine / linear (QC/layers.py TransitionMLP = NonLinear + MyLinear; nn.Linear): forward and every
+    gradient against float64 autograd of the same formulas, at the edge encoder's shape (E = 760 edge rows, 5 -> 2667 ->
+    5329) and a small ragged one."""
+    from graph_odenet_amd import functional as Fn
+    D = dev()
+    for E, fi, hid, fo in ((760, 5, 2667, 5329), (37, 13, 43, 73)):
+        g = torch.Generator().manual_seed(E)
+        x = torch.randn(E, fi, generator=g)
+        W1, b1 = torch.randn(fi, hid, generator=g) / fi ** 0.5, torch.randn(hid, generator=g) * 0.1
+        W2, b2 = torch.randn(hid, fo, generator=g) / hid ** 0.5, torch.randn(fo, generator=g) * 0.1
+        dy = torch.randn(E, fo, generator=g)
+        ref_in = [t.double().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+        y64 = torch.relu(ref_in[0] @ ref_in[1] + ref_in[2]) @ ref_in[3] + ref_in[4]
+        y64.backward(dy.double())
+        got_in = [t.to(D).requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+        y = Fn.mlp2(*got_in)
+        y.backward(dy.to(D))
+        close(y, y64.float(), 1e-5, "mlp2 forward")
+        for a, b, nm in zip(got_in, ref_in, ("dx", "dW1", "db1", "dW2", "db2")):
+            assert (a.grad.cpu().double() - b.grad).abs().max().item() <= 1e-5 * max(1.0, b.grad.abs().max().item()), nm
+    # affine (W stored in x out) and linear (out x in), with and without bias
+    x = torch.randn(100, 37, requires_grad=True)
+    W = torch.randn(37, 21, requires_grad=True)
+    b = torch.randn(21, requires_grad=True)
+    dy = torch.randn(100, 21)
+    (x @ W + b).backward(dy)
+    for form in ("affine", "linear"):
+        xs, bs = x.detach().to(D).requires_grad_(True), b.detach().to(D).requires_grad_(True)
+        Ws = (W.detach() if form == "affine" else W.detach().t().contiguous()).to(D).requires_grad_(True)
+        out = Fn.affine(xs, Ws, bs) if form == "affine" else Fn.linear(xs, Ws, bs)
+        out.backward(dy.to(D))
+        close(out, (x @ W + b).detach(), 1e-5, form)
+        close(xs.grad, x.grad, 1e-5, form + " dx"); close(bs.grad, b.grad, 1e-5, form + " db")
+        close(Ws.grad if form == "affine" else Ws.grad.t(), W.grad, 1e-5, form + " dW")
+
+
+def test_one_launch_adam_matches_torch_adam():
+    """graph_odenet_amd.optim.Adam (csrc/mlp.hip gode_adam_f32: the whole parameter list in one launch, step counter on
+    the device) against torch.optim.Adam on the CPU over eight steps: weight decay, a parameter that never receives a
+    gradient, one that receives it only from step 3 on, more tensors than one argument block holds (70 > 64), a change
+    of the learning rate between steps, and a state_dict round trip into torch's optimiser."""
+    from graph_odenet_amd import optim
+    g = torch.Generator().manual_seed(0)
+    shapes = [(300, 17), (5329,), (1,), (64, 64)] + [(3, 5)] * 66
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    got = [p.detach().clone().to(dev()).requires_grad_(True) for p in ref]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4)
+    o_ref, o_got = torch.optim.Adam(ref, **kw), optim.Adam(got, **kw)
+    for step in range(8):
+        grads = [torch.randn(s, generator=g) * (1 + step) for s in shapes]
+        for i, (p, q, gr) in enumerate(zip(ref, got, grads)):
+            if i == 2 or (i == 3 and step < 3):
+                p.grad = q.grad = None
+            else:
+                p.grad, q.grad = gr.clone(), gr.clone().to(dev())
+        if step == 5:
+            for o in (o_ref, o_got):
+                o.param_groups[0]["lr"] = 3e-3
+        o_ref.step(); o_got.step()
+        for i, (p, q) in enumerate(zip(ref, got)):
+            # parameter 3 joins three steps late: its own step count would differ in torch (per-parameter counters) -
+            # the group-wide device counter is what a training loop in which every parameter always has a gradient
+            # sees; checked for the parameters that were there from the start
+            if i != 3:
+                assert (q.detach().cpu() - p.detach()).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item()), (step, i)
+    assert got[2].grad is None and torch.equal(got[2].detach().cpu(), ref[2].detach())
+    sd = o_got.state_dict()
+    o_new = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in got], **kw)
+    o_new.load_state_dict(sd)                                     # torch's keys: step, exp_avg, exp_avg_sq
+    assert float(o_new.state[o_new.param_groups[0]["params"][0]]["step"]) == 8.0

@@ -39,7 +39,8 @@ def _time_steps(fn, warm=3, n=10):
 
 
 def _trainer(m, fwd, idx, y, lr=0.01, wd=5e-4):
-    opt = torch.optim.Adam(m.parameters(), lr=lr, weight_decay=wd)
+    from graph_odenet_amd.optim import Adam
+    opt = Adam(m.parameters(), lr=lr, weight_decay=wd)
 
     def step():
         m.train(); opt.zero_grad(); m.nfe = 0
@@ -111,7 +112,8 @@ def c4_qc(dev, model_name, captured=False):
     for b in range(16):
         x, ef, Esrc, Etgt, batch = qm9_like_batch(20, seed=b, device=dev)
         batches.append((x, ef, Esrc, Etgt, batch, torch.randn(20, 12, generator=torch.Generator().manual_seed(b)).to(dev)))
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    from graph_odenet_amd.optim import Adam
+    opt = Adam(net.parameters(), lr=1e-3)
     it = [0]
 
     def step():
@@ -135,7 +137,7 @@ def c4_qc(dev, model_name, captured=False):
         from graph_odenet_amd.qc_step import CapturedQCStep
         if hipgraph.memset_nodes_ok(dev):
             padded = [pad_batch(*b[:5])[:5] + (b[5],) for b in batches]
-            opt2 = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+            opt2 = Adam(net.parameters(), lr=1e-3)
             cstep = CapturedQCStep(net, opt2, F.mse_loss)
             jt = [0]
 

@@ -84,9 +84,6 @@ def main():
             rec("gn_time_gemm bwd (%d terms)" % nt,
                 timeit(lambda: ops.gn_time_gemm_bwd(terms, n, d, 32, 1e-5, gam, W, True, Y, out=OUT)), (nt + 2) * nd, fl / 1e3)
             rec("wgrad (%d terms)" % nt, timeit(lambda: ops.wgrad(terms, n, d, 32, 1e-5, gam, bet, Y, True)), (nt + 1) * nd, fl / 1e3)
-        for nt, terms in ((1, [(1.0, X)]), (2, [(1.0, X), (0.1, K1)])):
-            rec("fused bwd + wgrad (%d terms)" % nt,
-                timeit(lambda: ops.gn_time_gemm_bwd_wgrad(terms, n, d, 32, 1e-5, gam, bet, W, True, Y, out=OUT)), (nt + 2) * nd, 2 * fl / 1e3)
         t2 = [(1.0, X), (0.1, K1)]
         rec("gn_time_gemm bwd (2 terms)", timeit(lambda: ops.gn_time_gemm_bwd(t2, n, d, 32, 1e-5, gam, W, True, Y, out=OUT)), 4 * nd, fl / 1e3)
         rec("wgrad (2 terms)", timeit(lambda: ops.wgrad(t2, n, d, 32, 1e-5, gam, bet, Y, True)), 3 * nd, fl / 1e3)

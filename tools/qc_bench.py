@@ -55,7 +55,8 @@ def cpu_oracle_step(model_name, batch_size, reps):
     def mpnn_cpu(x, Esrc, Etgt, A):
         return R.mpnn_enn_edge(x, Esrc, Etgt, A, net.mpnn.update_net, net.mpnn.T)
     net.mpnn.forward = mpnn_cpu
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    from graph_odenet_amd.optim import Adam
+    opt = Adam(net.parameters(), lr=1e-3)
     x, ef, Esrc, Etgt, batch, tgt = batches[0]
     ts = []
     for _ in range(reps + 1):
@@ -99,7 +100,8 @@ def main():
     args.bucket = args.bucket or args.captured
     net, batches = build(dev, args.model, rank, args.steps + args.warmup, args.batch_size, args.bucket, args.prepared)
     broadcast_parameters(net, 0)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=args.captured)
+    from graph_odenet_amd.optim import Adam
+    opt = Adam(net.parameters(), lr=1e-3)
     bucket = GradBucket(net, overlap=not args.captured)
     cstep = None
     if args.captured:
