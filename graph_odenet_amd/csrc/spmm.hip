@@ -219,9 +219,20 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(
     int row, b, e, slot = -1;
     if (items) { const int4 it = items[gid]; row = it.x; b = it.y; e = it.z; slot = it.w; }
     else { row = gid; b = rowptr[gid]; e = rowptr[gid + 1]; }
+    // widths that are not a multiple of 4 (h = 73 of the QC models; 7 classes arrive padded to 8 and never come here):
+    // lanes over consecutive columns (coalesced row reads), four gathers in flight per lane, the sum in CSR order
     for (int c = lane; c < d; c += G) {
         float acc = 0.f;
-        for (int j = b; j < e; ++j) {
+        int j = b;
+        for (; j + 4 <= e; j += 4) {
+            const int c0 = col[j], c1 = col[j + 1], c2 = col[j + 2], c3 = col[j + 3];
+            const float x0 = X[(int64_t)c0 * ldx + c], x1 = X[(int64_t)c1 * ldx + c], x2 = X[(int64_t)c2 * ldx + c],
+                        x3 = X[(int64_t)c3 * ldx + c];
+            float v0 = 1.f, v1 = 1.f, v2 = 1.f, v3 = 1.f;
+            if (val) { v0 = val[j]; v1 = val[j + 1]; v2 = val[j + 2]; v3 = val[j + 3]; }
+            acc = fmaf(v0, x0, acc); acc = fmaf(v1, x1, acc); acc = fmaf(v2, x2, acc); acc = fmaf(v3, x3, acc);
+        }
+        for (; j < e; ++j) {
             const float v = val ? val[j] : 1.f;
             acc = fmaf(v, X[(int64_t)col[j] * ldx + c], acc);
         }

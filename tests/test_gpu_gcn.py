@@ -364,7 +364,7 @@ def test_odegcn3_dopri5_vs_oracle_on_cora(golden):
 
 def test_pubmed_dense_paper_dopri5_vs_oracle(golden):
     """C2: Pubmed's real topology, symmetric normalisation, adjacency passed DENSE as GCN-dense-paper does
-    (utils.py:87), ODEBlock with the reference's default dopri5 (rtol=atol=1e-5), d=16 (--hidden default).
+    (utils.py:87), through dense_paper.ODEGCN3 (the variant's own model class), ODEBlock with the reference's default dopri5 (rtol=atol=1e-5), d=16 (--hidden default).
     Features are synthetic (the reference checkout lacks ind.pubmed.allx): row-normalised sparse Bernoulli,
     density 10 %, F=500, seed 0.  Forward AND adjoint: same controller decisions as the oracle, logits 1e-4,
     gradients at the noise floor of the fp32 computation (fp64 replay of the same steps as ground truth)."""
@@ -380,7 +380,14 @@ def test_pubmed_dense_paper_dopri5_vs_oracle(golden):
     labels = torch.randint(0, 3, (n,), generator=gen)
     idx = torch.randperm(n, generator=gen)[:60]                 # Planetoid's 20 labelled nodes per class
     torch.manual_seed(1)
-    m = models.ODEGCN3(nfeat=500, nhid=16, nclass=3, dropout=0.0)
+    # the GCN-dense-paper variant's own class: Glorot-uniform weights with the relu gain, zero
+    # biases, dropout on the input features (p = 0 here: the oracle has no dropout), dense adjacency
+    from graph_odenet_amd import dense_paper
+    m = dense_paper.ODEGCN3(nfeat=500, nhid=16, nclass=3, dropout=0.0)
+    assert type(m.gc2.odefunc) is dense_paper.ODEfunc and float(m.gc1.bias.abs().max()) == 0.0
+    with torch.no_grad():                            # zero biases make relu'(0) ties: give them the GCN variant's spread
+        for b in (m.gc1.bias, m.gc3.bias, m.gc2.odefunc.gc1.bias):
+            b.uniform_(-0.25, 0.25)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     m = m.to(dev())
     adj_dense = adj_sp.to(dev()).to_dense()          # 19717^2 fp32 = 1.55 GB, as the reference holds it
@@ -855,8 +862,14 @@ def test_odegcn3_rk4_forward_backward_vs_oracle_on_citeseer_and_pubmed(golden, n
     noise_floor_check(out, ref_out, out64, "logits", slack=2.0)
     close(out, ref_out, 2e-5, what="logits")
     torch.nn.functional.nll_loss(out[idx.to(dev())], labels.to(dev())[idx.to(dev())]).backward()
+    # Pubmed: the ODE function's weight gradient is BIMODAL under a 1e-7 relative perturbation of the first layer's output
+    # (one relu mask of a pre-activation next to zero, on an entry with a large cotangent, decides): 2.1e-5 or 1.08e-4 from
+    # the fp64 oracle, three trials each way, with the library GEMM in the first layer as with csrc/rect.hip
+    # (tools/dev/pubmed_rect_probe.py, profiles/r03_pubmed_conditioning.txt; the fp32 oracle sits at 1.1e-5).  The bar
+    # covers both branches; on Citeseer no such tie exists and the 1e-5 floor stays.
+    floor = 2e-4 if name == "pubmed" else 1e-5
     for k, p in m.named_parameters():
-        noise_floor_check(p.grad, ref_g[k], g64[k], "grad " + k, slack=4.0)
+        noise_floor_check(p.grad, ref_g[k], g64[k], "grad " + k, slack=4.0, floor=floor)
 
 
 def test_integration_times_read_once_per_version():
