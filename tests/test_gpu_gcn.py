@@ -874,17 +874,19 @@ def test_odegcn3_rk4_forward_backward_vs_oracle_on_citeseer_and_pubmed(golden, n
 
 def test_integration_times_read_once_per_version():
     """odeint keeps the host values of a device-resident `integration_time` (the reference's ODEBlock moves it to the
-    GPU, GCN/models.py:195) on the tensor, keyed by its version counter: no device->host copy - a host synchronisation
-    - per forward pass, and an in-place change is still seen."""
+    GPU, GCN/models.py:195) on the tensor, keyed by its storage address, version counter and shape: no device->host copy
+    - a host synchronisation - per forward pass, and an in-place change or a re-pointing (`set_`) is still seen."""
     from graph_odenet_amd import odeint as OI
     t = torch.tensor([0.0, 1.0], device=dev())
     assert OI._times(t) == [0.0, 1.0]
-    assert t._gode_times == (t._version, [0.0, 1.0])
+    assert t._gode_times == ((t.data_ptr(), t._version, (2,)), [0.0, 1.0])
     got = OI._times(t)
     got[1] = 5.0                                   # callers get their own list
     assert OI._times(t) == [0.0, 1.0]
     t[1] = 2.0
     assert OI._times(t) == [0.0, 2.0]
+    t.set_(torch.tensor([0.0, 3.0], device=dev()))          # same object, other storage: no version bump
+    assert OI._times(t) == [0.0, 3.0]
     assert OI._times(torch.tensor([0.0, 0.5])) == [0.0, 0.5] and OI._times([0, 1]) == [0.0, 1.0]
 
 

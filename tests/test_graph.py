@@ -95,18 +95,3 @@ def test_relabel_is_a_symmetric_permutation_with_row_entries_in_place():
         assert torch.equal(h.val[b0:b1], g.val[a0:a1])
     deg = (g.rowptr[1:] - g.rowptr[:-1]).long() + torch.bincount(g.col.long(), minlength=n)
     assert bool((deg[order][:-1] >= deg[order][1:]).all())
-
-
-def test_tall_skinny_weight_gradient_in_row_blocks():
-    """layers._xt_g: x^T g of a rectangular layer as a batched product over row blocks (a ragged tail included) equals
-    the plain product up to summation order."""
-    import torch
-    from graph_odenet_amd.layers import _xt_g
-    gen = torch.Generator().manual_seed(0)
-    for n in (1000, 65536, 70001):
-        x, g = torch.randn(n, 24, generator=gen), torch.randn(n, 7, generator=gen)
-        want = x.double().t() @ g.double()
-        got = _xt_g(x, g)
-        assert got.shape == (24, 7)
-        assert (got.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
-    assert torch.equal(_xt_g(x[:1000], g[:1000]), torch.mm(x[:1000].t(), g[:1000]))
