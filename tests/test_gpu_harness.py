@@ -16,7 +16,7 @@ def test_train_res_output_format(capsys):
     lines = out.strip().splitlines()
     assert len([l for l in lines if l.startswith("Epoch: ")]) == 3
     assert re.match(r"Epoch: 0001 loss_train: \d+\.\d{4} acc_train: \d\.\d{4} loss_val: \d+\.\d{4} acc_val: \d\.\d{4} "
-                    r"time: \d+\.\d{4}s nfe_f: 16 nfe_b: 16", lines[0])
+                    r"time: \d+\.\d{4}s nfe_f: 16 nfe_b: 17", lines[0])
     assert any(l.startswith("Test set results: loss= ") for l in lines)
     assert 'Optimization on dataset "cora" Finished!' in out
     assert "#Parameters: 23383" in out                       # SURVEY 3.1's count for ode3 on Cora
