@@ -53,7 +53,7 @@ class Rk4Workspace(ctypes.Structure):
     _fields_ = [("S", ctypes.c_void_p), ("dZ", ctypes.c_void_p), ("dS", ctypes.c_void_p), ("S2", ctypes.c_void_p),
                 ("ky", ctypes.c_void_p * 4), ("ka", ctypes.c_void_p * 4), ("ktheta", ctypes.c_void_p * 4),
                 ("wpart", ctypes.c_void_p), ("gpart", ctypes.c_void_p), ("bpart", ctypes.c_void_p),
-                ("colsum_scratch", ctypes.c_void_p), ("X", ctypes.c_void_p * 2)]
+                ("colsum_scratch", ctypes.c_void_p), ("X", ctypes.c_void_p * 2), ("small_part", ctypes.c_void_p)]
 
 
 class ReduceSeg(ctypes.Structure):
@@ -127,6 +127,14 @@ SIGNATURES = {
     "gode_adam_chunk": (c_i64, []),
     "gode_adam_tick_f32": (c_i, [c_p, c_f, c_f, c_p]),
     "gode_adam_f32": (c_i, [ctypes.POINTER(AdamArgs), ctypes.c_int32, c_p, c_i64, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),
+    "gode_gcn_small_supported": (c_i, [c_i64, c_i64, ctypes.c_int32]),
+    "gode_gcn_small_parts": (c_i64, [c_i64]),
+    "gode_gcn_small_part_len": (c_i64, [c_i64]),
+    "gode_gcn_feval_small_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), ctypes.POINTER(LinComb), c_f, c_f, ctypes.POINTER(LinComb),
+                                       ctypes.POINTER(LinComb), c_p, c_p, c_p]),
+    "gode_gcn_vjp_small_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), ctypes.POINTER(LinComb), c_p, c_f, ctypes.POINTER(LinComb),
+                                     c_p, c_p, c_p]),
+    "gode_gcn_small_finish_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_f, c_p]),
     "gode_wgrad_parts": (c_i64, [c_i64]),
     "gode_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
                              c_p, c_i64, c_i, c_p, c_p]),

@@ -80,6 +80,12 @@ int stage_finish_merged(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t*
     return 0;
 }
 
+// Launch-bound graphs: ONE launch per f-eval and one per VJP (csrc/small.hip) instead of 2 + 8
+bool fused_small(const gode_gcn_odefunc_t* f) {
+    return gode_opt_small_fused() && gode_gcn_small_supported(f->n, f->d, f->groups);
+}
+gode_lincomb_t negated(gode_lincomb_t lc) { for (int j = 0; j < lc.n; ++j) lc.coef[j] = -lc.coef[j]; return lc; }
+
 }  // namespace
 
 extern "C" int64_t gode_gcn_ode_theta_len(int64_t d) { return (d + 1) * d + 3 * d + 1; }
@@ -95,10 +101,17 @@ extern "C" int gode_gcn_ode_rk4_forward(const gode_gcn_odefunc_t* f, float* y, f
     const double h = ((double)t1 - (double)t0) / n_steps;
     float* cur = y;
     float* k[4] = {ws->ky[0], ws->ky[1], ws->ky[2], ws->ky[3]};
+    const bool fused = fused_small(f);
     for (int i = 0; i < n_steps; ++i) {
         const double t = (double)t0 + i * h;
         for (int s = 0; s < 4; ++s) {
             gode_lincomb_t xin = stage_terms(cur, k, s, h);
+            if (fused) {
+                gode_lincomb_t pre = combine_terms(cur, k, h);
+                GODE_TRY(gode_gcn_feval_small_f32(f, &xin, (float)(t + C38[s] * h), s == 3 ? (float)(h * B38[3]) : 1.f,
+                                                  s == 3 ? &pre : nullptr, nullptr, nullptr, k[s], stream));
+                continue;
+            }
             GODE_TRY(gode_gn_time_gemm_f32(&xin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1,
                                            (float)(t + C38[s] * h), ws->S, stream));
             gode_spmm_epilogue_t ep = {};
@@ -185,7 +198,8 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
     const bool mat = ws->X[0] != nullptr && ws->X[1] != nullptr;
     auto x_out_of = [&](int g) -> float* { return (mat && (g % 4) >= 2) ? ws->X[g & 1] : nullptr; };
 
-    {
+    const bool fused = fused_small(f) && ws->small_part != nullptr;
+    if (!fused) {
         gode_lincomb_t yin0 = stage_terms(ycur, ky, 0, h);
         GODE_TRY(gode_gn_time_gemm_xout_f32(&yin0, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1,
                                             (float)((double)t0), Sbuf[0], x_out_of(0), stream));
@@ -194,6 +208,26 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
     for (int g = 0; g < total; ++g) {
         const int i = g / 4, s = g % 4;
         const float ts = (float)((double)t0 + i * h + C38[s] * h);
+        if (fused) {
+            // three launches per stage: f-eval (+ masked cotangent dZ), VJP (+ block partials), their reduction
+            const gode_lincomb_t yin = stage_terms(ycur, ky, s, h);
+            const gode_lincomb_t cot = negated(stage_terms(acur, ka, s, h));          // cotangent of the VJP is -a
+            const gode_lincomb_t ypre = combine_terms(ycur, ky, h), apre = combine_terms(acur, ka, h);
+            GODE_TRY(gode_gcn_feval_small_f32(f, &yin, ts, s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &ypre : nullptr,
+                                              &cot, ws->dZ, ky[s], stream));
+            GODE_TRY(gode_gcn_vjp_small_f32(f, &yin, ws->dZ, s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &apre : nullptr,
+                                            ka[s], ws->small_part, stream));
+            GODE_TRY(gode_gcn_small_finish_f32(f, ws->small_part, ws->ktheta[s], ts, stream));
+            if (s == 3) {
+                gode_lincomb_t tc;
+                tc.n = 5; tc.coef[0] = 1.f; tc.ptr[0] = theta;
+                for (int q = 0; q < 4; ++q) { tc.coef[1 + q] = (float)(h * B38[q]); tc.ptr[1 + q] = ws->ktheta[q]; }
+                GODE_TRY(gode_lincomb_f32(theta, &tc, P, stream));
+                float* tmp = ycur; ycur = ky[3]; ky[3] = tmp;
+                tmp = acur; acur = ka[3]; ka[3] = tmp;
+            }
+            continue;
+        }
         gode_lincomb_t yin = stage_terms(ycur, ky, s, h);     // terms of THIS stage (used by Gb / Wg below)
         if (x_out_of(g)) { yin.n = 1; yin.coef[0] = 1.f; yin.ptr[0] = x_out_of(g); }
         gode_lincomb_t ain = stage_terms(acur, ka, s, h);
@@ -300,6 +334,7 @@ gode_lincomb_t dp_terms(const float* y, float* const* k, const double* coef, int
 
 int dp_eval_forward(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws, const gode_lincomb_t* yin, float t,
                     float* k_out, void* stream) {
+    if (fused_small(f)) return gode_gcn_feval_small_f32(f, yin, t, 1.f, nullptr, nullptr, nullptr, k_out, stream);
     GODE_TRY(gode_gn_time_gemm_f32(yin, f->n, f->d, f->groups, f->eps, f->gamma, f->beta, f->W, f->d, 1, t, ws->S, stream));
     gode_spmm_epilogue_t ep = {};
     ep.bias = f->b; ep.relu = 1; ep.alpha = 1.f;
@@ -311,6 +346,12 @@ int dp_eval_forward(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws,
 int dp_eval_adjoint(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws, gode_lincomb_t yin,
                     const gode_lincomb_t& ain, float t, float* ky, float* ka, float* kth, void* stream) {
     const int64_t n = f->n, d = f->d, nW = (d + 1) * d, P = gode_gcn_ode_theta_len(d);
+    if (fused_small(f) && ws->small_part) {
+        const gode_lincomb_t cot = negated(ain);
+        GODE_TRY(gode_gcn_feval_small_f32(f, &yin, t, 1.f, nullptr, &cot, ws->dZ, ky, stream));
+        GODE_TRY(gode_gcn_vjp_small_f32(f, &yin, ws->dZ, 1.f, nullptr, ka, ws->small_part, stream));
+        return gode_gcn_small_finish_f32(f, ws->small_part, kth, t, stream);
+    }
     float* xo = (yin.n >= 3 && ws->X[0]) ? ws->X[0] : nullptr;
     GODE_TRY(gode_gn_time_gemm_xout_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1, t, ws->S, xo, stream));
     if (xo) { yin.n = 1; yin.coef[0] = 1.f; yin.ptr[0] = xo; }

@@ -1,0 +1,342 @@
+// small.hip — the GCN ODE function and its vector-Jacobian products on LAUNCH-BOUND graphs (citation-graph sizes), as
+// one kernel per evaluation and one per VJP, gfx950.
+//
+// Replaces, for graphs of at most 65 536 nodes and widths 16 / 32 / 64 (the reference's `--hidden 16` default and the
+// widths its GroupNorm(min(32, d), d) leaves with 1 or 2 channels per group), the launch sequences of
+//   ODEfunc.forward (GCN/models.py:172-179): GroupNorm, time column, FixedGraphConvolution (GCN/layers.py:69-75), relu
+//   and its autograd (what an adjoint stage needs)
+// that the large-graph path issues as 2 + 8 launches (gn_time_gemm, spmm; spmm^T, VJP, weight gradient, column sums,
+// reductions).  On Cora (2 708 x 16) every one of those kernels runs for 2-4 us and the training step is bound by the
+// NUMBER of kernels (768 per step, ~4.4 us each once captured).  No grid barrier and no persistent kernel is needed to
+// fuse them: the products are re-associated so that everything after the gather is ROW-LOCAL.
+//
+//   forward   z_i = ( sum_j a_ij [t | GN(x_j)] ) W + b      = (A [t|GN(x)]) W  instead of  A ([t|GN(x)] W): the gather
+//             collects normalised neighbour rows (GroupNorm is recomputed per gathered row: a few flops), the dense
+//             product with the (d+1) x d weight block in LDS follows in the same wave, then bias, relu, the RK combine
+//             and the masked cotangent dZ = cot * [z > 0] - ONE launch per f-eval;
+//   VJP       dS_i = sum_j a^T_ij dZ_j (gather), dxn_i = dS_i W1^T, GroupNorm backward, k_a row; weight gradient
+//             sum_i [1|xn_i]^T dS_i, bias gradient sum_i dZ_i, dgamma / dbeta: per-wave register accumulators, one
+//             block partial row per block - ONE launch; a third (gode_reduce_segments_f32) closes the stage.
+// Same mathematics as the multi-launch path; the forward sums in another order ((A xn) W vs A (xn W): differences of a
+// few ulp, inside the 1e-5 parity bar - tests/test_gpu_gcn.py runs both against the oracle).
+//
+// Work decomposition: a wave owns a row at a time; a lane holds 4 consecutive columns (float4), so d/4 lanes span a row
+// and the wave's 256/d sub-groups stride over the row's non-zeros (a 168-neighbour hub of Cora costs 168 d / 256 dependent
+// gathers, not 168) and over the k-range of the dense product; sub-group sums are combined with xor-shuffles (fixed
+// order: deterministic).  Bound: launch latency (the graphs live in L2).
+#include "common.h"
+#include "dense_common.h"
+#include "options.h"
+
+namespace {
+
+constexpr int kSmallPartBlocks = 256;
+
+// sum over the sub-groups of a wave (lanes `from` apart and beyond), every lane ends with the total
+__device__ __forceinline__ void xor_combine4(float4& v, int from) {
+#pragma unroll
+    for (int off = from; off < 64; off <<= 1) {
+        v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
+        v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: out[i] = (sum pre)[i] + alpha * relu(z_i),  z_i = (sum_j a_ij [t | GN(x_j)]) W + b;  Y2[i] = (sum cot)[i] * [z_i > 0]
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, int CG>
+__global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                             const float* __restrict__ val, LinComb xin, int n_rows,
+                                                             float eps, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, float t, float alpha,
+                                                             LinComb pre, LinComb cot, float* __restrict__ Y2,
+                                                             float* __restrict__ out)
+{
+    constexpr int LPR = D / 4, SG = 64 / LPR;                  // lanes per row, sub-groups per wave
+    __shared__ __attribute__((aligned(16))) float Ws[(D + 1) * D];
+    __shared__ __attribute__((aligned(16))) float mrow[4][D + 4];            // [0] = t * rowsum, [4 ..] = aggregated GN rows
+    for (int i = threadIdx.x; i < (D + 1) * D; i += 256) Ws[i] = W[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
+    const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bi = bias ? ld4(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* mr = mrow[wave];
+    for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {     // wave-uniform
+        const int b = rowptr[row], e = rowptr[row + 1];
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        float r = 0.f;
+        for (int j = b + s; j < e; j += SG) {
+            const int cj = col[j];
+            const float a = val ? val[j] : 1.f;
+            const float4 xn = gn_forward_v<CG>(lc_load4(xin, (int64_t)cj * D + 4 * q), eps, gm, bt);
+            m.x = fmaf(a, xn.x, m.x); m.y = fmaf(a, xn.y, m.y); m.z = fmaf(a, xn.z, m.z); m.w = fmaf(a, xn.w, m.w);
+            r += a;
+        }
+        xor_combine4(m, LPR);
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) r += __shfl_xor(r, off, 64);
+        if (s == 0) {
+            *reinterpret_cast<float4*>(mr + 4 + 4 * q) = m;
+            if (q == 0) mr[0] = t * r;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dense: this sub-group's share of the k range (k = 0: the time row)
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = s; k <= D; k += SG) {
+            const float mk = k == 0 ? mr[0] : mr[3 + k];
+            const float4 w = *reinterpret_cast<const float4*>(Ws + k * D + 4 * q);
+            z.x = fmaf(mk, w.x, z.x); z.y = fmaf(mk, w.y, z.y); z.z = fmaf(mk, w.z, z.z); z.w = fmaf(mk, w.w, z.w);
+        }
+        xor_combine4(z, LPR);
+        if (s == 0) {
+            z.x += bi.x; z.y += bi.y; z.z += bi.z; z.w += bi.w;
+            float4 y = make_float4(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f), fmaxf(z.z, 0.f), fmaxf(z.w, 0.f));
+            const int64_t o = (int64_t)row * D + 4 * q;
+            if (pre.n > 0) {
+                const float4 p = lc_load4(pre, o);
+                y.x = fmaf(alpha, y.x, p.x); y.y = fmaf(alpha, y.y, p.y); y.z = fmaf(alpha, y.z, p.z); y.w = fmaf(alpha, y.w, p.w);
+            } else if (alpha != 1.f) {
+                y.x *= alpha; y.y *= alpha; y.z *= alpha; y.w *= alpha;
+            }
+            *reinterpret_cast<float4*>(out + o) = y;
+            if (Y2) {
+                float4 g = lc_load4(cot, o);
+                g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f; g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+                *reinterpret_cast<float4*>(Y2 + o) = g;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                         // the next row's mrow stores follow these reads
+    }
+}
+
+// GroupNorm backward of one float4 (CG = 1, 2 or 4 channels per group, all inside the float4), the arithmetic of
+// gn_gemm_bwd_kernel: ATen's algebraic form for the ill-conditioned 1- and 2-channel groups, the normalised form for 4.
+template <int CG>
+__device__ __forceinline__ float4 gn_backward4(const float4 x, const float4 dy, const float4 gm, float eps, float4& xh_out) {
+    float4 mean, rstd;
+    gn_stats<CG>(x, eps, mean, rstd);
+    const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y, (x.z - mean.z) * rstd.z, (x.w - mean.w) * rstd.w);
+    xh_out = xh;
+    const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+    if (CG == 4) {
+        const float m1 = ((dh.x + dh.y) + (dh.z + dh.w)) * 0.25f;
+        const float m2 = ((dh.x * xh.x + dh.y * xh.y) + (dh.z * xh.z + dh.w * xh.w)) * 0.25f;
+        const float rs = rstd.x;
+        return make_float4(rs * (dh.x - m1 - xh.x * m2), rs * (dh.y - m1 - xh.y * m2), rs * (dh.z - m1 - xh.z * m2), rs * (dh.w - m1 - xh.w * m2));
+    }
+    const float4 px = make_float4(dh.x * x.x, dh.y * x.y, dh.z * x.z, dh.w * x.w);
+    float4 ds, db;
+    if (CG == 1) { ds = px; db = dh; }
+    else {
+        ds = make_float4(px.x + px.y, px.x + px.y, px.z + px.w, px.z + px.w);
+        db = make_float4(dh.x + dh.y, dh.x + dh.y, dh.z + dh.w, dh.z + dh.w);
+    }
+    constexpr float sc = 1.0f / CG;
+    const float4 r3 = make_float4(rstd.x * rstd.x * rstd.x * sc, rstd.y * rstd.y * rstd.y * sc, rstd.z * rstd.z * rstd.z * sc, rstd.w * rstd.w * rstd.w * sc);
+    const float4 c2 = make_float4((db.x * mean.x - ds.x) * r3.x, (db.y * mean.y - ds.y) * r3.y, (db.z * mean.z - ds.z) * r3.z, (db.w * mean.w - ds.w) * r3.w);
+    const float4 c3 = make_float4(-c2.x * mean.x - db.x * rstd.x * sc, -c2.y * mean.y - db.y * rstd.y * sc,
+                                  -c2.z * mean.z - db.z * rstd.z * sc, -c2.w * mean.w - db.w * rstd.w * sc);
+    return make_float4(rstd.x * gm.x * dy.x + c2.x * x.x + c3.x, rstd.y * gm.y * dy.y + c2.y * x.y + c3.y,
+                       rstd.z * gm.z * dy.z + c2.z * x.z + c3.z, rstd.w * gm.w * dy.w + c2.w * x.w + c3.w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// VJP: dS_i = sum_j aT_ij dZ_j;  ka_i = (sum pre)_i + out_scale * GN'(x_i)^T (dS_i W1^T);  block partial row
+// part[block] = [ colsum(dS) | sum_i xn_i^T dS_i  ((D+1) x D, row 0 = time row) | colsum(dZ) | dgamma | dbeta ]
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, int CG>
+__global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restrict__ rowptrT, const int* __restrict__ colT,
+                                                           const float* __restrict__ valT, LinComb xin, int n_rows,
+                                                           float eps, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ W,
+                                                           const float* __restrict__ dZ, float out_scale, LinComb pre,
+                                                           float* __restrict__ ka, float* __restrict__ part)
+{
+    constexpr int LPR = D / 4, SG = 64 / LPR, NS = D / SG;     // NS = columns of dW per lane (1, 4, 16)
+    constexpr int PLEN = (D + 1) * D + 3 * D;
+    __shared__ __attribute__((aligned(16))) float Wt[D * (D + 4)];           // Wt[n][k] = W1[k][n], row stride D + 4
+    __shared__ __attribute__((aligned(16))) float dsrow[4][D];
+    __shared__ float red[PLEN];
+    for (int i = threadIdx.x; i < D * D; i += 256) {
+        const int k = i / D, n = i % D;
+        Wt[n * (D + 4) + k] = W[(int64_t)(k + 1) * D + n];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
+    const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* dr = dsrow[wave];
+    float acc[4][NS];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) acc[a][i] = 0.f;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cz = cs, dg = cs, db = cs;
+    for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {
+        const int b = rowptrT[row], e = rowptrT[row + 1];
+        float4 dS = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = b + s; j < e; j += SG) {
+            const int cj = colT[j];
+            const float a = valT ? valT[j] : 1.f;
+            const float4 g = ld4(dZ + (int64_t)cj * D + 4 * q);
+            dS.x = fmaf(a, g.x, dS.x); dS.y = fmaf(a, g.y, dS.y); dS.z = fmaf(a, g.z, dS.z); dS.w = fmaf(a, g.w, dS.w);
+        }
+        xor_combine4(dS, LPR);
+        if (s == 0) *reinterpret_cast<float4*>(dr + 4 * q) = dS;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dxn[4q ..] = sum_n dS_n W1[k][n]: this sub-group's share of n
+        float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = s; n < D; n += SG) {
+            const float dn = dr[n];
+            const float4 w = *reinterpret_cast<const float4*>(Wt + n * (D + 4) + 4 * q);
+            dy.x = fmaf(dn, w.x, dy.x); dy.y = fmaf(dn, w.y, dy.y); dy.z = fmaf(dn, w.z, dy.z); dy.w = fmaf(dn, w.w, dy.w);
+        }
+        xor_combine4(dy, LPR);
+        const int64_t o = (int64_t)row * D + 4 * q;
+        const float4 x = lc_load4(xin, o);
+        float4 xh;
+        const float4 dx = gn_backward4<CG>(x, dy, gm, eps, xh);
+        const float4 xn = gn_forward_v<CG>(x, eps, gm, bt);
+        if (s == 0) {
+            float4 out = make_float4(out_scale * dx.x, out_scale * dx.y, out_scale * dx.z, out_scale * dx.w);
+            if (pre.n > 0) { const float4 p = lc_load4(pre, o); out.x += p.x; out.y += p.y; out.z += p.z; out.w += p.w; }
+            *reinterpret_cast<float4*>(ka + o) = out;
+            dg.x += dy.x * xh.x; dg.y += dy.y * xh.y; dg.z += dy.z * xh.z; dg.w += dy.w * xh.w;
+            db.x += dy.x; db.y += dy.y; db.z += dy.z; db.w += dy.w;
+            cs.x += dS.x; cs.y += dS.y; cs.z += dS.z; cs.w += dS.w;
+            const float4 zz = ld4(dZ + o);
+            cz.x += zz.x; cz.y += zz.y; cz.z += zz.z; cz.w += zz.w;
+        }
+        // weight gradient: lane (q, s) owns rows k = 4q .. 4q+3 of dW1 and columns n = s NS .. s NS + NS - 1
+        const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const float dn = dr[s * NS + i];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a][i] = fmaf(xv[a], dn, acc[a][i]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // block partial: the four waves add through LDS in wave order (fixed order: deterministic)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int idx = (1 + 4 * q + a) * D + s * NS + i;
+                    red[idx] = (w == 0 ? 0.f : red[idx]) + acc[a][i];
+                }
+            if (s == 0) {
+                const float c4[4][4] = {{cs.x, cs.y, cs.z, cs.w}, {cz.x, cz.y, cz.z, cz.w}, {dg.x, dg.y, dg.z, dg.w}, {db.x, db.y, db.z, db.w}};
+                const int base[4] = {0, (D + 1) * D, (D + 1) * D + D, (D + 1) * D + 2 * D};
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int idx = base[v] + 4 * q + a;
+                        red[idx] = (w == 0 ? 0.f : red[idx]) + c4[v][a];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = part + (int64_t)blockIdx.x * PLEN;
+    for (int i = threadIdx.x; i < PLEN; i += 256) out[i] = red[i];
+}
+
+int small_cg(int64_t d, int32_t groups) {
+    // channels per group when the fused small-graph kernels are instantiated for (d, groups), else -1
+    if (d != 16 && d != 32 && d != 64) return -1;
+    if (groups <= 0 || d % groups) return -1;
+    const int64_t cg = d / groups;
+    return (cg == 1 || cg == 2 || cg == 4) ? (int)cg : -1;
+}
+
+int64_t feval_blocks(int64_t n) { int64_t b = (n + 3) / 4; if (b < 1) b = 1; if (b > 2048) b = 2048; return b; }
+
+}  // namespace
+
+extern "C" int64_t gode_gcn_small_parts(int64_t n_rows) {
+    int64_t b = (n_rows + 3) / 4;
+    if (b < 1) b = 1;
+    if (b > kSmallPartBlocks) b = kSmallPartBlocks;
+    return b;
+}
+extern "C" int64_t gode_gcn_small_part_len(int64_t d) { return (d + 1) * d + 3 * d; }
+
+extern "C" int gode_gcn_small_supported(int64_t n_rows, int64_t d, int32_t groups) {
+    return n_rows > 0 && n_rows <= 65536 && small_cg(d, groups) > 0;
+}
+
+#define GODE_SMALL_DISPATCH(MACRO)                                                                           \
+    if (d == 16 && cg == 1) { MACRO(16, 1) } else if (d == 16 && cg == 2) { MACRO(16, 2) } else if (d == 16 && cg == 4) { MACRO(16, 4) } \
+    else if (d == 32 && cg == 1) { MACRO(32, 1) } else if (d == 32 && cg == 2) { MACRO(32, 2) } else if (d == 32 && cg == 4) { MACRO(32, 4) } \
+    else if (d == 64 && cg == 1) { MACRO(64, 1) } else if (d == 64 && cg == 2) { MACRO(64, 2) } else if (d == 64 && cg == 4) { MACRO(64, 4) }
+
+extern "C" int gode_gcn_feval_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin, float t,
+                                        float alpha, const gode_lincomb_t* pre, const gode_lincomb_t* cot, float* Y2,
+                                        float* out, void* stream)
+{
+    if (!f || !xin || !out) return GODE_E_NULLPTR;
+    if (!gode_gcn_small_supported(f->n, f->d, f->groups)) return GODE_E_UNSUPPORTED;
+    if (!f->A.rowptr || !f->A.col || !f->W) return GODE_E_NULLPTR;
+    int rc = check_lincomb(xin, true); if (rc) return rc;
+    if (pre && pre->n > 0) { rc = check_lincomb(pre, true); if (rc) return rc; } else pre = nullptr;
+    if (Y2) { rc = check_lincomb(cot, true); if (rc) return rc; } else cot = nullptr;
+    if (!lincomb_aligned16(xin) || !lincomb_aligned16(pre) || !lincomb_aligned16(cot) ||
+        ((((uintptr_t)out) | ((uintptr_t)Y2) | ((uintptr_t)f->gamma) | ((uintptr_t)f->beta) | ((uintptr_t)f->b)) & 15)) return GODE_E_ALIGN;
+    const LinComb lx = make_lincomb(xin), lp = make_lincomb(pre), lcot = make_lincomb(cot);
+    const int64_t d = f->d;
+    const int cg = small_cg(d, f->groups);
+    const dim3 grid((unsigned)feval_blocks(f->n));
+#define GODE_FEV(DV, CGV) hipLaunchKernelGGL((gcn_feval_small_kernel<DV, CGV>), grid, dim3(256), 0, (hipStream_t)stream,         \
+                                             f->A.rowptr, f->A.col, f->A.val, lx, (int)f->n, f->eps, f->gamma, f->beta, f->W,    \
+                                             f->b, t, alpha, lp, lcot, Y2, out);
+    GODE_SMALL_DISPATCH(GODE_FEV)
+#undef GODE_FEV
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_gcn_vjp_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin, const float* dZ,
+                                      float out_scale, const gode_lincomb_t* pre, float* ka, float* part, void* stream)
+{
+    if (!f || !xin || !dZ || !ka || !part) return GODE_E_NULLPTR;
+    if (!gode_gcn_small_supported(f->n, f->d, f->groups)) return GODE_E_UNSUPPORTED;
+    if (!f->AT.rowptr || !f->AT.col || !f->W) return GODE_E_NULLPTR;
+    int rc = check_lincomb(xin, true); if (rc) return rc;
+    if (pre && pre->n > 0) { rc = check_lincomb(pre, true); if (rc) return rc; } else pre = nullptr;
+    if (!lincomb_aligned16(xin) || !lincomb_aligned16(pre) ||
+        ((((uintptr_t)dZ) | ((uintptr_t)ka) | ((uintptr_t)f->gamma) | ((uintptr_t)f->beta)) & 15)) return GODE_E_ALIGN;
+    const LinComb lx = make_lincomb(xin), lp = make_lincomb(pre);
+    const int64_t d = f->d;
+    const int cg = small_cg(d, f->groups);
+    const dim3 grid((unsigned)gode_gcn_small_parts(f->n));
+#define GODE_VJS(DV, CGV) hipLaunchKernelGGL((gcn_vjp_small_kernel<DV, CGV>), grid, dim3(256), 0, (hipStream_t)stream,           \
+                                             f->AT.rowptr, f->AT.col, f->AT.val, lx, (int)f->n, f->eps, f->gamma, f->beta, f->W, \
+                                             dZ, out_scale, lp, ka, part);
+    GODE_SMALL_DISPATCH(GODE_VJS)
+#undef GODE_VJS
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+// theta-k = [ W ((d+1) d, row 0 = t * colsum(dS)) | b | gamma | beta | a_t ] from the block partials of
+// gode_gcn_vjp_small_f32, in one launch (a_t = colsum(dS) . W[0, :])
+extern "C" int gode_gcn_small_finish_f32(const gode_gcn_odefunc_t* f, const float* part, float* ktheta, float t, void* stream)
+{
+    if (!f || !part || !ktheta) return GODE_E_NULLPTR;
+    const int64_t d = f->d, nW = (d + 1) * d, P = nW + 3 * d + 1, plen = gode_gcn_small_part_len(d);
+    const int64_t parts = gode_gcn_small_parts(f->n);
+    gode_reduce_seg_t sg[4] = {};
+    sg[0] = {ktheta, part, parts, plen, 0, 1, nW, f->W, d};
+    sg[1] = {ktheta + nW, part, parts, plen, nW, 1, d, nullptr, 0};
+    sg[2] = {ktheta + nW + d, part, parts, plen, nW + d, 1, d, nullptr, 0};
+    sg[3] = {ktheta + nW + 2 * d, part, parts, plen, nW + 2 * d, 1, d, nullptr, 0};
+    return gode_reduce_segments_f32(sg, 4, t, ktheta + (P - 1), stream);
+}

@@ -88,7 +88,17 @@ class _Shared:
             if getattr(self, "X2", None) is None:
                 self.X2 = [torch.empty_like(self.S), torch.empty_like(self.S)]
             ws.X[0], ws.X[1] = self.X2[0].data_ptr(), self.X2[1].data_ptr()
+            sp = self.small_part()
+            ws.small_part = sp.data_ptr() if sp is not None else None
         return ws
+
+    def small_part(self):
+        """Block partials of the fused launch-bound VJP (csrc/small.hip); None when the shape is outside that path."""
+        if getattr(self, "_small_part", None) is None:
+            lib = _lib.load()
+            self._small_part = torch.empty(lib.gode_gcn_small_parts(self.n) * lib.gode_gcn_small_part_len(self.d),
+                                           dtype=torch.float32, device=self.device)
+        return self._small_part
 
 
 def _func_struct(spec):
@@ -194,6 +204,26 @@ class GcnOdeSpec:
             raise ValueError("GcnOdeSpec: adjacency must be square")
 
 
+def small_fused(spec):
+    """True when the launch-bound one-launch f-eval / VJP of csrc/small.hip applies (and is switched on)."""
+    lib = _lib.load()
+    return bool(lib.gode_get_option(b"small_fused") == 1 and not getattr(spec.graph, "is_partitioned", False)
+                and lib.gode_gcn_small_supported(spec.graph.n_rows, spec.d, spec.groups))
+
+
+def _feval_small(spec, t, terms, out, pre=None, alpha=1.0, cot=None, out2=None):
+    lib = _lib.load()
+    fs = _func_struct(spec)
+    lx = _lib.lincomb(terms)
+    lp = _lib.lincomb(pre) if pre is not None else None
+    lc = _lib.lincomb(cot) if cot is not None else None
+    _lib.check(lib.gode_gcn_feval_small_f32(ctypes.byref(fs), ctypes.byref(lx), float(t), float(alpha),
+                                            ctypes.byref(lp) if lp is not None else None,
+                                            ctypes.byref(lc) if lc is not None else None,
+                                            _lib.ptr(out2) if cot is not None else None, _lib.ptr(out), _lib.stream_ptr()),
+               "gode_gcn_feval_small_f32")
+
+
 class GcnOdeField(Field):
     n_components = 1
     fused = True
@@ -204,6 +234,8 @@ class GcnOdeField(Field):
 
     def eval(self, t, terms, out):
         s, w = self.s, self.w
+        if small_fused(s):
+            return _feval_small(s, t, terms[0], out[0])
         ops.gn_time_gemm(terms[0], w.n, s.d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
         ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0])
 
@@ -226,6 +258,9 @@ class GcnOdeField(Field):
     def eval_combine(self, t, terms, pre, coef, out):
         """Last RK stage: out[0] = (sum pre[0]) + coef * f(t, sum terms[0]) without materialising f."""
         s, w = self.s, self.w
+        if small_fused(s):
+            _feval_small(s, t, terms[0], out[0], pre=pre[0], alpha=coef)
+            return (0,)
         ops.gn_time_gemm(terms[0], w.n, s.d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
         ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0], pre_terms=pre[0], alpha=coef)
         return (0,)
@@ -381,6 +416,24 @@ class GcnOdeAdjointField(Field):
         dZ, dS = w.bwd()
         n, d = w.n, s.d
         y_terms = terms[0]
+        packed = getattr(out[2], "_gode_packed", None)
+        if packed is not None and small_fused(s):
+            # launch-bound graphs: f-eval (+ masked cotangent), VJP (+ block partials), their reduction - three launches,
+            # the same ones the C drivers issue (csrc/small.hip)
+            lib = _lib.load()
+            last = pre is not None
+            _feval_small(s, t, y_terms, out[0], pre=pre[0] if last else None, alpha=coef if last else 1.0,
+                         cot=[(-c, x) for (c, x) in terms[1]], out2=dZ)
+            fs = _func_struct(s)
+            lx = _lib.lincomb(y_terms)
+            lp = _lib.lincomb(pre[1]) if last else None
+            part = w.small_part()
+            _lib.check(lib.gode_gcn_vjp_small_f32(ctypes.byref(fs), ctypes.byref(lx), _lib.ptr(dZ), float(coef if last else 1.0),
+                                                  ctypes.byref(lp) if lp is not None else None, _lib.ptr(out[1]), _lib.ptr(part),
+                                                  _lib.stream_ptr()), "gode_gcn_vjp_small_f32")
+            _lib.check(lib.gode_gcn_small_finish_f32(ctypes.byref(fs), _lib.ptr(part), _lib.ptr(packed), float(t),
+                                                     _lib.stream_ptr()), "gode_gcn_small_finish_f32")
+            return
         ops.gn_time_gemm(y_terms, n, d, s.groups, s.eps, s.gamma, s.beta, s.W, True, t, out=w.S)
         # k_y = relu(A S + b);  dZ = (-a) * mask
         ops.spmm(s.graph, w.S, bias=s.b, relu=True, out=out[0],

@@ -94,7 +94,10 @@ def integrate_rk4(field, y, t0, t1, n_steps, work=None):
     The entries of the list `y` hold the result on return; they may have been re-bound to other
     buffers (a fused field writes y + h*sum(b_i k_i) straight from the launch that produces the last
     stage and the solution / stage buffers swap roles), so callers read `y[c]` afterwards."""
-    ks = work if work is not None else _alloc_like(y, 4)
+    # a field may lay out the work copies itself (the adjoint field packs its small components into one buffer, which
+    # the fused launch-bound stage writes in one launch)
+    alloc = getattr(field, "alloc_like", None) or _alloc_like
+    ks = work if work is not None else alloc(y, 4)
     h = (t1 - t0) / n_steps
     nfe = 0
     nc = len(y)

@@ -394,7 +394,28 @@ typedef struct gode_rk4_workspace {
     float* X[2];                        /* nullable pair of n x d buffers (adjoint): the combined input of a stage with
                                            3 or 4 terms is written once by its forward launch and read as one array by
                                            the VJP and weight-gradient launches */
+    float* small_part;                  /* nullable: gode_gcn_small_parts(n) * gode_gcn_small_part_len(d) floats - enables
+                                           the fused launch-bound path of the adjoint drivers (csrc/small.hip) */
 } gode_rk4_workspace_t;
+
+/* Launch-bound graphs (n <= 65 536, d in {16, 32, 64}, 1 / 2 / 4 channels per GroupNorm group): ODEfunc.forward
+ * (GCN/models.py:172-179) as ONE launch and its VJPs as one more, by re-association - z_i = (sum_j a_ij [t | GN(x_j)]) W + b,
+ * everything after the gather row-local (csrc/small.hip).  gode_gcn_feval_small_f32: out = (sum pre) + alpha * relu(z),
+ * Y2 (nullable) = (sum cot) * [z > 0].  gode_gcn_vjp_small_f32: ka = (sum pre) + out_scale * GN'(x)^T ((A^T dZ) W1^T) and
+ * one block partial row per block in `part` (gode_gcn_small_parts(n) rows of gode_gcn_small_part_len(d) floats:
+ * [ [1|xn]^T dS ((d+1) x d) | colsum(dZ) | dgamma | dbeta ]); gode_gcn_small_finish_f32 reduces them into a theta-k
+ * vector [W | b | gamma | beta | a_t] (row 0 of W scaled by t, a_t = colsum(dS) . W[0,:]).  The rk4 / dopri5 drivers below
+ * take this path by themselves (option "small_fused", default 1).  GODE_E_UNSUPPORTED outside the shapes above. */
+int     gode_gcn_small_supported(int64_t n_rows, int64_t d, int32_t groups);
+int64_t gode_gcn_small_parts(int64_t n_rows);
+int64_t gode_gcn_small_part_len(int64_t d);
+int gode_gcn_feval_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin /* host */, float t, float alpha,
+                             const gode_lincomb_t* pre /* host, nullable */, const gode_lincomb_t* cot /* host, with Y2 */,
+                             float* Y2 /* nullable */, float* out, void* stream);
+int gode_gcn_vjp_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin /* host */, const float* dZ,
+                           float out_scale, const gode_lincomb_t* pre /* host, nullable */, float* ka, float* part,
+                           void* stream);
+int gode_gcn_small_finish_f32(const gode_gcn_odefunc_t* f, const float* part, float* ktheta, float t, void* stream);
 
 int64_t gode_gcn_ode_theta_len(int64_t d);
 int gode_gcn_ode_rk4_forward(const gode_gcn_odefunc_t* f, float* y, float** result,

@@ -965,3 +965,60 @@ def test_graph_convolution_sparse_features_and_padded_classes():
     for _ in range(3):
         lay(xdense, a2)
     assert L.sparse_features(xdense) is None
+
+
+@pytest.mark.parametrize("d", [16, 32, 64])
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_fused_small_graph_path_matches_multi_launch_path(d, method):
+    """csrc/small.hip (launch-bound graphs: one launch per f-eval, one per VJP, by re-association - everything after the
+    gather is row-local) against the multi-launch path of the large graphs (option small_fused 0) through the same ODE
+    block, C drivers and Python drivers: states to 1e-5, gradients to the noise floor of the width (one channel per
+    GroupNorm group at d = 16 / 32), on a graph with a 300-neighbour hub, isolated rows and duplicate-free random edges;
+    the fused path also against the fp64 oracle on Cora in test_odegcn3_rk4_forward_backward_vs_oracle_on_cora."""
+    from graph_odenet_amd import _lib, models, odeint as OI
+    lib = _lib.load()
+    torch.manual_seed(d)
+    n = 1500
+    r = torch.cat([torch.randint(0, n - 10, (6000,)), torch.zeros(300, dtype=torch.long)])     # rows n-10.. have no entry
+    c = torch.cat([torch.randint(0, n, (6000,)), torch.randperm(n)[:300]])
+    key = torch.unique(r * n + c)
+    r, c = key // n, key % n
+    v = torch.rand(key.numel()) + 0.1
+    v = v / torch.zeros(n).index_add_(0, r, v)[r]
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n)).to(dev())
+    x = torch.randn(n, d, device=dev()).relu()
+    gout = torch.randn(n, d, device=dev())
+    res = {}
+    try:
+        for fused in (1, 0):
+            for native in (True, False):
+                assert lib.gode_set_option(b"small_fused", fused) == 0 and lib.gode_get_option(b"small_fused") == fused
+                OI.NATIVE_RK4 = native
+                old_cap = OI.GRAPH_CAPTURE_MAX_ELEMS
+                OI.GRAPH_CAPTURE_MAX_ELEMS = 0
+                try:
+                    torch.manual_seed(1)
+                    blk = models.ODEBlock(models.ODEfunc(d), tol=1e-4, method=None if method == "dopri5" else "rk4",
+                                          step_size=0.25 if method == "rk4" else None).to(dev())
+                    with torch.no_grad():
+                        blk.odefunc.norm1.weight.uniform_(0.5, 1.5); blk.odefunc.norm1.bias.uniform_(-0.5, 0.5)
+                    xi = x.clone().requires_grad_(True)
+                    out = blk(xi, adj)
+                    out.backward(gout)
+                    res[(fused, native)] = (out.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in blk.parameters()])
+                finally:
+                    OI.NATIVE_RK4 = True
+                    OI.GRAPH_CAPTURE_MAX_ELEMS = old_cap
+    finally:
+        lib.gode_set_option(b"small_fused", 1)
+    ref = res[(0, True)]
+    gtol = {16: 2e-3, 32: 2e-3, 64: 2e-4}[d] if method == "rk4" else {16: 5e-3, 32: 5e-3, 64: 1e-3}[d]
+    for key_ in ((1, True), (1, False)):
+        got = res[key_]
+        close(got[0], ref[0], 1e-5 if method == "rk4" else 1e-4, "state %s" % (key_,))
+        close(got[1], ref[1], gtol, "gx %s" % (key_,))
+        for a, b in zip(got[2], ref[2]):
+            close(a, b, gtol, "param grad %s" % (key_,))
+    # C driver and Python driver issue the same fused kernels
+    if method == "rk4":
+        assert torch.equal(res[(1, True)][0], res[(1, False)][0])
