@@ -135,6 +135,7 @@ SIGNATURES = {
     "gode_gcn_vjp_small_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), ctypes.POINTER(LinComb), c_p, c_f, ctypes.POINTER(LinComb),
                                      c_p, c_p, c_p]),
     "gode_gcn_small_finish_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_f, c_p]),
+    "gode_gcn_small_finish4_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_p, c_p, c_p]),
     "gode_wgrad_parts": (c_i64, [c_i64]),
     "gode_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,
                              c_p, c_i64, c_i, c_p, c_p]),

@@ -205,24 +205,25 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
                                             (float)((double)t0), Sbuf[0], x_out_of(0), stream));
     }
     bool wg_pending = false;
+    float stage_t[4] = {0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < total; ++g) {
         const int i = g / 4, s = g % 4;
         const float ts = (float)((double)t0 + i * h + C38[s] * h);
         if (fused) {
-            // three launches per stage: f-eval (+ masked cotangent dZ), VJP (+ block partials), their reduction
+            // two launches per stage: f-eval (+ masked cotangent dZ), VJP (+ block partials); one more per step
             const gode_lincomb_t yin = stage_terms(ycur, ky, s, h);
             const gode_lincomb_t cot = negated(stage_terms(acur, ka, s, h));          // cotangent of the VJP is -a
             const gode_lincomb_t ypre = combine_terms(ycur, ky, h), apre = combine_terms(acur, ka, h);
             GODE_TRY(gode_gcn_feval_small_f32(f, &yin, ts, s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &ypre : nullptr,
                                               &cot, ws->dZ, ky[s], stream));
+            const int64_t slot = gode_gcn_small_parts(n) * gode_gcn_small_part_len(d);
             GODE_TRY(gode_gcn_vjp_small_f32(f, &yin, ws->dZ, s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &apre : nullptr,
-                                            ka[s], ws->small_part, stream));
-            GODE_TRY(gode_gcn_small_finish_f32(f, ws->small_part, ws->ktheta[s], ts, stream));
+                                            ka[s], ws->small_part + s * slot, stream));
+            stage_t[s] = ts;
             if (s == 3) {
-                gode_lincomb_t tc;
-                tc.n = 5; tc.coef[0] = 1.f; tc.ptr[0] = theta;
-                for (int q = 0; q < 4; ++q) { tc.coef[1 + q] = (float)(h * B38[q]); tc.ptr[1 + q] = ws->ktheta[q]; }
-                GODE_TRY(gode_lincomb_f32(theta, &tc, P, stream));
+                // theta <- theta + h * sum_s b_s ktheta_s straight from the four stages' block partials: one launch per step
+                const float wb[4] = {(float)(h * B38[0]), (float)(h * B38[1]), (float)(h * B38[2]), (float)(h * B38[3])};
+                GODE_TRY(gode_gcn_small_finish4_f32(f, ws->small_part, theta, wb, stage_t, stream));
                 float* tmp = ycur; ycur = ky[3]; ky[3] = tmp;
                 tmp = acur; acur = ka[3]; ka[3] = tmp;
             }

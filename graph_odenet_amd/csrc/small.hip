@@ -1,8 +1,8 @@
 // small.hip — the GCN ODE function and its vector-Jacobian products on LAUNCH-BOUND graphs (citation-graph sizes), as
 // one kernel per evaluation and one per VJP, gfx950.
 //
-// Replaces, for graphs of at most 65 536 nodes and widths 16 / 32 / 64 (the reference's `--hidden 16` default and the
-// widths its GroupNorm(min(32, d), d) leaves with 1 or 2 channels per group), the launch sequences of
+// Replaces, for graphs of at most 65 536 nodes and widths 16 / 32 (the reference's `--hidden 16` default; its
+// GroupNorm(min(32, d), d) has one channel per group there), the launch sequences of
 //   ODEfunc.forward (GCN/models.py:172-179): GroupNorm, time column, FixedGraphConvolution (GCN/layers.py:69-75), relu
 //   and its autograd (what an adjoint stage needs)
 // that the large-graph path issues as 2 + 8 launches (gn_time_gemm, spmm; spmm^T, VJP, weight gradient, column sums,
@@ -56,15 +56,20 @@ __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restr
     constexpr int LPR = D / 4, SG = 64 / LPR;                  // lanes per row, sub-groups per wave
     __shared__ __attribute__((aligned(16))) float Ws[(D + 1) * D];
     __shared__ __attribute__((aligned(16))) float mrow[4][D + 4];            // [0] = t * rowsum, [4 ..] = aggregated GN rows
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
+    // the kernel is a chain of dependent memory latencies (row pointer -> column -> operand row): the first row's
+    // pointers are requested before the weight block is staged, so that the two round trips overlap
+    int row = blockIdx.x * 4 + wave;
+    int b = 0, e = 0;
+    if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
     for (int i = threadIdx.x; i < (D + 1) * D; i += 256) Ws[i] = W[i];
     __syncthreads();
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
     const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 bi = bias ? ld4(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     float* mr = mrow[wave];
-    for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {     // wave-uniform
-        const int b = rowptr[row], e = rowptr[row + 1];
+    for (; row < n_rows; row += gridDim.x * 4) {                                    // wave-uniform
+        if (row != (int)(blockIdx.x * 4 + wave)) { b = rowptr[row]; e = rowptr[row + 1]; }
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
         float r = 0.f;
         for (int j = b + s; j < e; j += SG) {
@@ -160,12 +165,15 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
     __shared__ __attribute__((aligned(16))) float Wt[D * (D + 4)];           // Wt[n][k] = W1[k][n], row stride D + 4
     __shared__ __attribute__((aligned(16))) float dsrow[4][D];
     __shared__ float red[PLEN];
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
+    int row = blockIdx.x * 4 + wave;
+    int b = 0, e = 0;
+    if (row < n_rows) { b = rowptrT[row]; e = rowptrT[row + 1]; }        // requested before the weight block is staged
     for (int i = threadIdx.x; i < D * D; i += 256) {
         const int k = i / D, n = i % D;
         Wt[n * (D + 4) + k] = W[(int64_t)(k + 1) * D + n];
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
     const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     float* dr = dsrow[wave];
@@ -175,8 +183,8 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
 #pragma unroll
         for (int i = 0; i < NS; ++i) acc[a][i] = 0.f;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cz = cs, dg = cs, db = cs;
-    for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {
-        const int b = rowptrT[row], e = rowptrT[row + 1];
+    for (; row < n_rows; row += gridDim.x * 4) {
+        if (row != (int)(blockIdx.x * 4 + wave)) { b = rowptrT[row]; e = rowptrT[row + 1]; }
         float4 dS = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = b + s; j < e; j += SG) {
             const int cj = colT[j];
@@ -249,9 +257,54 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
     for (int i = threadIdx.x; i < PLEN; i += 256) out[i] = red[i];
 }
 
+// One launch per RK STEP for the small components: theta[j] += sum_s wb[s] * scale_s(j) * sum_p part_s[p][j] over the
+// four stages' block partials (the adjoint ODE is linear in a_theta and a_t and a fixed grid never looks at them, so
+// their stage derivatives need not exist as vectors).  Outputs: the (d+1) d + 3 d entries of [W | b | gamma | beta] (row
+// 0 of W - the time row - scaled by the stage time) and a_t = sum_s wb[s] colsum(dS_s) . W[0, :]  (last block).
+struct Finish4 { const float* part[4]; float wb[4]; float ts[4]; };
+__global__ __launch_bounds__(256) void small_finish4_kernel(Finish4 g, int n_part, int plen, int d, const float* __restrict__ W0,
+                                                           float* __restrict__ theta, int out_len)
+{
+    __shared__ float sm[8][33];
+    const int jj = threadIdx.x & 31, qq = threadIdx.x >> 5;
+    const bool time_block = blockIdx.x == gridDim.x - 1;
+    float at = 0.f;
+    const int n_chunks = time_block ? (d + 31) / 32 : 1;
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int j = time_block ? ch * 32 + jj : (int)blockIdx.x * 32 + jj;
+        const int lim = time_block ? d : out_len;
+        float v = 0.f;
+        if (j < lim) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float a = 0.f;
+                for (int p = qq; p < n_part; p += 8) a += g.part[s][(int64_t)p * plen + j];
+                const float sc = (!time_block && j < d) ? g.wb[s] * g.ts[s] : g.wb[s];
+                v = fmaf(sc, a, v);
+            }
+        }
+        sm[qq][jj] = v;
+        __syncthreads();
+        if (qq == 0 && j < lim) {
+            float tsum = sm[0][jj];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) tsum += sm[k][jj];
+            if (time_block) at = fmaf(tsum, W0[j], at);
+            else theta[j] += tsum;
+        }
+        __syncthreads();
+    }
+    if (time_block && qq == 0) {
+        for (int o = 16; o > 0; o >>= 1) at += __shfl_xor(at, o, 64);
+        if (jj == 0) theta[out_len] += at;
+    }
+}
+
 int small_cg(int64_t d, int32_t groups) {
     // channels per group when the fused small-graph kernels are instantiated for (d, groups), else -1
-    if (d != 16 && d != 32 && d != 64) return -1;
+    // widths 16 and 32 only: at 64 the MFMA kernels of the multi-launch path are faster (measured on Cora, hidden 64,
+    // rk4: 5.9 ms per step against 6.2 ms with these kernels instantiated for 64)
+    if (d != 16 && d != 32) return -1;
     if (groups <= 0 || d % groups) return -1;
     const int64_t cg = d / groups;
     return (cg == 1 || cg == 2 || cg == 4) ? (int)cg : -1;
@@ -275,8 +328,7 @@ extern "C" int gode_gcn_small_supported(int64_t n_rows, int64_t d, int32_t group
 
 #define GODE_SMALL_DISPATCH(MACRO)                                                                           \
     if (d == 16 && cg == 1) { MACRO(16, 1) } else if (d == 16 && cg == 2) { MACRO(16, 2) } else if (d == 16 && cg == 4) { MACRO(16, 4) } \
-    else if (d == 32 && cg == 1) { MACRO(32, 1) } else if (d == 32 && cg == 2) { MACRO(32, 2) } else if (d == 32 && cg == 4) { MACRO(32, 4) } \
-    else if (d == 64 && cg == 1) { MACRO(64, 1) } else if (d == 64 && cg == 2) { MACRO(64, 2) } else if (d == 64 && cg == 4) { MACRO(64, 4) }
+    else if (d == 32 && cg == 1) { MACRO(32, 1) } else if (d == 32 && cg == 2) { MACRO(32, 2) } else if (d == 32 && cg == 4) { MACRO(32, 4) }
 
 extern "C" int gode_gcn_feval_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin, float t,
                                         float alpha, const gode_lincomb_t* pre, const gode_lincomb_t* cot, float* Y2,
@@ -339,4 +391,21 @@ extern "C" int gode_gcn_small_finish_f32(const gode_gcn_odefunc_t* f, const floa
     sg[2] = {ktheta + nW + d, part, parts, plen, nW + d, 1, d, nullptr, 0};
     sg[3] = {ktheta + nW + 2 * d, part, parts, plen, nW + 2 * d, 1, d, nullptr, 0};
     return gode_reduce_segments_f32(sg, 4, t, ktheta + (P - 1), stream);
+}
+
+// theta += sum_s wb[s] * (stage derivative of the small components from the block partials of stage s), s < 4:
+// `part` holds the four stages' partial buffers back to back (stage s at part + s * parts * part_len).
+extern "C" int gode_gcn_small_finish4_f32(const gode_gcn_odefunc_t* f, const float* part, float* theta, const float* wb /* host[4] */,
+                                          const float* ts /* host[4] */, void* stream)
+{
+    if (!f || !part || !theta || !wb || !ts) return GODE_E_NULLPTR;
+    const int64_t d = f->d, nW = (d + 1) * d, out_len = nW + 3 * d, plen = gode_gcn_small_part_len(d);
+    const int64_t parts = gode_gcn_small_parts(f->n);
+    Finish4 g;
+    for (int s = 0; s < 4; ++s) { g.part[s] = part + (int64_t)s * parts * plen; g.wb[s] = wb[s]; g.ts[s] = ts[s]; }
+    const int64_t blocks = (out_len + 31) / 32 + 1;
+    hipLaunchKernelGGL(small_finish4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (int)parts, (int)plen,
+                       (int)d, f->W, theta, (int)out_len);
+    GODE_LAUNCH_CHECK();
+    return 0;
 }

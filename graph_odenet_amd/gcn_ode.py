@@ -96,7 +96,7 @@ class _Shared:
         """Block partials of the fused launch-bound VJP (csrc/small.hip); None when the shape is outside that path."""
         if getattr(self, "_small_part", None) is None:
             lib = _lib.load()
-            self._small_part = torch.empty(lib.gode_gcn_small_parts(self.n) * lib.gode_gcn_small_part_len(self.d),
+            self._small_part = torch.empty(4 * lib.gode_gcn_small_parts(self.n) * lib.gode_gcn_small_part_len(self.d),
                                            dtype=torch.float32, device=self.device)
         return self._small_part
 

@@ -394,11 +394,11 @@ typedef struct gode_rk4_workspace {
     float* X[2];                        /* nullable pair of n x d buffers (adjoint): the combined input of a stage with
                                            3 or 4 terms is written once by its forward launch and read as one array by
                                            the VJP and weight-gradient launches */
-    float* small_part;                  /* nullable: gode_gcn_small_parts(n) * gode_gcn_small_part_len(d) floats - enables
+    float* small_part;                  /* nullable: 4 * gode_gcn_small_parts(n) * gode_gcn_small_part_len(d) floats - enables
                                            the fused launch-bound path of the adjoint drivers (csrc/small.hip) */
 } gode_rk4_workspace_t;
 
-/* Launch-bound graphs (n <= 65 536, d in {16, 32, 64}, 1 / 2 / 4 channels per GroupNorm group): ODEfunc.forward
+/* Launch-bound graphs (n <= 65 536, d in {16, 32}, 1 / 2 / 4 channels per GroupNorm group): ODEfunc.forward
  * (GCN/models.py:172-179) as ONE launch and its VJPs as one more, by re-association - z_i = (sum_j a_ij [t | GN(x_j)]) W + b,
  * everything after the gather row-local (csrc/small.hip).  gode_gcn_feval_small_f32: out = (sum pre) + alpha * relu(z),
  * Y2 (nullable) = (sum cot) * [z > 0].  gode_gcn_vjp_small_f32: ka = (sum pre) + out_scale * GN'(x)^T ((A^T dZ) W1^T) and
@@ -416,6 +416,11 @@ int gode_gcn_vjp_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xi
                            float out_scale, const gode_lincomb_t* pre /* host, nullable */, float* ka, float* part,
                            void* stream);
 int gode_gcn_small_finish_f32(const gode_gcn_odefunc_t* f, const float* part, float* ktheta, float t, void* stream);
+/* fixed-grid solves: the four stages of an RK step write their partials back to back (stage s at
+ * part + s * parts * part_len) and ONE launch per step adds sum_s wb[s] * (stage derivative) to the packed small
+ * components theta = [W | b | gamma | beta | a_t] (wb[s] = h * b_s, ts[s] = stage times; host arrays of 4) */
+int gode_gcn_small_finish4_f32(const gode_gcn_odefunc_t* f, const float* part, float* theta, const float* wb /* host */,
+                               const float* ts /* host */, void* stream);
 
 int64_t gode_gcn_ode_theta_len(int64_t d);
 int gode_gcn_ode_rk4_forward(const gode_gcn_odefunc_t* f, float* y, float** result,

@@ -27,14 +27,18 @@ def main():
     dev = torch.device("cuda:0")
     adj, x, y, idx = cora()
     adj_g, x_g, y_g, idx_g = adj.to(dev), x.to(dev), y.to(dev), idx.to(dev)
+    only = sys.argv[1:]                       # e.g. "16:rk4" - restrict to some cases (profiling)
     for nhid in (16, 64):
         for method, step in (("rk4", 1 / 16), (None, None)):
+            if only and "%d:%s" % (nhid, method or "dopri5") not in only:
+                continue
             torch.manual_seed(0)
             m = models.ODEGCN3(nfeat=x.shape[1], nhid=nhid, nclass=7, dropout=0.5, method=method, step_size=step).to(dev)
-            opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=5e-4)
+            from graph_odenet_amd.optim import Adam
+            opt = Adam(m.parameters(), lr=0.01, weight_decay=5e-4)
 
             def train_step():
-                m.train(); opt.zero_grad(); m.nfe = 0
+                m.train(); opt.zero_grad(set_to_none=False); m.nfe = 0
                 out = m(x_g, adj_g)
                 nf = m.nfe; m.nfe = 0
                 loss = torch.nn.functional.nll_loss(out[idx_g], y_g[idx_g])
