@@ -262,10 +262,12 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
 // their stage derivatives need not exist as vectors).  Outputs: the (d+1) d + 3 d entries of [W | b | gamma | beta] (row
 // 0 of W - the time row - scaled by the stage time) and a_t = sum_s wb[s] colsum(dS_s) . W[0, :]  (last block).
 struct Finish4 { const float* part[4]; float wb[4]; float ts[4]; };
-__global__ __launch_bounds__(256) void small_finish4_kernel(Finish4 g, int n_part, int plen, int d, const float* __restrict__ W0,
-                                                           float* __restrict__ theta, int out_len)
+// 1 024 threads: 32 part-groups x 32 outputs; a thread has at most 4 x 8 loads (256 partial rows), all independent and in
+// flight together - the launch is one memory round trip, not a loop of them (8 part-groups took 34 us)
+__global__ __launch_bounds__(1024) void small_finish4_kernel(Finish4 g, int n_part, int plen, int d, const float* __restrict__ W0,
+                                                            float* __restrict__ theta, int out_len)
 {
-    __shared__ float sm[8][33];
+    __shared__ float sm[32][33];
     const int jj = threadIdx.x & 31, qq = threadIdx.x >> 5;
     const bool time_block = blockIdx.x == gridDim.x - 1;
     float at = 0.f;
@@ -275,12 +277,25 @@ __global__ __launch_bounds__(256) void small_finish4_kernel(Finish4 g, int n_par
         const int lim = time_block ? d : out_len;
         float v = 0.f;
         if (j < lim) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int p0 = qq; p0 < n_part; p0 += 256) {
+                float x[4][8];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int p = p0 + 32 * u;
+                        x[s][u] = p < n_part ? g.part[s][(int64_t)p * plen + j] : 0.f;
+                    }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[s] += x[s][u];
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float a = 0.f;
-                for (int p = qq; p < n_part; p += 8) a += g.part[s][(int64_t)p * plen + j];
                 const float sc = (!time_block && j < d) ? g.wb[s] * g.ts[s] : g.wb[s];
-                v = fmaf(sc, a, v);
+                v = fmaf(sc, a[s], v);
             }
         }
         sm[qq][jj] = v;
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(256) void small_finish4_kernel(Finish4 g, int n_par
         if (qq == 0 && j < lim) {
             float tsum = sm[0][jj];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) tsum += sm[k][jj];
+            for (int k = 1; k < 32; ++k) tsum += sm[k][jj];
             if (time_block) at = fmaf(tsum, W0[j], at);
             else theta[j] += tsum;
         }
@@ -404,7 +419,7 @@ extern "C" int gode_gcn_small_finish4_f32(const gode_gcn_odefunc_t* f, const flo
     Finish4 g;
     for (int s = 0; s < 4; ++s) { g.part[s] = part + (int64_t)s * parts * plen; g.wb[s] = wb[s]; g.ts[s] = ts[s]; }
     const int64_t blocks = (out_len + 31) / 32 + 1;
-    hipLaunchKernelGGL(small_finish4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (int)parts, (int)plen,
+    hipLaunchKernelGGL(small_finish4_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, g, (int)parts, (int)plen,
                        (int)d, f->W, theta, (int)out_len);
     GODE_LAUNCH_CHECK();
     return 0;
