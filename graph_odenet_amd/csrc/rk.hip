@@ -310,6 +310,36 @@ int red_blocks(int64_t n) {
     return (int)b;
 }
 
+// Column sums of a WIDE, short matrix (the bias gradients of the QC edge encoder: 760 x 5329 and 760 x 2667 - the
+// row-block kernels above would run on 3 blocks there: 330-550 us): a block owns 32 columns, its 8 row groups stride
+// over the rows with eight loads in flight each and are added in a fixed order; writes the result itself.
+__global__ __launch_bounds__(256) void colsum_wide_kernel(float* __restrict__ out, const float* __restrict__ X, int64_t n_rows, int d,
+                                                         float scale, int accumulate) {
+    __shared__ float sm[8][33];
+    const int jj = threadIdx.x & 31, qq = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + jj;
+    float s = 0.f;
+    if (c < d) {
+        int64_t r = qq;
+        for (; r + 56 < n_rows; r += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = X[(r + 8 * u) * d + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < n_rows; r += 8) s += X[r * d + c];
+    }
+    sm[qq][jj] = s;
+    __syncthreads();
+    if (qq == 0 && c < d) {
+        float t = sm[0][jj];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sm[k][jj];
+        out[c] = accumulate ? out[c] + scale * t : scale * t;
+    }
+}
+
 int64_t colsum_blocks(int64_t n_rows) {
     int64_t b = (n_rows + 255) / 256;
     if (b < 1) b = 1;
@@ -479,6 +509,11 @@ extern "C" int gode_colsum_f32(float* out, const float* X, int64_t n_rows, int64
     if (!out || !scratch || (n_rows > 0 && !X)) return GODE_E_NULLPTR;
     if (d > INT32_MAX) return GODE_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
+    if (d >= 512 && n_rows <= 4 * d) {               // wide and short: one launch, blocks over the columns
+        hipLaunchKernelGGL(colsum_wide_kernel, dim3((unsigned)((d + 31) / 32)), dim3(256), 0, s, out, X, n_rows, (int)d, scale, accumulate);
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
     const int64_t nb = colsum_blocks(n_rows);
     const int64_t rpb = (n_rows + nb - 1) / nb;
     if (d % 4 == 0 && d <= 1024 && !(((uintptr_t)X) & 15) && !(((uintptr_t)scratch) & 15))

@@ -155,11 +155,14 @@ def test_lincomb_and_error_norms():
 def test_colsum_and_reduce_parts():
     from graph_odenet_amd import ops
     torch.manual_seed(1)
-    for n, d in ((1, 16), (300, 7), (5000, 128), (70000, 73)):
+    # (760, 5329), (37, 2667), (2000, 600): wide and short - the bias gradients of the QC edge encoder (colsum_wide_kernel)
+    for n, d in ((1, 16), (300, 7), (5000, 128), (70000, 73), (760, 5329), (37, 2667), (2000, 600), (1, 513)):
         X = torch.randn(n, d)
         out = torch.zeros(d, device=dev())
         ops.colsum_(out, X.to(dev()), scale=-0.5)
         close(out, -0.5 * X.double().sum(0).float(), tol=1e-5 * max(1, n ** 0.5), what="colsum")
+        ops.colsum_(out, X.to(dev()), scale=2.0, accumulate=True)
+        close(out, 1.5 * X.double().sum(0).float(), tol=2e-5 * max(1, n ** 0.5), what="colsum accumulate")
     P = torch.randn(37, 1000)
     out = torch.ones(1000, device=dev())
     ops.reduce_parts_(out, P.to(dev()), scale=2.0, accumulate=True)
