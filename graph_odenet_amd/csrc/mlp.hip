@@ -24,18 +24,21 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;    // BM: the tall variant; the flat one has 64 rows
+constexpr int BK = 16;                       // k depth of a staged tile
 constexpr int LDT = 128 + 4;                 // floats per k-row of a staged tile (k-major): +4 keeps the transposing stores at 2-way
 
 // Loads this thread's ROWS/16 elements of a (ROWS x 16) operand tile into registers / stores them k-major into LDS.
 //   KCONTIG: source is [row][k] with k contiguous (A of C = A B; A and B of C = A B^T)
 //   !KCONTIG: source is [k][row] with row contiguous (B of C = A B; A and B of C = A^T B)
-// Thread t, element j:  KCONTIG: row = (t >> 2) + 64 (j >> 2), k = 4 (t & 3) + (j & 3)  - 2-way LDS store conflicts (free)
+// Thread t, element j:  KCONTIG: k = t & 15, row = (t >> 4) + 16 j - 16 lanes read the 64 contiguous bytes of a row's
+//                                k-tile (rows of 2667 / 5329 floats are only 4-byte aligned: dword loads), 2-way LDS store
+//                                conflicts (free).  (Round-3 first version: k = 4 (t & 3) + (j & 3) - four lanes x 4 B
+//                                at a 16-byte stride per row: 40-59 TFLOP/s against 87 for the row-contiguous operands.)
 //                       else   : row = (t & 31) + 32 (j % (ROWS/32)), k = (t >> 5) + 8 (j / (ROWS/32))  - coalesced, conflict-free
 template <bool KCONTIG, int ROWS>
 __device__ __forceinline__ void tile_coords(int j, int& row, int& k) {
     const int t = threadIdx.x;
-    if (KCONTIG) { row = (t >> 2) + 64 * (j >> 2); k = 4 * (t & 3) + (j & 3); }
+    if (KCONTIG) { k = t & 15; row = (t >> 4) + 16 * j; }
     else { row = (t & 31) + 32 * (j % (ROWS / 32)); k = (t >> 5) + 8 * (j / (ROWS / 32)); }
 }
 template <bool KCONTIG, int ROWS>
@@ -65,39 +68,40 @@ __device__ __forceinline__ void tile_store(float* tile /* [BK][LDT] */, const fl
 }
 
 // C[M x N] = opA(A) opB(B):  A_KC: A given as [M][K] (else [K][M]);  B_KC: B given as [N][K] (else [K][N]).
-// MT = 32-row tiles per wave: 2 -> 128 x 128 block tile, 1 -> 64 x 128 (products with few row tiles: fills the chip)
-template <bool A_KC, bool B_KC, int MT>
+// MT / NTW = 32-row / 32-column tiles per wave: block tile (64 MT) x (64 NTW) - 128 x 128, 64 x 128 or 64 x 64, chosen by
+// the launcher so that the busiest CU carries the least matrix work
+template <bool A_KC, bool B_KC, int MT, int NTW>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
                                                           float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                           const float* __restrict__ bias, int relu,
                                                           const float* __restrict__ mask, int64_t ldmask)
 {
-    constexpr int TM = 64 * MT;                                   // block tile rows
+    constexpr int TM = 64 * MT, TN = 64 * NTW;                    // block tile rows / columns
     __shared__ float As[2][BK * LDT];
     __shared__ float Bs[2][BK * LDT];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int wm = (wave >> 1) * 32 * MT, wn = (wave & 1) * 64;   // this wave's (32 MT) x 64 part of the block tile
+    const int wm = (wave >> 1) * 32 * MT, wn = (wave & 1) * 32 * NTW;   // this wave's (32 MT) x (32 NTW) part of the block tile
     const int li = l & 31, lk = l >> 5;
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * BN;
-    f32x16 acc[MT][2];
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    f32x16 acc[MT][NTW];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NTW; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    float ra[TM / 16], rb[BN / 16];
+    float ra[TM / 16], rb[TN / 16];
     tile_load<A_KC, TM>(A, lda, m0, M, 0, K, ra);
-    tile_load<B_KC, BN>(B, ldb, n0, N, 0, K, rb);
+    tile_load<B_KC, TN>(B, ldb, n0, N, 0, K, rb);
     tile_store<A_KC, TM>(As[0], ra);
-    tile_store<B_KC, BN>(Bs[0], rb);
+    tile_store<B_KC, TN>(Bs[0], rb);
     __syncthreads();
     const int n_kt = (K + BK - 1) / BK;
     for (int kt = 0; kt < n_kt; ++kt) {
         const int cur = kt & 1;
         tile_load<A_KC, TM>(A, lda, m0, M, (kt + 1) * BK, K, ra);     // next tile (zeros past K): in flight during the
-        tile_load<B_KC, BN>(B, ldb, n0, N, (kt + 1) * BK, K, rb);     // matrix phase
+        tile_load<B_KC, TN>(B, ldb, n0, N, (kt + 1) * BK, K, rb);     // matrix phase
         const float* as = As[cur] + lk * LDT + wm + li;
         const float* bs = Bs[cur] + lk * LDT + wn + li;
 #pragma unroll
@@ -105,16 +109,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
             float av[MT];
 #pragma unroll
             for (int a = 0; a < MT; ++a) av[a] = as[2 * ks * LDT + 32 * a];
-            const float b0 = bs[2 * ks * LDT], b1 = bs[2 * ks * LDT + 32];
+            float bv[NTW];
 #pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], b0, acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], b1, acc[a][1], 0, 0, 0);
-            }
+            for (int b = 0; b < NTW; ++b) bv[b] = bs[2 * ks * LDT + 32 * b];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NTW; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         if (kt + 1 < n_kt) {
             tile_store<A_KC, TM>(As[cur ^ 1], ra);                // the other buffer: last read in iteration kt - 1,
-            tile_store<B_KC, BN>(Bs[cur ^ 1], rb);                // which every wave left through the barrier below
+            tile_store<B_KC, TN>(Bs[cur ^ 1], rb);                // which every wave left through the barrier below
         }
         __syncthreads();
     }
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NTW; ++b) {
             const int col = n0 + wn + 32 * b + li;
             const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
@@ -193,19 +199,20 @@ extern "C" int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
     // A is M x K (trans_a = 0, row-major, lda >= K) or K x M (trans_a = 1, lda >= M); B is K x N (trans_b = 0, ldb >= N)
     // or N x K (trans_b = 1, ldb >= K)
     if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N || (mask && ldmask < N)) return GODE_E_SHAPE;
-    // 128 x 128 or 64 x 128 block tiles: whichever leaves the busiest CU with less matrix work - (blocks / 256 CUs rounded
-    // up) x rows per tile.  The products of a QM9 batch have 6-7 row tiles of 128: at 7 x 42 = 294 blocks 38 CUs would
-    // carry two of them (measured 0.54 ms against 0.27 ms at 6 x 42 = 252).
-    const int64_t nb = (N + BN - 1) / BN;
-    const int64_t cost2 = ((((M + 127) / 128) * nb + 255) / 256) * 2, cost1 = ((((M + 63) / 64) * nb + 255) / 256) * 1;
-    const bool small = cost1 < cost2;
-    const int64_t tm = small ? 64 : BM;
-    const dim3 grid((unsigned)nb, (unsigned)((M + tm - 1) / tm));
+    // block tile 128 x 128, 64 x 128 or 64 x 64: the largest one that still gives two blocks per CU (a block is one wave
+    // per SIMD: its barriers and load latencies hide under the co-resident block's matrix work), else the smallest.
+    // Measured on the three products of a 760-edge batch (tools/dev/gemm_probe.py), 128^2 / 64x128 / 64^2:
+    // H W2 0.314 / 0.264 / 0.268 ms, dA W2^T 0.615 / 0.415 / 0.305 ms, H^T dA 0.252 / 0.245 / 0.275 ms.
+    auto blocks_of = [&](int64_t tm, int64_t tn) { return ((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
+    const int shape = blocks_of(128, 128) >= 500 ? 22 : (blocks_of(64, 128) >= 500 ? 12 : 11);
+    const int64_t tm = shape == 22 ? 128 : 64, tn = shape == 11 ? 64 : 128;
+    const dim3 grid((unsigned)((N + tn - 1) / tn), (unsigned)((M + tm - 1) / tm));
     if (grid.y > 65535) return GODE_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
-#define GODE_GEMM2(AKC, BKC, MTV) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, MTV>), grid, dim3(256), 0, s, A, lda, B, ldb, \
-                                                     C, ldc, (int)M, (int)N, (int)K, bias, relu ? 1 : 0, mask, ldmask)
-#define GODE_GEMM(AKC, BKC) { if (small) GODE_GEMM2(AKC, BKC, 1); else GODE_GEMM2(AKC, BKC, 2); }
+#define GODE_GEMM2(AKC, BKC, MTV, NTV) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, MTV, NTV>), grid, dim3(256), 0, s, A, lda, B, ldb, \
+                                                          C, ldc, (int)M, (int)N, (int)K, bias, relu ? 1 : 0, mask, ldmask)
+#define GODE_GEMM(AKC, BKC) { if (shape == 22) GODE_GEMM2(AKC, BKC, 2, 2); else if (shape == 12) GODE_GEMM2(AKC, BKC, 1, 2); \
+                              else GODE_GEMM2(AKC, BKC, 1, 1); }
     if (!trans_a && !trans_b) GODE_GEMM(true, false)
     else if (!trans_a && trans_b) GODE_GEMM(true, true)
     else if (trans_a && !trans_b) GODE_GEMM(false, false)
