@@ -24,30 +24,28 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;                       // k depth of a staged tile
-constexpr int LDT = 128 + 4;                 // floats per k-row of a staged tile (k-major): +4 keeps the transposing stores at 2-way
-
-// Loads this thread's ROWS/16 elements of a (ROWS x 16) operand tile into registers / stores them k-major into LDS.
+// Loads this thread's ROWS * BK / 256 elements of a (ROWS x BK) operand tile into registers / stores them k-major into LDS
+// (row stride ROWS + 1 floats: both kinds of store and the operand reads are conflict-free).
 //   KCONTIG: source is [row][k] with k contiguous (A of C = A B; A and B of C = A B^T)
 //   !KCONTIG: source is [k][row] with row contiguous (B of C = A B; A and B of C = A^T B)
-// Thread t, element j:  KCONTIG: k = t & 15, row = (t >> 4) + 16 j - 16 lanes read the 64 contiguous bytes of a row's
-//                                k-tile (rows of 2667 / 5329 floats are only 4-byte aligned: dword loads), 2-way LDS store
-//                                conflicts (free).  (Round-3 first version: k = 4 (t & 3) + (j & 3) - four lanes x 4 B
-//                                at a 16-byte stride per row: 40-59 TFLOP/s against 87 for the row-contiguous operands.)
-//                       else   : row = (t & 31) + 32 (j % (ROWS/32)), k = (t >> 5) + 8 (j / (ROWS/32))  - coalesced, conflict-free
-template <bool KCONTIG, int ROWS>
+// Thread t, element j:  KCONTIG: k = t % BK, row = t / BK + (256 / BK) j - BK lanes read the 4 BK contiguous bytes of a
+//                                row's k-tile (rows of 2667 / 5329 floats are only 4-byte aligned: dword loads).  (The
+//                                first version read four lanes x 4 B at a 16-byte stride per row: 40-59 TFLOP/s against
+//                                87 for the row-contiguous operands.)
+//                       else   : row = (t & 31) + 32 (j % (ROWS/32)), k = (t >> 5) + 8 (j / (ROWS/32)) - coalesced
+template <bool KCONTIG, int ROWS, int BK>
 __device__ __forceinline__ void tile_coords(int j, int& row, int& k) {
     const int t = threadIdx.x;
-    if (KCONTIG) { k = t & 15; row = (t >> 4) + 16 * j; }
+    if (KCONTIG) { k = t % BK; row = t / BK + (256 / BK) * j; }
     else { row = (t & 31) + 32 * (j % (ROWS / 32)); k = (t >> 5) + 8 * (j / (ROWS / 32)); }
 }
-template <bool KCONTIG, int ROWS>
+template <bool KCONTIG, int ROWS, int BK>
 __device__ __forceinline__ void tile_load(const float* __restrict__ src, int64_t ld, int row0, int n_rows, int k0, int n_k,
-                                          float (&v)[ROWS / 16]) {
+                                          float (&v)[ROWS * BK / 256]) {
 #pragma unroll
-    for (int j = 0; j < ROWS / 16; ++j) {
+    for (int j = 0; j < ROWS * BK / 256; ++j) {
         int row, k;
-        tile_coords<KCONTIG, ROWS>(j, row, k);
+        tile_coords<KCONTIG, ROWS, BK>(j, row, k);
         // unconditional loads from clamped coordinates (a load under a branch is waited for at the join, which would
         // put the wait in front of the matrix phase); out-of-range elements are zeroed afterwards
         const bool ok = row0 + row < n_rows && k0 + k < n_k;
@@ -57,20 +55,21 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ src, int64_t
         v[j] = ok ? x : 0.f;
     }
 }
-template <bool KCONTIG, int ROWS>
-__device__ __forceinline__ void tile_store(float* tile /* [BK][LDT] */, const float (&v)[ROWS / 16]) {
+template <bool KCONTIG, int ROWS, int BK>
+__device__ __forceinline__ void tile_store(float* tile /* [BK][ROWS + 1] */, const float (&v)[ROWS * BK / 256]) {
 #pragma unroll
-    for (int j = 0; j < ROWS / 16; ++j) {
+    for (int j = 0; j < ROWS * BK / 256; ++j) {
         int row, k;
-        tile_coords<KCONTIG, ROWS>(j, row, k);
-        tile[k * LDT + row] = v[j];
+        tile_coords<KCONTIG, ROWS, BK>(j, row, k);
+        tile[k * (ROWS + 1) + row] = v[j];
     }
 }
 
 // C[M x N] = opA(A) opB(B):  A_KC: A given as [M][K] (else [K][M]);  B_KC: B given as [N][K] (else [K][N]).
 // MT / NTW = 32-row / 32-column tiles per wave: block tile (64 MT) x (64 NTW) - 128 x 128, 64 x 128 or 64 x 64, chosen by
-// the launcher so that the busiest CU carries the least matrix work
-template <bool A_KC, bool B_KC, int MT, int NTW>
+// the launcher; BK = k depth of a staged tile (16 for the largest tile: 64 KB of static LDS; 32 otherwise - half the
+// barriers per flop).
+template <bool A_KC, bool B_KC, int MT, int NTW, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
                                                           float* __restrict__ C, int64_t ldc, int M, int N, int K,
@@ -78,8 +77,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                                                           const float* __restrict__ mask, int64_t ldmask)
 {
     constexpr int TM = 64 * MT, TN = 64 * NTW;                    // block tile rows / columns
-    __shared__ float As[2][BK * LDT];
-    __shared__ float Bs[2][BK * LDT];
+    constexpr int LDA = TM + 1, LDB = TN + 1;
+    __shared__ float As[2][BK * LDA];
+    __shared__ float Bs[2][BK * LDB];
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int wm = (wave >> 1) * 32 * MT, wn = (wave & 1) * 32 * NTW;   // this wave's (32 MT) x (32 NTW) part of the block tile
     const int li = l & 31, lk = l >> 5;
@@ -91,27 +91,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
         for (int b = 0; b < NTW; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    float ra[TM / 16], rb[TN / 16];
-    tile_load<A_KC, TM>(A, lda, m0, M, 0, K, ra);
-    tile_load<B_KC, TN>(B, ldb, n0, N, 0, K, rb);
-    tile_store<A_KC, TM>(As[0], ra);
-    tile_store<B_KC, TN>(Bs[0], rb);
+    float ra[TM * BK / 256], rb[TN * BK / 256];
+    tile_load<A_KC, TM, BK>(A, lda, m0, M, 0, K, ra);
+    tile_load<B_KC, TN, BK>(B, ldb, n0, N, 0, K, rb);
+    tile_store<A_KC, TM, BK>(As[0], ra);
+    tile_store<B_KC, TN, BK>(Bs[0], rb);
     __syncthreads();
     const int n_kt = (K + BK - 1) / BK;
     for (int kt = 0; kt < n_kt; ++kt) {
         const int cur = kt & 1;
-        tile_load<A_KC, TM>(A, lda, m0, M, (kt + 1) * BK, K, ra);     // next tile (zeros past K): in flight during the
-        tile_load<B_KC, TN>(B, ldb, n0, N, (kt + 1) * BK, K, rb);     // matrix phase
-        const float* as = As[cur] + lk * LDT + wm + li;
-        const float* bs = Bs[cur] + lk * LDT + wn + li;
+        tile_load<A_KC, TM, BK>(A, lda, m0, M, (kt + 1) * BK, K, ra);     // next tile (zeros past K): in flight during the
+        tile_load<B_KC, TN, BK>(B, ldb, n0, N, (kt + 1) * BK, K, rb);     // matrix phase
+        const float* as = As[cur] + lk * LDA + wm + li;
+        const float* bs = Bs[cur] + lk * LDB + wn + li;
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            float av[MT];
+            float av[MT], bv[NTW];
 #pragma unroll
-            for (int a = 0; a < MT; ++a) av[a] = as[2 * ks * LDT + 32 * a];
-            float bv[NTW];
+            for (int a = 0; a < MT; ++a) av[a] = as[2 * ks * LDA + 32 * a];
 #pragma unroll
-            for (int b = 0; b < NTW; ++b) bv[b] = bs[2 * ks * LDT + 32 * b];
+            for (int b = 0; b < NTW; ++b) bv[b] = bs[2 * ks * LDB + 32 * b];
 #pragma unroll
             for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -119,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         if (kt + 1 < n_kt) {
-            tile_store<A_KC, TM>(As[cur ^ 1], ra);                // the other buffer: last read in iteration kt - 1,
-            tile_store<B_KC, TN>(Bs[cur ^ 1], rb);                // which every wave left through the barrier below
+            tile_store<A_KC, TM, BK>(As[cur ^ 1], ra);            // the other buffer: last read in iteration kt - 1,
+            tile_store<B_KC, TN, BK>(Bs[cur ^ 1], rb);            // which every wave left through the barrier below
         }
         __syncthreads();
     }
@@ -130,12 +129,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 #pragma unroll
         for (int b = 0; b < NTW; ++b) {
             const int col = n0 + wn + 32 * b + li;
-            const float bv = (bias && col < N) ? bias[col] : 0.f;
+            const float bvv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 if (row < M && col < N) {
-                    float v = acc[a][b][e] + bv;
+                    float v = acc[a][b][e] + bvv;
                     if (relu) v = fmaxf(v, 0.f);
                     if (mask) v = mask[(int64_t)row * ldmask + col] > 0.f ? v : 0.f;
                     C[(int64_t)row * ldc + col] = v;
@@ -209,10 +208,10 @@ extern "C" int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
     const dim3 grid((unsigned)((N + tn - 1) / tn), (unsigned)((M + tm - 1) / tm));
     if (grid.y > 65535) return GODE_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
-#define GODE_GEMM2(AKC, BKC, MTV, NTV) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, MTV, NTV>), grid, dim3(256), 0, s, A, lda, B, ldb, \
-                                                          C, ldc, (int)M, (int)N, (int)K, bias, relu ? 1 : 0, mask, ldmask)
-#define GODE_GEMM(AKC, BKC) { if (shape == 22) GODE_GEMM2(AKC, BKC, 2, 2); else if (shape == 12) GODE_GEMM2(AKC, BKC, 1, 2); \
-                              else GODE_GEMM2(AKC, BKC, 1, 1); }
+#define GODE_GEMM2(AKC, BKC, MTV, NTV, BKV) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, MTV, NTV, BKV>), grid, dim3(256), 0, s, A, lda, \
+                                                               B, ldb, C, ldc, (int)M, (int)N, (int)K, bias, relu ? 1 : 0, mask, ldmask)
+#define GODE_GEMM(AKC, BKC) { if (shape == 22) GODE_GEMM2(AKC, BKC, 2, 2, 16); else if (shape == 12) GODE_GEMM2(AKC, BKC, 1, 2, 32); \
+                              else GODE_GEMM2(AKC, BKC, 1, 1, 32); }
     if (!trans_a && !trans_b) GODE_GEMM(true, false)
     else if (!trans_a && trans_b) GODE_GEMM(true, true)
     else if (trans_a && !trans_b) GODE_GEMM(false, false)
