@@ -55,8 +55,7 @@ def cpu_oracle_step(model_name, batch_size, reps):
     def mpnn_cpu(x, Esrc, Etgt, A):
         return R.mpnn_enn_edge(x, Esrc, Etgt, A, net.mpnn.update_net, net.mpnn.T)
     net.mpnn.forward = mpnn_cpu
-    from graph_odenet_amd.optim import Adam
-    opt = Adam(net.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)         # host baseline: torch's own optimiser
     x, ef, Esrc, Etgt, batch, tgt = batches[0]
     ts = []
     for _ in range(reps + 1):
