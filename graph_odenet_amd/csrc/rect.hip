@@ -36,7 +36,7 @@ __device__ __forceinline__ float4 to_f_layout(const float4 v, int src_x4) {
 // out[row][c_base + ...] = sum_k in[row][k] * Wop(k, col):  NT column tiles of 16 per wave pass.
 //   TRANSW = false:  Wop(k, col) = W[k * M + col]     (S = X W;     K = inner = rows of W, M = columns of W = outputs)
 //   TRANSW = true :  Wop(k, col) = W[col * Kin + k]   (dX = dS W^T; inner = columns of W, outputs = rows of W)
-// VEC: in / out rows are 16-byte aligned and ld % 4 == 0 (float4 traffic in the memory layout); else scalar accesses.
+// VEC: in / out rows are 16-byte aligned and ld % 4 == 0 (16-byte accesses); else dword accesses, same lane layout.
 template <int NT, bool TRANSW, bool VEC>
 __global__ __launch_bounds__(256) void rect_gemm_kernel(const float* __restrict__ in, int64_t ld_in, int n_rows, int inner,
                                                         const float* __restrict__ W, int w_ld, int n_out,
@@ -53,24 +53,19 @@ __global__ __launch_bounds__(256) void rect_gemm_kernel(const float* __restrict_
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < inner; k0 += 16) {
-            float4 xv;
-            if (VEC) {
+            // memory layout (lane m: row m >> 2, floats 4 (m & 3) .. + 3 of the 16-wide k chunk: four lanes cover the 64
+            // contiguous bytes of a row) in both cases; rows that are not 16-byte aligned (K = 3703, 1433) take four dword
+            // loads per lane instead of one 16-byte load.  (The first version read unaligned operands in the MFMA layout -
+            // adjacent lanes 4 K bytes apart: 0.68 ms for Citeseer's 3327 x 3703 input layer.)
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            {
                 const int row = tile * 16 + mr, k = k0 + 4 * mg;
-                xv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < n_rows && k < inner) {
-                    if (k + 3 < inner) xv = ld4(in + (int64_t)row * ld_in + k);
-                    else {
-                        const float* p = in + (int64_t)row * ld_in + k;
-                        xv.x = p[0]; if (k + 1 < inner) xv.y = p[1]; if (k + 2 < inner) xv.z = p[2];
-                    }
+                    const float* p = in + (int64_t)row * ld_in + k;
+                    if (VEC && k + 3 < inner) xv = ld4(p);
+                    else { xv.x = p[0]; if (k + 1 < inner) xv.y = p[1]; if (k + 2 < inner) xv.z = p[2]; if (k + 3 < inner) xv.w = p[3]; }
                 }
                 xv = to_f_layout(xv, to_f);
-            } else {
-                const int row = tile * 16 + r, k = k0 + 4 * g;
-                const float* p = in + (int64_t)row * ld_in + k;
-                const bool ok = row < n_rows;
-                xv = make_float4(ok && k < inner ? p[0] : 0.f, ok && k + 1 < inner ? p[1] : 0.f,
-                                 ok && k + 2 < inner ? p[2] : 0.f, ok && k + 3 < inner ? p[3] : 0.f);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -87,24 +82,13 @@ __global__ __launch_bounds__(256) void rect_gemm_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-            if (VEC) {
-                const float4 o = to_f_layout(make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]), to_m);   // -> memory layout
-                const int row = tile * 16 + mr, col = c_base + 16 * tt + 4 * mg;
-                if (row < n_rows && col < out_cols) {
-                    // columns >= n_out come out as exact zeros (their weights were read as zero)
-                    if (col + 3 < out_cols) *reinterpret_cast<float4*>(out + (int64_t)row * ld_out + col) = o;
-                    else {
-                        float* p = out + (int64_t)row * ld_out + col;
-                        p[0] = o.x; if (col + 1 < out_cols) p[1] = o.y; if (col + 2 < out_cols) p[2] = o.z;
-                    }
-                }
-            } else {
-                const int row = tile * 16 + r;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int col = c_base + 16 * tt + 4 * g + q;
-                    if (row < n_rows && col < out_cols) out[(int64_t)row * ld_out + col] = acc[tt][q];
-                }
+            const float4 o = to_f_layout(make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]), to_m);   // -> memory layout
+            const int row = tile * 16 + mr, col = c_base + 16 * tt + 4 * mg;
+            if (row < n_rows && col < out_cols) {
+                // columns >= n_out come out as exact zeros (their weights were read as zero)
+                float* p = out + (int64_t)row * ld_out + col;
+                if (VEC && col + 3 < out_cols) *reinterpret_cast<float4*>(p) = o;
+                else { p[0] = o.x; if (col + 1 < out_cols) p[1] = o.y; if (col + 2 < out_cols) p[2] = o.z; if (col + 3 < out_cols) p[3] = o.w; }
             }
         }
     }

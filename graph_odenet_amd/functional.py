@@ -56,16 +56,32 @@ class _DenseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W):
+        from .layers import sparse_features, _pad4
         x, W = x.contiguous(), W.contiguous()
         ctx.save_for_backward(x, W)
-        return ops.rect_gemm(x, W)
+        # a mostly-zero input (Citeseer's 3327 x 3703 bag of words under the GAT input layer's three projections) runs
+        # as CSR(X) @ W on the aggregation kernel from its second sighting (layers.sparse_features)
+        ctx.xs = sparse_features(x)
+        if ctx.xs is None:
+            return ops.rect_gemm(x, W)
+        m, mp = W.shape[1], _pad4(W.shape[1])
+        y = ops.spmm(ctx.xs, W if mp == m else torch.nn.functional.pad(W, (0, mp - m)))
+        return y if mp == m else y[:, :m].contiguous()
 
     @staticmethod
     def backward(ctx, dy):
+        from .layers import _pad4
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
         gx = ops.rect_gemm_nt(dy, W) if ctx.needs_input_grad[0] else None
-        gw = ops.rect_wgrad(x, dy) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            if ctx.xs is None:
+                gw = ops.rect_wgrad(x, dy)
+            else:
+                m, mp = W.shape[1], _pad4(W.shape[1])
+                gw = ops.spmm(ctx.xs.transpose(), dy if mp == m else torch.nn.functional.pad(dy, (0, mp - m)))
+                gw = gw if mp == m else gw[:, :m].contiguous()
         return gx, gw
 
 

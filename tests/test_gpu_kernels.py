@@ -556,12 +556,12 @@ def test_vjp_from_exact_bf16_pieces(n, groups):
 
 
 @pytest.mark.parametrize("n", [1, 17, 1000, 70001])
-@pytest.mark.parametrize("K,M", [(16, 7), (128, 16), (1433, 16), (500, 16), (3, 3), (100, 40), (64, 200), (130, 129)])
+@pytest.mark.parametrize("K,M", [(16, 7), (128, 16), (1433, 16), (500, 16), (3, 3), (100, 40), (64, 200), (130, 129), (3703, 64), (3703, 2)])
 def test_rectangular_products_vs_float64(n, K, M):
     """csrc/rect.hip: the dense products of a GraphConvolution with in_features != out_features (GCN/layers.py:32
     `torch.mm(input, self.weight)` and its autograd) on the exact fp32 matrix instruction - X W (with the output padded
     to a multiple of four columns, pad = exact zeros), dS W^T (dS a column block of the padded matrix), X^T dS (block
-    partials + fixed-order sum) - against float64; aligned rows take the 16-byte path, K % 4 != 0 the scalar one."""
+    partials + fixed-order sum) - against float64; aligned rows take the 16-byte accesses, K % 4 != 0 (Cora 1433, Citeseer 3703) dword accesses in the same lane layout."""
     from graph_odenet_amd import ops
     if n * K > 40_000_000:
         pytest.skip("operand larger than the test needs")
@@ -586,6 +586,35 @@ def test_rectangular_products_vs_float64(n, K, M):
     dw = ops.rect_wgrad(x.to(D), dSd[:, :M]).cpu()
     assert dw.shape == (K, M)
     assert (dw.double() - want_dw).abs().max().item() <= 3e-6 * (want_dw.abs().max().item() + 1e-30) * max(1.0, (n / 4096) ** 0.5)
+
+
+def test_dense_on_a_mostly_zero_input_takes_the_csr_route():
+    """functional.dense (the GAT input layer's three projections of Citeseer's 3327 x 3703 bag of words, GAT/layers.py:43-45)
+    runs CSR(X) @ W from the second sighting of the same tensor object; output widths 64 and 2 (the logit pair, padded to
+    4 columns for the aggregation kernel); forward and weight gradient against float64 on both routes."""
+    from graph_odenet_amd import functional as Fn, layers as L
+    g = torch.Generator().manual_seed(11)
+    n, K = 3327, 3703
+    x = (torch.rand(n, K, generator=g) < 0.009).float()
+    x = x / x.sum(1, keepdim=True).clamp_min(1)
+    xd = x.to(dev())
+    for M in (64, 2):
+        W = (torch.randn(K, M, generator=g) / K ** 0.5)
+        dy = torch.randn(n, M, generator=g)
+        ref, ref_gw = x.double() @ W.double(), x.double().t() @ dy.double()
+        routes = []
+        for sighting in range(3):
+            Wd = W.to(dev()).requires_grad_(True)
+            y = Fn.dense(xd, Wd)
+            y.backward(dy.to(dev()))
+            routes.append(y.grad_fn.xs is not None)
+            assert y.shape == (n, M) and y.is_contiguous()
+            assert (y.detach().cpu().double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+            assert (Wd.grad.cpu().double() - ref_gw).abs().max().item() <= 3e-6 * ref_gw.abs().max().item()
+        if M == 64:
+            assert routes == [False, True, True], routes
+        else:
+            assert routes == [True, True, True], routes           # the tensor was already classified
 
 
 @pytest.mark.parametrize("M,N,K", [(760, 5329, 2667), (760, 2667, 5), (5, 2667, 760), (1, 1, 1), (129, 130, 17), (64, 128, 16), (300, 73, 200)])

@@ -25,15 +25,19 @@ x = (torch.rand(n, 3703, generator=gen) < 0.01).float()
 x = (x / x.sum(1, keepdim=True).clamp_min(1)).to(dev)
 y = torch.randint(0, 6, (n,), generator=gen).to(dev)
 idx = torch.arange(120, device=dev)
+only = sys.argv[1:]          # e.g. "8:64:rk4" - restrict to some cases (profiling)
 for heads, nhid in ((1, 16), (1, 64), (8, 64), (8, 128)):
     zoo = gat_models if heads == 1 else gat_heads.zoo(heads)
     for method, step in (("rk4", 1 / 16), (None, None)):
+        if only and "%d:%d:%s" % (heads, nhid, method or "dopri5") not in only:
+            continue
         torch.manual_seed(0)
         m = zoo.ODEGCN3(nfeat=3703, nhid=nhid, nclass=6, dropout=0.5, method=method, step_size=step).to(dev)
-        opt = torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=5e-4)
+        from graph_odenet_amd.optim import Adam
+        opt = Adam(m.parameters(), lr=0.01, weight_decay=5e-4)
 
         def train_step():
-            m.train(); opt.zero_grad(); m.nfe = 0
+            m.train(); opt.zero_grad(set_to_none=False); m.nfe = 0
             out = m(x, src, tgt, Mtgt)
             nf = m.nfe; m.nfe = 0
             torch.nn.functional.nll_loss(out[idx], y[idx]).backward(); opt.step()
