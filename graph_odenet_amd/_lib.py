@@ -77,7 +77,8 @@ class GatWorkspace(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("X", "Ps", "Pt", "A2", "a", "amax", "wgt", "den", "logits_scratch", "dz", "da",
                                                "dPs", "dPt", "dA2", "pair", "gp", "bp")] + \
                [("wp", ctypes.c_void_p * 3), ("maxpath_scratch", ctypes.c_void_p), ("colsum_scratch", ctypes.c_void_p),
-                ("zeros", ctypes.c_void_p), ("heads_scratch", ctypes.c_void_p), ("colsum_scratch2", ctypes.c_void_p)]
+                ("zeros", ctypes.c_void_p), ("heads_scratch", ctypes.c_void_p), ("colsum_scratch2", ctypes.c_void_p),
+                ("small_part", ctypes.c_void_p)]
 
 
 GODE_ADAM_MAX_TENSORS = 64
@@ -127,6 +128,14 @@ SIGNATURES = {
     "gode_adam_chunk": (c_i64, []),
     "gode_adam_tick_f32": (c_i, [c_p, c_f, c_f, c_p]),
     "gode_adam_f32": (c_i, [ctypes.POINTER(AdamArgs), ctypes.c_int32, c_p, c_i64, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),
+    "gode_gat_small_supported": (c_i, [c_i64, c_i64, ctypes.c_int32, c_i64]),
+    "gode_gat_small_parts": (c_i64, [c_i64]),
+    "gode_gat_small_part_len": (c_i64, [c_i64, c_i64]),
+    "gode_gat_project_small_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p,
+                                         c_i64, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "gode_gat_dense_vjp_small_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p,
+                                           c_i64, c_p, c_p, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p]),
+    "gode_gat_small_finish_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     "gode_gcn_small_supported": (c_i, [c_i64, c_i64, ctypes.c_int32]),
     "gode_gcn_small_parts": (c_i64, [c_i64]),
     "gode_gcn_small_part_len": (c_i64, [c_i64]),

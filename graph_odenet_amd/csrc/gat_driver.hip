@@ -6,6 +6,7 @@
 // and the error-ratio sums, so that an adaptive step on a citation-size graph is one call instead of ~200.
 // The launch sequence of one evaluation is graph_odenet_amd/gat_ode.py (GatOdeField / GatOdeAdjointField).
 #include "common.h"
+#include "options.h"
 
 namespace {
 
@@ -58,10 +59,21 @@ __global__ void odd_entries_kernel(float* __restrict__ dst, const float* __restr
     if (i < n) dst[i] = src[2 * i + 1];
 }
 
+inline bool small_dense(const gode_gat_odefunc_t* f) {
+    return gode_opt_small_fused() && gode_gat_small_supported(f->n, f->d, f->groups, n_heads(f));
+}
+
 // Ps, Pt, A2 of the stage input; a multi-term input is combined once (x_out) and read back as one array afterwards
 int project(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lincomb_t* yin, float t, void* stream) {
     const int64_t n = f->n, d = f->d;
     float* xo = yin->n > 1 ? w->X : nullptr;
+    const int64_t Hh = n_heads(f);
+    if (small_dense(f)) {                       // launch-bound graphs: the three products (and the bias add) as one launch
+        GODE_TRY(gode_gat_project_small_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, f->Wtgt, f->Wlog, Hh,
+                                            Hh > 1 ? f->bf : nullptr, t, w->Ps, w->Pt, w->A2, xo, stream));
+        if (xo) { yin->n = 1; yin->coef[0] = 1.f; yin->ptr[0] = xo; }
+        return 0;
+    }
     GODE_TRY(gode_gn_time_gemm_pair_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, f->Wtgt, 1, t, w->Ps, w->Pt,
                                         xo, stream));
     if (xo) { yin->n = 1; yin->coef[0] = 1.f; yin->ptr[0] = xo; }
@@ -117,6 +129,11 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
     } else {
         GODE_TRY(gode_gat_scatter_f32(f->ms_inc.rowptr, f->ms_inc.col, f->mt_inc.rowptr, f->mt_inc.col, w->dz, w->da, o, nv,
                                       w->dPs, o, w->dPt, o, w->dA2, w->dA2 + 1, 2, stream));
+    }
+    if (w->small_part && small_dense(f)) {      // k_a and all parameter-gradient partials in one launch, one more to close
+        GODE_TRY(gode_gat_dense_vjp_small_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, f->Wtgt, f->Wlog, H,
+                                              w->dPs, w->dPt, w->dA2, 1.f, nullptr, ka, w->small_part, stream));
+        return gode_gat_small_finish_f32(w->small_part, n, d, H, t, kth, kat, stream);
     }
     float* g_src = kth; float* g_tgt = kth + nW; float* g_log = kth + 2 * nW;
     float* g_bf = g_log + nL; float* g_bw = g_bf + d; float* g_gamma = g_bw + H; float* g_beta = g_gamma + d;

@@ -1,0 +1,456 @@
+// gat_small.hip — the ROW-LOCAL (dense) half of the GAT ODE function and of its vector-Jacobian product on LAUNCH-BOUND
+// graphs (Citeseer: 3 327 nodes), as one kernel per direction, gfx950.
+//
+// f(t, x) = relu(EdgeAttention([t | GroupNorm(x)]))  (GAT/models.py:172-179 -> GAT/layers.py:95-122).  The two Linear
+// layers of the reference (f: o x 2i on [h_src | h_tgt], w: 1 x 2i; GAT/layers.py:43,45) are applied at node level and
+// split by role (graph_odenet_amd/gat_ode.py): Ps = [t|xn] Wsrc, Pt = [t|xn] Wtgt, A2 = [t|xn] Wlog (n x 2H logit
+// columns).  On a large graph these are three products on the MFMA kernels of gemm.hip, and their autograd is three VJP
+// launches, three weight-gradient launches, two column sums and the reductions; on a citation graph every one of them
+// runs for 4-27 us (the 2H-column block on the generic kernels) and an adjoint stage is ~18 launches.  Here:
+//
+//   gode_gat_project_small_f32     Ps, Pt (+ per-head bias), A2 (and the combined stage input) from ONE read of x:
+//                                  replaces gode_gn_time_gemm_pair_f32 + gode_gn_time_gemm_f32 (+ the bias add)
+//   gode_gat_dense_vjp_small_f32   k_a = GN'(x)^T (dPs Wsrc^T + dPt Wtgt^T + dA2 Wlog^T) (+ pre), and block partials of
+//                                  ALL parameter gradients of the stage - dWsrc, dWtgt, dWlog (row 0 = column sums of
+//                                  dPs / dPt / dA2: the time rows, and, read again, the bias gradients bf = colsum(dPt),
+//                                  bw = odd columns of colsum(dA2)), dgamma, dbeta, and the block's share of
+//                                  a_t = colsums . W[0, :]: replaces 3 + 3 + 2 launches
+//   gode_gat_small_finish_f32      k_theta and k_a_t from the partials: one launch, every load in flight at once
+//
+// Work decomposition as in small.hip: a wave owns a row at a time, a lane holds 4 consecutive columns, the wave's
+// 256/d sub-groups stride over the reduction index of the dense products and are combined with xor-shuffles (fixed
+// order: deterministic).  Weights live in LDS ((d+1) x (2d + 2H) floats: 37 KB at d = 64, H = 8).
+#include "common.h"
+#include "dense_common.h"
+#include "options.h"
+
+namespace {
+
+constexpr int kGatPartBlocks = 512;        // one or two rows per wave on a citation graph; the closing launch reads them 16 at a time
+
+__device__ __forceinline__ void xor_combine4(float4& v, int from) {
+#pragma unroll
+    for (int off = from; off < 64; off <<= 1) {
+        v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
+        v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+    }
+}
+__device__ __forceinline__ void fma4(float4& acc, float a, const float4 w) {
+    acc.x = fmaf(a, w.x, acc.x); acc.y = fmaf(a, w.y, acc.y); acc.z = fmaf(a, w.z, acc.z); acc.w = fmaf(a, w.w, acc.w);
+}
+__device__ __forceinline__ void add4(float4& acc, const float4 v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+
+// GroupNorm backward of one float4: small.hip's gn_backward4 (the arithmetic of gn_gemm_bwd_kernel)
+template <int CG>
+__device__ __forceinline__ float4 gn_backward4(const float4 x, const float4 dy, const float4 gm, float eps, float4& xh_out) {
+    float4 mean, rstd;
+    gn_stats<CG>(x, eps, mean, rstd);
+    const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y, (x.z - mean.z) * rstd.z, (x.w - mean.w) * rstd.w);
+    xh_out = xh;
+    const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+    if (CG == 4) {
+        const float m1 = ((dh.x + dh.y) + (dh.z + dh.w)) * 0.25f;
+        const float m2 = ((dh.x * xh.x + dh.y * xh.y) + (dh.z * xh.z + dh.w * xh.w)) * 0.25f;
+        const float rs = rstd.x;
+        return make_float4(rs * (dh.x - m1 - xh.x * m2), rs * (dh.y - m1 - xh.y * m2), rs * (dh.z - m1 - xh.z * m2), rs * (dh.w - m1 - xh.w * m2));
+    }
+    const float4 px = make_float4(dh.x * x.x, dh.y * x.y, dh.z * x.z, dh.w * x.w);
+    float4 ds, db;
+    if (CG == 1) { ds = px; db = dh; }
+    else {
+        ds = make_float4(px.x + px.y, px.x + px.y, px.z + px.w, px.z + px.w);
+        db = make_float4(dh.x + dh.y, dh.x + dh.y, dh.z + dh.w, dh.z + dh.w);
+    }
+    constexpr float sc = 1.0f / CG;
+    const float4 r3 = make_float4(rstd.x * rstd.x * rstd.x * sc, rstd.y * rstd.y * rstd.y * sc, rstd.z * rstd.z * rstd.z * sc, rstd.w * rstd.w * rstd.w * sc);
+    const float4 c2 = make_float4((db.x * mean.x - ds.x) * r3.x, (db.y * mean.y - ds.y) * r3.y, (db.z * mean.z - ds.z) * r3.z, (db.w * mean.w - ds.w) * r3.w);
+    const float4 c3 = make_float4(-c2.x * mean.x - db.x * rstd.x * sc, -c2.y * mean.y - db.y * rstd.y * sc,
+                                  -c2.z * mean.z - db.z * rstd.z * sc, -c2.w * mean.w - db.w * rstd.w * sc);
+    return make_float4(rstd.x * gm.x * dy.x + c2.x * x.x + c3.x, rstd.y * gm.y * dy.y + c2.y * x.y + c3.y,
+                       rstd.z * gm.z * dy.z + c2.z * x.z + c3.z, rstd.w * gm.w * dy.w + c2.w * x.w + c3.w);
+}
+
+// four logit-row entries 4 q .. 4 q + 3 of a row of nl floats (nl = 2 H: rows are 8-byte aligned only)
+__device__ __forceinline__ float4 load_logit4(const float* __restrict__ p, int c0, int nl) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 < nl) v.x = p[c0];
+    if (c0 + 1 < nl) v.y = p[c0 + 1];
+    if (c0 + 2 < nl) v.z = p[c0 + 2];
+    if (c0 + 3 < nl) v.w = p[c0 + 3];
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// projections:  [Ps | Pt | A2][i] = [t | GN(x_i)] [Wsrc | Wtgt | Wlog]     (NLP = logit columns padded to 4 or 16)
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, int CG, int NLP>
+__global__ __launch_bounds__(256) void gat_project_small_kernel(LinComb xin, int n_rows, float eps,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ Wsrc, const float* __restrict__ Wtgt,
+                                                               const float* __restrict__ Wlog, int nl,
+                                                               const float* __restrict__ pt_bias, float t,
+                                                               float* __restrict__ Ps, float* __restrict__ Pt,
+                                                               float* __restrict__ A2, float* __restrict__ xout)
+{
+    constexpr int LPR = D / 4, SG = 64 / LPR, WS = 2 * D + NLP;
+    __shared__ __attribute__((aligned(16))) float Wall[(D + 1) * WS];
+    __shared__ __attribute__((aligned(16))) float mrow[4][D + 4];            // [0] = t, [4 ..] = the normalised row
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
+    for (int i = threadIdx.x; i < (D + 1) * D; i += 256) {
+        const int k = i / D, c = i % D;
+        Wall[k * WS + c] = Wsrc[i];
+        Wall[k * WS + D + c] = Wtgt[i];
+    }
+    for (int i = threadIdx.x; i < (D + 1) * NLP; i += 256) {
+        const int k = i / NLP, c = i % NLP;
+        Wall[k * WS + 2 * D + c] = c < nl ? Wlog[k * nl + c] : 0.f;
+    }
+    __syncthreads();
+    const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 pb = pt_bias ? ld4(pt_bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_l = 4 * q < NLP;
+    float* mr = mrow[wave];
+    for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {            // wave-uniform
+        const int64_t o = (int64_t)row * D + 4 * q;
+        const float4 x = lc_load4(xin, o);
+        const float4 xn = gn_forward_v<CG>(x, eps, gm, bt);
+        if (s == 0) {
+            if (xout) *reinterpret_cast<float4*>(xout + o) = x;
+            *reinterpret_cast<float4*>(mr + 4 + 4 * q) = xn;
+            if (q == 0) mr[0] = t;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pt = ps, pl = ps;
+        for (int k = s; k <= D; k += SG) {
+            const float mk = k == 0 ? mr[0] : mr[3 + k];
+            const float* wk = Wall + k * WS + 4 * q;
+            fma4(ps, mk, *reinterpret_cast<const float4*>(wk));
+            fma4(pt, mk, *reinterpret_cast<const float4*>(wk + D));
+            if (has_l) fma4(pl, mk, *reinterpret_cast<const float4*>(wk + 2 * D));
+        }
+        xor_combine4(ps, LPR);
+        xor_combine4(pt, LPR);
+        xor_combine4(pl, LPR);                                   // lanes without logit columns carry zeros
+        if (s == 0) {
+            *reinterpret_cast<float4*>(Ps + o) = ps;
+            add4(pt, pb);
+            *reinterpret_cast<float4*>(Pt + o) = pt;
+            if (has_l) {
+                float* ap = A2 + (int64_t)row * nl;
+                const int c0 = 4 * q;
+                if (c0 < nl) ap[c0] = pl.x;
+                if (c0 + 1 < nl) ap[c0 + 1] = pl.y;
+                if (c0 + 2 < nl) ap[c0 + 2] = pl.z;
+                if (c0 + 3 < nl) ap[c0 + 3] = pl.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                         // the next row's mrow stores follow these reads
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// VJP of the projections + every parameter-gradient partial of the stage.
+// part[block] = [ dWsrc ((D+1) x D, row 0 = colsum dPs) | dWtgt (row 0 = colsum dPt) | dWlog ((D+1) x nl, row 0 = colsum dA2)
+//                 | dgamma | dbeta | colsums . [Wsrc[0] | Wtgt[0] | Wlog[0]] ]
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, int NLP> struct GatVjpShape {
+    static constexpr int LPR = D / 4, SG = 64 / LPR, NS = D / SG, NSL = (NLP + SG - 1) / SG;
+    static constexpr int NIN = 2 * D + NLP;                      // columns of [dPs | dPt | dA2]
+    static constexpr int WT = NIN * (D + 4);                     // transposed weights, row stride D + 4
+    static constexpr int PMAX = 2 * (D + 1) * D + (D + 1) * NLP + 2 * D + 1;
+    static constexpr int BUF = WT > PMAX ? WT : PMAX;
+};
+
+template <int D, int CG, int NLP>
+__global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, int n_rows, float eps,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ Wsrc, const float* __restrict__ Wtgt,
+                                                                 const float* __restrict__ Wlog, int nl,
+                                                                 const float* __restrict__ dPs, const float* __restrict__ dPt,
+                                                                 const float* __restrict__ dA2, float out_scale, LinComb pre,
+                                                                 float* __restrict__ ka, float* __restrict__ part)
+{
+    using S = GatVjpShape<D, NLP>;
+    constexpr int LPR = S::LPR, SG = S::SG, NS = S::NS, NSL = S::NSL, NIN = S::NIN, nW = (D + 1) * D;
+    // Wt[c][k] = W(k + 1, c) over the 2 D + NLP input columns c; the same storage holds the block partial afterwards
+    __shared__ __attribute__((aligned(16))) float buf[S::BUF];
+    __shared__ __attribute__((aligned(16))) float dsrow[4][NIN];
+    float* Wt = buf;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
+    for (int i = threadIdx.x; i < D * D; i += 256) {
+        const int k = i / D, c = i % D;
+        Wt[c * (D + 4) + k] = Wsrc[(int64_t)(k + 1) * D + c];
+        Wt[(D + c) * (D + 4) + k] = Wtgt[(int64_t)(k + 1) * D + c];
+    }
+    for (int i = threadIdx.x; i < D * NLP; i += 256) {
+        const int k = i / NLP, c = i % NLP;
+        Wt[(2 * D + c) * (D + 4) + k] = c < nl ? Wlog[(int64_t)(k + 1) * nl + c] : 0.f;
+    }
+    __syncthreads();
+    const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_l = 4 * q < NLP;
+    float* dr = dsrow[wave];
+    float acc_s[4][NS], acc_t[4][NS], acc_l[4][NSL];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { acc_s[a][i] = 0.f; acc_t[a][i] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) acc_l[a][i] = 0.f;
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cs_s = zero4, cs_t = zero4, cs_l = zero4, dg = zero4, db = zero4;
+    for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {
+        const int64_t o = (int64_t)row * D + 4 * q;
+        const float4 gs = ld4(dPs + o), gt = ld4(dPt + o);
+        const float4 gl = has_l ? load_logit4(dA2 + (int64_t)row * nl, 4 * q, nl) : zero4;
+        const float4 x = lc_load4(xin, o);
+        if (s == 0) {
+            *reinterpret_cast<float4*>(dr + 4 * q) = gs;
+            *reinterpret_cast<float4*>(dr + D + 4 * q) = gt;
+            if (has_l) *reinterpret_cast<float4*>(dr + 2 * D + 4 * q) = gl;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dxn[4q ..] = sum_c g_c W(1 + 4q .., c): this sub-group's share of the 2 D + NLP columns
+        float4 dy = zero4;
+        for (int c = s; c < NIN; c += SG) fma4(dy, dr[c], *reinterpret_cast<const float4*>(Wt + c * (D + 4) + 4 * q));
+        xor_combine4(dy, LPR);
+        float4 xh;
+        const float4 dx = gn_backward4<CG>(x, dy, gm, eps, xh);
+        const float4 xn = gn_forward_v<CG>(x, eps, gm, bt);
+        if (s == 0) {
+            float4 out = make_float4(out_scale * dx.x, out_scale * dx.y, out_scale * dx.z, out_scale * dx.w);
+            if (pre.n > 0) add4(out, lc_load4(pre, o));
+            *reinterpret_cast<float4*>(ka + o) = out;
+            dg.x += dy.x * xh.x; dg.y += dy.y * xh.y; dg.z += dy.z * xh.z; dg.w += dy.w * xh.w;
+            add4(db, dy);
+            add4(cs_s, gs); add4(cs_t, gt); add4(cs_l, gl);
+        }
+        // weight gradients: lane (q, s) owns rows 1 + 4q .. 4q + 4 of the three blocks and columns s NS .. (s NSL ..)
+        const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const float a_s = dr[s * NS + i], a_t = dr[D + s * NS + i];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { acc_s[a][i] = fmaf(xv[a], a_s, acc_s[a][i]); acc_t[a][i] = fmaf(xv[a], a_t, acc_t[a][i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int c = s * NSL + i;
+            const float a_l = c < NLP ? dr[2 * D + c] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc_l[a][i] = fmaf(xv[a], a_l, acc_l[a][i]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();                                             // every wave is done with Wt: the storage becomes the partial
+    float* red = buf;
+    const int oL = 2 * nW, oG = oL + (D + 1) * nl, oB = oG + D, oT = oB + D, plen = oT + 1;
+    for (int w = 0; w < 4; ++w) {                                // the four waves add in wave order (deterministic)
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int idx = (1 + 4 * q + a) * D + s * NS + i;
+                    red[idx] = (w == 0 ? 0.f : red[idx]) + acc_s[a][i];
+                    red[nW + idx] = (w == 0 ? 0.f : red[nW + idx]) + acc_t[a][i];
+                }
+#pragma unroll
+                for (int i = 0; i < NSL; ++i) {
+                    const int c = s * NSL + i;
+                    if (c < nl) {
+                        const int idx = oL + (1 + 4 * q + a) * nl + c;
+                        red[idx] = (w == 0 ? 0.f : red[idx]) + acc_l[a][i];
+                    }
+                }
+            }
+            if (s == 0) {
+                const float c4[4][4] = {{cs_s.x, cs_s.y, cs_s.z, cs_s.w}, {cs_t.x, cs_t.y, cs_t.z, cs_t.w},
+                                        {dg.x, dg.y, dg.z, dg.w}, {db.x, db.y, db.z, db.w}};
+                const int base[4] = {0, nW, oG, oB};
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int idx = base[v] + 4 * q + a;
+                        red[idx] = (w == 0 ? 0.f : red[idx]) + c4[v][a];
+                    }
+                if (has_l) {
+                    const float cl[4] = {cs_l.x, cs_l.y, cs_l.z, cs_l.w};
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        if (4 * q + a < nl) {
+                            const int idx = oL + 4 * q + a;
+                            red[idx] = (w == 0 ? 0.f : red[idx]) + cl[a];
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {                                             // the block's share of a_t' = colsums . time rows of the weights
+        float v = 0.f;
+        for (int c = l; c < 2 * D + nl; c += 64) {
+            const float cs = c < D ? red[c] : (c < 2 * D ? red[nW + c - D] : red[oL + c - 2 * D]);
+            const float w0 = c < D ? Wsrc[c] : (c < 2 * D ? Wtgt[c - D] : Wlog[c - 2 * D]);
+            v = fmaf(cs, w0, v);
+        }
+        v = wave_sum(v);
+        if (l == 0) red[oT] = v;
+    }
+    __syncthreads();
+    float* out = part + (int64_t)blockIdx.x * plen;
+    for (int i = threadIdx.x; i < plen; i += 256) out[i] = red[i];
+}
+
+// k_theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta] (time rows scaled by t) and k_a_t from the block partials:
+// 1 024 threads = 32 part-groups x 32 outputs, 16 loads per thread in flight together (512 partial rows: one round).
+struct GatFinish {
+    const float* part; int n_part, plen, d, nl, heads, out_len;
+    float t; float* ktheta; float* kat;
+};
+__global__ __launch_bounds__(1024) void gat_small_finish_kernel(GatFinish g)
+{
+    __shared__ float sm[32][33];
+    const int jj = threadIdx.x & 31, qq = threadIdx.x >> 5;
+    const int j = (int)blockIdx.x * 32 + jj;
+    const int d = g.d, nW = (d + 1) * d, nL = (d + 1) * g.nl;
+    const int oBf = 2 * nW + nL, oBw = oBf + d, oGm = oBw + g.heads;     // theta offsets; gamma, beta are contiguous in both
+    int src = -1; float scale = 1.f;
+    if (j < g.out_len) {
+        if (j < 2 * nW) { src = j; if (j % nW < d) scale = g.t; }
+        else if (j < oBf) { src = j; if (j - 2 * nW < g.nl) scale = g.t; }
+        else if (j < oBw) src = nW + (j - oBf);                          // bf = colsum(dPt): the time row of the Wtgt block
+        else if (j < oGm) src = 2 * nW + 2 * (j - oBw) + 1;              // bw_h = colsum(dA2)[2h + 1]
+        else src = 2 * nW + nL + (j - oGm);                             // dgamma | dbeta
+    } else if (j == g.out_len) src = g.plen - 1;                         // a_t'
+    float v = 0.f;
+    if (src >= 0) {
+        for (int p0 = qq; p0 < g.n_part; p0 += 32 * 16) {       // 16 independent loads in flight per thread
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = p0 + 32 * u;
+                x[u] = p < g.n_part ? g.part[(int64_t)p * g.plen + src] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v += x[u];
+        }
+    }
+    sm[qq][jj] = v;
+    __syncthreads();
+    if (qq == 0 && src >= 0) {
+        float tsum = sm[0][jj];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) tsum += sm[k][jj];
+        if (j < g.out_len) g.ktheta[j] = scale * tsum;
+        else *g.kat = tsum;
+    }
+}
+
+int gat_small_cg(int64_t d, int32_t groups) {
+    if (d != 16 && d != 32 && d != 64) return -1;
+    if (groups <= 0 || d % groups) return -1;
+    const int64_t cg = d / groups;
+    return (cg == 1 || cg == 2 || cg == 4) ? (int)cg : -1;
+}
+
+int64_t project_blocks(int64_t n) { int64_t b = (n + 3) / 4; if (b < 1) b = 1; if (b > 1024) b = 1024; return b; }
+
+}  // namespace
+
+extern "C" int gode_gat_small_supported(int64_t n_rows, int64_t d, int32_t groups, int64_t heads) {
+    if (heads < 1) heads = 1;
+    return n_rows > 0 && n_rows <= 65536 && heads <= 8 && d % heads == 0 && gat_small_cg(d, groups) > 0;
+}
+extern "C" int64_t gode_gat_small_parts(int64_t n_rows) {
+    int64_t b = (n_rows + 3) / 4;
+    if (b < 1) b = 1;
+    if (b > kGatPartBlocks) b = kGatPartBlocks;
+    return b;
+}
+extern "C" int64_t gode_gat_small_part_len(int64_t d, int64_t heads) {
+    if (heads < 1) heads = 1;
+    return 2 * (d + 1) * d + (d + 1) * 2 * heads + 2 * d + 1;
+}
+
+#define GODE_GATS_DISPATCH(MACRO)                                                                                   \
+    if (nlp == 4) {                                                                                                  \
+        if (d == 16 && cg == 1) { MACRO(16, 1, 4) } else if (d == 16 && cg == 2) { MACRO(16, 2, 4) } else if (d == 16 && cg == 4) { MACRO(16, 4, 4) } \
+        else if (d == 32 && cg == 1) { MACRO(32, 1, 4) } else if (d == 32 && cg == 2) { MACRO(32, 2, 4) } else if (d == 32 && cg == 4) { MACRO(32, 4, 4) } \
+        else if (d == 64 && cg == 1) { MACRO(64, 1, 4) } else if (d == 64 && cg == 2) { MACRO(64, 2, 4) } else if (d == 64 && cg == 4) { MACRO(64, 4, 4) } \
+    } else {                                                                                                         \
+        if (d == 16 && cg == 1) { MACRO(16, 1, 16) } else if (d == 16 && cg == 2) { MACRO(16, 2, 16) } else if (d == 16 && cg == 4) { MACRO(16, 4, 16) } \
+        else if (d == 32 && cg == 1) { MACRO(32, 1, 16) } else if (d == 32 && cg == 2) { MACRO(32, 2, 16) } else if (d == 32 && cg == 4) { MACRO(32, 4, 16) } \
+        else if (d == 64 && cg == 1) { MACRO(64, 1, 16) } else if (d == 64 && cg == 2) { MACRO(64, 2, 16) } else if (d == 64 && cg == 4) { MACRO(64, 4, 16) } \
+    }
+
+extern "C" int gode_gat_project_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                                          const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
+                                          const float* Wlog, int64_t heads, const float* pt_bias, float t, float* Ps,
+                                          float* Pt, float* A2, float* x_out, void* stream)
+{
+    if (heads < 1) heads = 1;
+    if (!xin || !Wsrc || !Wtgt || !Wlog || !Ps || !Pt || !A2) return GODE_E_NULLPTR;
+    if (!gode_gat_small_supported(n_rows, d, groups, heads)) return GODE_E_UNSUPPORTED;
+    int rc = check_lincomb(xin, true); if (rc) return rc;
+    if (!lincomb_aligned16(xin) || ((((uintptr_t)Ps) | ((uintptr_t)Pt) | ((uintptr_t)x_out) | ((uintptr_t)gamma) | ((uintptr_t)beta) |
+                                     ((uintptr_t)pt_bias)) & 15)) return GODE_E_ALIGN;
+    const LinComb lx = make_lincomb(xin);
+    const int cg = gat_small_cg(d, groups);
+    const int nl = (int)(2 * heads), nlp = nl <= 4 ? 4 : 16;
+    const dim3 grid((unsigned)project_blocks(n_rows));
+#define GODE_GPJ(DV, CGV, NLV) hipLaunchKernelGGL((gat_project_small_kernel<DV, CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                                  lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, pt_bias, t, Ps, Pt, A2, x_out);
+    GODE_GATS_DISPATCH(GODE_GPJ)
+#undef GODE_GPJ
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                                            const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
+                                            const float* Wlog, int64_t heads, const float* dPs, const float* dPt,
+                                            const float* dA2, float out_scale, const gode_lincomb_t* pre, float* ka,
+                                            float* part, void* stream)
+{
+    if (heads < 1) heads = 1;
+    if (!xin || !Wsrc || !Wtgt || !Wlog || !dPs || !dPt || !dA2 || !ka || !part) return GODE_E_NULLPTR;
+    if (!gode_gat_small_supported(n_rows, d, groups, heads)) return GODE_E_UNSUPPORTED;
+    int rc = check_lincomb(xin, true); if (rc) return rc;
+    if (pre && pre->n > 0) { rc = check_lincomb(pre, true); if (rc) return rc; } else pre = nullptr;
+    if (!lincomb_aligned16(xin) || !lincomb_aligned16(pre) ||
+        ((((uintptr_t)dPs) | ((uintptr_t)dPt) | ((uintptr_t)ka) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15)) return GODE_E_ALIGN;
+    const LinComb lx = make_lincomb(xin), lp = make_lincomb(pre);
+    const int cg = gat_small_cg(d, groups);
+    const int nl = (int)(2 * heads), nlp = nl <= 4 ? 4 : 16;
+    const dim3 grid((unsigned)gode_gat_small_parts(n_rows));
+#define GODE_GVJ(DV, CGV, NLV) hipLaunchKernelGGL((gat_dense_vjp_small_kernel<DV, CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                                  lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, dPs, dPt, dA2, out_scale, lp, ka, part);
+    GODE_GATS_DISPATCH(GODE_GVJ)
+#undef GODE_GVJ
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_gat_small_finish_f32(const float* part, int64_t n_rows, int64_t d, int64_t heads, float t, float* ktheta,
+                                         float* kat, void* stream)
+{
+    if (heads < 1) heads = 1;
+    if (!part || !ktheta || !kat) return GODE_E_NULLPTR;
+    if (n_rows <= 0 || n_rows > 65536 || d <= 0 || heads > 8) return GODE_E_SHAPE;
+    GatFinish g;
+    g.part = part; g.n_part = (int)gode_gat_small_parts(n_rows); g.plen = (int)gode_gat_small_part_len(d, heads);
+    g.d = (int)d; g.nl = (int)(2 * heads); g.heads = (int)heads;
+    g.out_len = (int)(2 * (d + 1) * d + (d + 1) * 2 * heads + d + heads + 2 * d);
+    g.t = t; g.ktheta = ktheta; g.kat = kat;
+    const int blocks = (g.out_len + 1 + 31) / 32;
+    hipLaunchKernelGGL(gat_small_finish_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, g);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}

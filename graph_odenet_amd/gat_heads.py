@@ -219,6 +219,9 @@ class _HeadsWork:
         self.colsum_scratch = torch.empty(max(lib.gode_colsum_scratch_bytes(n, d), 16), **u8)
         self.colsum_scratch2 = torch.empty(max(lib.gode_colsum_scratch_bytes(n, 2 * H), 16), **u8)
         self.err_scratch = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), **u8)
+        self.small_part = None
+        if not spec.pad_logits and lib.gode_gat_small_supported(n, d, spec.groups, H):
+            self.small_part = ops.gat_small_part(n, d, H, device)
         if spec.pad_logits:
             self.A2pad, self.dA2pad = torch.empty(n, d, **f), torch.zeros(n, d, **f)     # columns >= 2H of dA2pad stay 0
             self.wp[2] = torch.empty(npw, spec.i * d, **f)
@@ -233,6 +236,7 @@ class GatHeadsField(GatOdeField):
 
     def __init__(self, spec, work):
         self.s, self.w = spec, work
+        self.heads = spec.heads
         self.token = ("gat-heads", id(spec.eg))
 
     @property
@@ -271,14 +275,19 @@ class GatHeadsField(GatOdeField):
             for j in range(3):
                 ws.wp[j] = w.wp[j].data_ptr()
             ws.maxpath_scratch = p(w.heads_scratch)
+            ws.small_part = p(w.small_part)
         return fs, ws
 
     def _project(self, t, y_terms):
         s, w = self.s, self.w
         x_out = w.X if len(y_terms) > 1 else None
+        terms = [(1.0, w.X)] if x_out is not None else y_terms
+        if self.small():
+            ops.gat_project_small(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, s.heads, s.bf, t,
+                                  w.Ps, w.Pt, w.A2, x_out=x_out)
+            return terms
         ops.gn_time_gemm_pair(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, True, t, w.Ps, w.Pt,
                               x_out=x_out)
-        terms = [(1.0, w.X)] if x_out is not None else y_terms
         if s.pad_logits:
             ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog_pad, True, t, out=w.A2pad)
             w.A2.copy_(w.A2pad[:, :2 * s.heads])
@@ -330,6 +339,11 @@ class GatHeadsAdjointField(GatHeadsField):
         g = s.views(out[3])
         ops.gat_vjp(eg, w.proj, o, w.bf0, w.a, w.zero, w.wgt, w.den, out[0].view(nv, o), w.dz, w.da, w.dPs.view(nv, o),
                     w.dPt.view(nv, o), w.dA2.view(nv, 2), cot_terms=terms[1], cot_scale=-1.0, heads=H)
+        if self.small():
+            ops.gat_dense_vjp_small(xt, n, d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, H, w.dPs, w.dPt, w.dA2,
+                                    out[1], w.small_part)
+            ops.gat_small_finish(w.small_part, n, d, H, t, out[3], out[2])
+            return
         from .gat_ode import MERGED_FINISH_MAX_ROWS
         merged = n <= MERGED_FINISH_MAX_ROWS and s.groups > 0 and not s.pad_logits      # one reduction launch per stage
         if merged:

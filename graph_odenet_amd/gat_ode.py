@@ -101,6 +101,8 @@ class _Work:
         self.colsum_scratch = torch.empty(max(lib.gode_colsum_scratch_bytes(n, o), 16), **u8)
         self.colsum_scratch2 = torch.empty(max(lib.gode_colsum_scratch_bytes(n, 2), 16), **u8)
         self.err_scratch = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), **u8)
+        # launch-bound graphs: block partials of the one-launch dense VJP (csrc/gat_small.hip)
+        self.small_part = ops.gat_small_part(n, o, 1, device) if lib.gode_gat_small_supported(n, o, spec.groups, 1) else None
 
 
 class GatOdeField(Field):
@@ -111,8 +113,14 @@ class GatOdeField(Field):
         self.s, self.w = spec, work
         self.token = ("gat", id(spec.eg))
 
+    heads = 1
+
     def prepare(self):
         self.s.refresh()
+
+    def small(self):
+        """The dense half runs on the one-launch kernels of csrc/gat_small.hip (launch-bound graphs; option small_fused)."""
+        return self.w.small_part is not None and ops.gat_small_supported(self.s.n, self.s.d, self.s.groups, self.heads)
 
     # ---- one adaptive step per C call (csrc/gat_driver.hip) -------------------------------------------------------
     def _structs(self, adjoint):
@@ -143,6 +151,7 @@ class GatOdeField(Field):
             for j in range(3):
                 ws.wp[j] = w.wp[j].data_ptr()
             ws.maxpath_scratch = p(eg.maxpath_scratch())
+            ws.small_part = p(w.small_part)
         return fs, ws
 
     def dopri5_step_native(self, y, kk, y1, t, h, rtol, atol):
@@ -160,9 +169,13 @@ class GatOdeField(Field):
         """Ps, Pt, A2 of the stage input; returns the term list later launches of the stage should read."""
         s, w = self.s, self.w
         x_out = w.X if len(y_terms) > 1 else None
+        terms = [(1.0, w.X)] if x_out is not None else y_terms
+        if self.small():
+            ops.gat_project_small(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, 1, None, t,
+                                  w.Ps, w.Pt, w.A2, x_out=x_out)
+            return terms
         ops.gn_time_gemm_pair(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, True, t, w.Ps, w.Pt,
                               x_out=x_out)
-        terms = [(1.0, w.X)] if x_out is not None else y_terms
         ops.gn_time_gemm(terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wlog, True, t, out=w.A2)
         return terms
 
@@ -221,6 +234,12 @@ class GatOdeAdjointField(GatOdeField):
         # cotangent -a of the VJP, masked by the outer relu, is formed inside the kernel
         ops.gat_vjp(eg, w.proj, o, s.bf, w.a, w.amax, w.wgt, w.den, out[0], w.dz, w.da, w.dPs, w.dPt, w.dA2,
                     cot_terms=terms[1], cot_scale=-1.0)
+        if self.small():
+            # launch-bound graphs: k_a and the partials of every parameter gradient in one launch, one more to close
+            ops.gat_dense_vjp_small(xt, n, o, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, 1, w.dPs, w.dPt, w.dA2,
+                                    out[1], w.small_part)
+            ops.gat_small_finish(w.small_part, n, o, 1, t, out[3], out[2])
+            return
         # bias gradients: sum over edges of dz / da = sum over nodes of the per-target sums just formed (every edge has
         # exactly one target) - N rows instead of E
         merged = n <= MERGED_FINISH_MAX_ROWS and s.groups > 0        # launch-bound: ONE reduction launch closes the stage

@@ -188,6 +188,72 @@ def gn_time_gemm_pair(x_terms, n_rows, d, groups, eps, gamma, beta, Wa, Wb, has_
           "gode_gn_time_gemm_pair_f32")
 
 
+def gat_small_supported(n_rows, d, groups, heads=1):
+    """The one-launch dense kernels of csrc/gat_small.hip cover this shape (and the option small_fused is on)."""
+    lib = _lib.load()
+    return bool(lib.gode_get_option(b"small_fused")) and bool(lib.gode_gat_small_supported(n_rows, d, groups, heads))
+
+
+def gat_small_part(n_rows, d, heads, device):
+    lib = _lib.load()
+    return torch.empty(lib.gode_gat_small_parts(n_rows), lib.gode_gat_small_part_len(d, heads), dtype=torch.float32, device=device)
+
+
+def gat_project_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, Wlog, heads, pt_bias, t, Ps, Pt, A2, x_out=None):
+    """Ps, Pt (+ pt_bias), A2 = [t | GN(x)] @ [Wsrc | Wtgt | Wlog] in one launch (x = sum of x_terms, written to x_out)."""
+    lib = _lib.load()
+    for tns, nm in ((gamma, "gamma"), (beta, "beta"), (Wsrc, "Wsrc"), (Wtgt, "Wtgt"), (Wlog, "Wlog"), (pt_bias, "pt_bias"),
+                    (Ps, "Ps"), (Pt, "Pt"), (A2, "A2"), (x_out, "x_out")):
+        _need(tns, nm)
+    if _need_terms(x_terms, "x") != n_rows * d:
+        raise ValueError("gat_project_small: x terms have wrong size")
+    if tuple(Wsrc.shape) != (d + 1, d) or tuple(Wtgt.shape) != (d + 1, d) or tuple(Wlog.shape) != (d + 1, 2 * heads):
+        raise ValueError("gat_project_small: weights must be (d+1) x d, (d+1) x d, (d+1) x 2H")
+    if Ps.numel() != n_rows * d or Pt.numel() != n_rows * d or A2.numel() != n_rows * 2 * heads or \
+            (x_out is not None and x_out.numel() != n_rows * d) or (pt_bias is not None and pt_bias.numel() != d):
+        raise ValueError("gat_project_small: output buffers have wrong size")
+    lc = lincomb(x_terms)
+    check(lib.gode_gat_project_small_f32(ctypes.byref(lc), n_rows, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(Wsrc), ptr(Wtgt),
+                                         ptr(Wlog), heads, ptr(pt_bias), float(t), ptr(Ps), ptr(Pt), ptr(A2), ptr(x_out),
+                                         stream_ptr()), "gode_gat_project_small_f32")
+
+
+def gat_dense_vjp_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, Wlog, heads, dPs, dPt, dA2, ka, part,
+                        out_scale=1.0, pre_terms=None):
+    """k_a and the block partials of every parameter gradient of a GAT adjoint stage in one launch (csrc/gat_small.hip)."""
+    lib = _lib.load()
+    for tns, nm in ((gamma, "gamma"), (beta, "beta"), (Wsrc, "Wsrc"), (Wtgt, "Wtgt"), (Wlog, "Wlog"), (dPs, "dPs"), (dPt, "dPt"),
+                    (dA2, "dA2"), (ka, "ka"), (part, "part")):
+        _need(tns, nm)
+    if _need_terms(x_terms, "x") != n_rows * d:
+        raise ValueError("gat_dense_vjp_small: x terms have wrong size")
+    if tuple(Wsrc.shape) != (d + 1, d) or tuple(Wtgt.shape) != (d + 1, d) or tuple(Wlog.shape) != (d + 1, 2 * heads):
+        raise ValueError("gat_dense_vjp_small: weights must be (d+1) x d, (d+1) x d, (d+1) x 2H")
+    if dPs.numel() != n_rows * d or dPt.numel() != n_rows * d or dA2.numel() != n_rows * 2 * heads or ka.numel() != n_rows * d or \
+            part.numel() != lib.gode_gat_small_parts(n_rows) * lib.gode_gat_small_part_len(d, heads):
+        raise ValueError("gat_dense_vjp_small: buffers have wrong size")
+    lc = lincomb(x_terms)
+    pre = None
+    if pre_terms:
+        if _need_terms(pre_terms, "pre") != n_rows * d:
+            raise ValueError("gat_dense_vjp_small: pre terms have wrong size")
+        pre = lincomb(pre_terms)
+    check(lib.gode_gat_dense_vjp_small_f32(ctypes.byref(lc), n_rows, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(Wsrc), ptr(Wtgt),
+                                           ptr(Wlog), heads, ptr(dPs), ptr(dPt), ptr(dA2), float(out_scale),
+                                           ctypes.byref(pre) if pre is not None else None, ptr(ka), ptr(part), stream_ptr()),
+          "gode_gat_dense_vjp_small_f32")
+
+
+def gat_small_finish(part, n_rows, d, heads, t, ktheta, kat):
+    lib = _lib.load()
+    _need(part, "part"); _need(ktheta, "ktheta"); _need(kat, "kat")
+    if part.numel() != lib.gode_gat_small_parts(n_rows) * lib.gode_gat_small_part_len(d, heads) or \
+            ktheta.numel() != lib.gode_gat_ode_theta_len_heads(d, heads) or kat.numel() != 1:
+        raise ValueError("gat_small_finish: buffers have wrong size")
+    check(lib.gode_gat_small_finish_f32(ptr(part), n_rows, d, heads, float(t), ptr(ktheta), ptr(kat), stream_ptr()),
+          "gode_gat_small_finish_f32")
+
+
 def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS, out_scale=1.0, out=None,
                      want_affine_grads=True, pre_terms=None, parts=None):
     """Returns (dx, dgamma_part, dbeta_part); parts are [n_part, d_in] block partials (or None).

@@ -480,7 +480,36 @@ typedef struct gode_gat_workspace {
     /* second column-sum scratch (gode_colsum_scratch_bytes(n, 2 * max(heads, 1))): with it, and up to 65 536 rows, the
      * reductions that close an adjoint stage run as one launch (gode_reduce_segments_f32); NULL: separate launches */
     void* colsum_scratch2;
+    /* nullable: gode_gat_small_parts(n) * gode_gat_small_part_len(d, heads) floats - with it, and where
+     * gode_gat_small_supported, the dense half of a stage runs on the one-launch kernels below */
+    float* small_part;
 } gode_gat_workspace_t;
+
+/* ---- GAT ODE function on launch-bound graphs: the row-local half of an evaluation / of an adjoint stage as ONE launch
+ * each (csrc/gat_small.hip).  Replaces, for n <= 65 536 nodes, d in {16, 32, 64}, 1 / 2 / 4 channels per GroupNorm group
+ * and up to 8 heads, the node-level forms of `self.f` and `self.w` of GAT/layers.py:43,45 (Wsrc, Wtgt: (d+1) x d, Wlog:
+ * (d+1) x 2H, row 0 = the time column's weights; see gode_gat_odefunc_t) and their autograd:
+ *   project    Ps = [t|GN(x)] Wsrc, Pt = [t|GN(x)] Wtgt (+ pt_bias, nullable: d floats), A2 = [t|GN(x)] Wlog (n x 2H);
+ *              x = sum of the terms of `xin`, also written to x_out when given
+ *   dense_vjp  ka = out_scale * GN'(x)^T (dPs Wsrc[1:]^T + dPt Wtgt[1:]^T + dA2 Wlog[1:]^T) + sum pre, and one partial row
+ *              per block in `part`: [ dWsrc | dWtgt | dWlog (row 0 of each = the column sums of dPs / dPt / dA2) | dgamma |
+ *              dbeta | colsums . time rows of the weights ]
+ *   finish     ktheta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta] (gode_gat_ode_theta_len_heads floats; time rows * t,
+ *              bf = colsum(dPt), bw_h = colsum(dA2)[2h+1]) and *kat = the a_t derivative, from the partials (fixed order:
+ *              deterministic) */
+int     gode_gat_small_supported(int64_t n_rows, int64_t d, int32_t groups, int64_t heads);
+int64_t gode_gat_small_parts(int64_t n_rows);
+int64_t gode_gat_small_part_len(int64_t d, int64_t heads);
+int gode_gat_project_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                               const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
+                               const float* Wlog, int64_t heads, const float* pt_bias, float t, float* Ps, float* Pt,
+                               float* A2, float* x_out, void* stream);
+int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
+                                 const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
+                                 const float* Wlog, int64_t heads, const float* dPs, const float* dPt, const float* dA2,
+                                 float out_scale, const gode_lincomb_t* pre, float* ka, float* part, void* stream);
+int gode_gat_small_finish_f32(const float* part, int64_t n_rows, int64_t d, int64_t heads, float t, float* ktheta,
+                              float* kat, void* stream);
 
 int64_t gode_gat_ode_theta_len(int64_t d);
 int64_t gode_gat_ode_theta_len_heads(int64_t d, int64_t heads);

@@ -414,3 +414,111 @@ def test_native_dopri5_step_for_heads_matches_python_driver(golden, d, H):
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for a, b in zip(res[True][2], res[False][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n", [1, 37, 3327])
+@pytest.mark.parametrize("d,H", [(16, 1), (32, 1), (64, 1), (16, 2), (32, 4), (64, 8), (16, 8), (64, 3)])
+def test_one_launch_dense_half_vs_float64_autograd(n, d, H):
+    """csrc/gat_small.hip (launch-bound graphs): the node-level products of GAT/layers.py:43,45 behind GroupNorm and the
+    time column (GAT/models.py:175-177) as ONE launch - Ps, Pt (+ per-head bias), A2 - and their whole autograd as one
+    launch plus the closing reduction: k_a, dWsrc, dWtgt, dWlog (time rows scaled by t), bf = colsum(dPt), bw = odd
+    columns of colsum(dA2), dgamma, dbeta, and a_t' = colsums . time rows.  Against float64 autograd; a multi-term stage
+    input is combined in the kernel and written out."""
+    from graph_odenet_amd import ops
+    if not ops.gat_small_supported(n, d, min(32, d), H):
+        pytest.skip("shape outside the one-launch kernels")
+    g = torch.Generator().manual_seed(n + 7 * d + H)
+    groups, eps, t = min(32, d), 1e-5, 0.37
+    xa, xb = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)
+    terms = [(1.0, xa), (0.25, xb)]
+    gamma, beta = 1 + 0.3 * torch.randn(d, generator=g), 0.3 * torch.randn(d, generator=g)
+    Wsrc, Wtgt = torch.randn(d + 1, d, generator=g) / d ** 0.5, torch.randn(d + 1, d, generator=g) / d ** 0.5
+    Wlog, bf = torch.randn(d + 1, 2 * H, generator=g) / d ** 0.5, torch.randn(d, generator=g)
+    dPs, dPt, dA2 = torch.randn(n, d, generator=g), torch.randn(n, d, generator=g), torch.randn(n, 2 * H, generator=g)
+    pre = torch.randn(n, d, generator=g)
+    # float64 reference
+    P = [v.double().requires_grad_(True) for v in (xa + 0.25 * xb, gamma, beta, Wsrc, Wtgt, Wlog)]
+    x64, g64, b64, ws64, wt64, wl64 = P
+    xg = x64.view(n, groups, d // groups)                         # GroupNorm(groups, d) on n x d (GAT/models.py:165,175)
+    xn = ((xg - xg.mean(2, keepdim=True)) / torch.sqrt(xg.var(2, unbiased=False, keepdim=True) + eps)).reshape(n, d) * g64 + b64
+    ttx = torch.cat([torch.full((n, 1), t, dtype=torch.float64), xn], 1)
+    rPs, rPt, rA2 = ttx @ ws64, ttx @ wt64 + bf.double(), ttx @ wl64
+    ((rPs * dPs.double()).sum() + (rPt * dPt.double()).sum() + (rA2 * dA2.double()).sum()).backward()
+    D = dev()
+    f = dict(dtype=torch.float32, device=D)
+    dt = [(c, v.to(D)) for c, v in terms]
+    Ps, Pt, A2, X = torch.empty(n, d, **f), torch.empty(n, d, **f), torch.empty(n, 2 * H, **f), torch.empty(n, d, **f)
+    ops.gat_project_small(dt, n, d, groups, eps, gamma.to(D), beta.to(D), Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H, bf.to(D), t, Ps, Pt, A2,
+                          x_out=X)
+    assert torch.equal(X.cpu(), torch.addcmul(xa, xb, torch.tensor(0.25))) or (X.cpu() - (xa + 0.25 * xb)).abs().max().item() <= 1e-6
+    # conditioning (SURVEY.md Q4/H5, as tests/test_gpu_kernels.py::test_gn_time_gemm_fwd_bwd_wgrad): one channel per group
+    # -> GroupNorm returns beta + rounding noise * 316 and its x-gradient is 0 in real arithmetic; two channels per group
+    # -> rstd reaches 316 on rows whose two values nearly coincide
+    cg = d // groups
+    ftol, xtol, wtol = {1: (2e-4, 2e-3, 2e-4), 2: (2e-5, 1e-4, 2e-5)}.get(cg, (3e-6, 2e-5, 4e-6))
+    for got, ref, nm in ((Ps, rPs, "Ps"), (Pt, rPt, "Pt"), (A2, rA2, "A2")):
+        assert (got.cpu().double() - ref.detach()).abs().max().item() <= ftol * max(1.0, ref.abs().max().item()), nm
+    part = ops.gat_small_part(n, d, H, D)
+    part.fill_(float("nan"))                                   # every entry that is read must have been written
+    ka = torch.empty(n, d, **f)
+    ops.gat_dense_vjp_small([(1.0, X)], n, d, groups, eps, gamma.to(D), beta.to(D), Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H,
+                            dPs.to(D), dPt.to(D), dA2.to(D), ka, part, out_scale=-0.5, pre_terms=[(2.0, pre.to(D))])
+    want_ka = -0.5 * x64.grad + 2.0 * pre.double()
+    assert (ka.cpu().double() - want_ka).abs().max().item() <= xtol * max(1.0, want_ka.abs().max().item())
+    nth = 2 * (d + 1) * d + (d + 1) * 2 * H + d + H + 2 * d
+    kth, kat = torch.full((nth,), float("nan"), **f), torch.full((1,), float("nan"), **f)
+    ops.gat_small_finish(part, n, d, H, t, kth, kat)
+    nW, nL = (d + 1) * d, (d + 1) * 2 * H
+    cs = [dPs.double().sum(0), dPt.double().sum(0), dA2.double().sum(0)]
+    want = torch.cat([ws64.grad.reshape(-1), wt64.grad.reshape(-1), wl64.grad.reshape(-1), cs[1], cs[2][1::2], g64.grad, b64.grad])
+    got = kth.cpu().double()
+    assert got.shape == want.shape
+    i_gamma = 2 * nW + nL + d + H                          # dgamma multiplies the cotangent by the normalised (noisy) value
+    for lo, hi, tol, nm in ((0, i_gamma, wtol, "weights and biases"), (i_gamma, i_gamma + d, 2e-3 if cg == 1 else 2e-5, "dgamma"),
+                            (i_gamma + d, nth, 2e-5, "dbeta")):
+        scale = max(1.0, want[lo:hi].abs().max().item())
+        bad = (got[lo:hi] - want[lo:hi]).abs().max().item()
+        assert bad <= tol * scale * max(1.0, n ** 0.5), (nm, bad, scale)
+    want_at = (cs[0] * Wsrc[0].double()).sum() + (cs[1] * Wtgt[0].double()).sum() + (cs[2] * Wlog[0].double()).sum()
+    assert abs(kat.item() - want_at.item()) <= 4e-6 * max(1.0, abs(want_at.item())) * max(1.0, n ** 0.5)
+
+
+@pytest.mark.parametrize("heads,d", [(1, 16), (1, 64), (8, 64), (4, 32)])
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_one_launch_dense_half_matches_multi_launch_path(golden, heads, d, method):
+    """The same ODE block with the option small_fused off (three products, three VJPs, three weight-gradient launches,
+    two column sums per stage) and on (csrc/gat_small.hip), on Citeseer's edge list: forward and every parameter gradient."""
+    from graph_odenet_amd import _lib, gat_heads, gat_models
+    from graph_odenet_amd.models import ODEBlock
+    lib = _lib.load()
+    n, src, tgt, Mtgt = _citeseer(golden)
+    D = dev()
+    src, tgt, Mtgt = src.to(D), tgt.to(D), Mtgt.to(D)
+    x0 = (torch.randn(n, d, generator=torch.Generator().manual_seed(3)) * 0.5).to(D)
+    gout = torch.randn(n, d, generator=torch.Generator().manual_seed(4)).to(D)
+    res = {}
+    try:
+        for fused in (0, 1):
+            lib.gode_set_option(b"small_fused", fused)
+            torch.manual_seed(9)
+            fn = gat_models.ODEfunc(d) if heads == 1 else gat_heads.ODEfunc(d, heads)
+            kw = dict(method="rk4", step_size=0.25) if method == "rk4" else dict(method="dopri5", tol=1e-5)
+            blk = ODEBlock(fn, **kw).to(D)
+            xg = x0.clone().requires_grad_(True)
+            out = blk(xg, src, tgt, Mtgt)
+            out.backward(gout)
+            res[fused] = (out.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in blk.parameters()])
+    finally:
+        lib.gode_set_option(b"small_fused", 1)
+    ftol = 1e-5 if method == "rk4" else 1e-4
+    gtol = 1e-4 if method == "rk4" else 5e-3            # adaptive: accept / reject decisions move with rounding
+    if d == 64:
+        # two channels per GroupNorm group: rstd reaches 316 on rows whose two values nearly coincide, and the summation
+        # order of the products (MFMA tiles vs sub-group sums) then shows at 1e-4: BOTH paths sit 2.4e-4 .. 8e-4 from the
+        # float64 oracle on this problem and 2.7e-4 .. 4e-4 from each other (tools/dev/gat_cond_probe.py,
+        # profiles/r03_gat_conditioning.txt); at d = 16 all three agree to 2e-5
+        ftol, gtol = 2e-3, 2e-2
+    close(res[1][0], res[0][0], ftol, "forward")
+    close(res[1][1], res[0][1], gtol, "dx")
+    for a, b in zip(res[1][2], res[0][2]):
+        close(a, b, gtol, "parameter gradient")

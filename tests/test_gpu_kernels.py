@@ -571,8 +571,9 @@ def test_rectangular_products_vs_float64(n, K, M):
     D = dev()
     ref = x.double() @ W.double()
     scale = ref.abs().max().item() + 1e-30
+    kt = max(1.0, (K / 256) ** 0.5)                       # fp32 accumulation over K terms
     got = ops.rect_gemm(x.to(D), W.to(D)).cpu()
-    assert got.shape == (n, M) and (got.double() - ref).abs().max().item() <= 2e-6 * scale
+    assert got.shape == (n, M) and (got.double() - ref).abs().max().item() <= 2e-6 * scale * kt
     mp = (M + 3) // 4 * 4
     gotp = ops.rect_gemm(x.to(D), W.to(D), pad_to=mp).cpu()
     assert gotp.shape == (n, mp) and torch.equal(gotp[:, :M], got) and bool((gotp[:, M:] == 0).all())
