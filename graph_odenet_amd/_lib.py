@@ -129,7 +129,7 @@ SIGNATURES = {
     "gode_adam_tick_f32": (c_i, [c_p, c_f, c_f, c_p]),
     "gode_adam_f32": (c_i, [ctypes.POINTER(AdamArgs), ctypes.c_int32, c_p, c_i64, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),
     "gode_gat_small_supported": (c_i, [c_i64, c_i64, ctypes.c_int32, c_i64]),
-    "gode_gat_small_parts": (c_i64, [c_i64]),
+    "gode_gat_small_parts": (c_i64, [c_i64, c_i64]),
     "gode_gat_small_part_len": (c_i64, [c_i64, c_i64]),
     "gode_gat_project_small_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p,
                                          c_i64, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),

@@ -267,6 +267,199 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_wave_kernel(const int* __rest
     }
 }
 
+// ---- small-graph variants with PREFETCHED INDICES ----------------------------------------------------------------
+// (o in {16, 32, 64}.)  The wave kernels above walk a row's edges a few at a time, and every trip is a chain of dependent loads
+// (eid[k] -> src[e], a[e] -> Ps[src]): Citeseer's 99-edge hub takes 25 trips of ~0.3 us and sets the kernel's duration
+// (8-10 us for 12 k edges).  Here the 64 lanes first fetch the indices and per-edge scalars of 64 CSR slots at once
+// (two load levels for the whole chunk), then LPR = o/4 lanes per edge (16 B each) gather the chunk's projection rows
+// with the indices taken from registers (__shfl): the gathers of a chunk are independent of each other and issue back
+// to back, so a hub costs about as many round trips as a leaf.
+__device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_agg_fwd_pf_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
+                                                             const float* __restrict__ val,
+                                                             const int* __restrict__ src, const int* __restrict__ tgt,
+                                                             Proj pv, const float* __restrict__ bf, const float* __restrict__ a,
+                                                             const float* __restrict__ amax, float eps, int n_rows,
+                                                             float* __restrict__ out, float* __restrict__ w_out,
+                                                             float* __restrict__ s_out) {
+    constexpr int O = 4 * LPR, NS = 64 / LPR, U = LPR < 4 ? LPR : 4;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_rows) return;
+    const int l = threadIdx.x & 63, q = l & (LPR - 1), sg = l / LPR;
+    const int b = rowptr[v], end = rowptr[v + 1];
+    const float m = amax[0];
+    const float4 bias = bf ? ldf4(bf + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cv = ldf4(pv.pt + (int64_t)v * pv.ldt + 4 * q);
+    cv.x += bias.x; cv.y += bias.y; cv.z += bias.z; cv.w += bias.w;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f;
+    for (int base = b; base < end; base += 64) {
+        const int k = base + l;
+        int sc = 0, tg = v; float we = 0.f;
+        if (k < end) {
+            const int e = eid ? eid[k] : k;
+            sc = src[e]; tg = tgt[e];
+            const float w = expf(a[e] - m);
+            w_out[e] = w;
+            we = (val ? val[k] : 1.f) * w;
+        }
+        const bool own = __all(tg == v);                       // canonical incidence: every edge of the row targets the row
+        const int cnt = end - base;
+        for (int u0 = 0; u0 < LPR; u0 += U) {
+            if (u0 * NS >= cnt) break;
+            float4 xv[U], cc[U]; float wj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = (u0 + u) * NS + sg;              // < 64; lanes beyond the row carry weight 0 and row 0
+                const int sj = __shfl(sc, j, 64), tj = __shfl(tg, j, 64);
+                wj[u] = __shfl(we, j, 64);
+                xv[u] = ldf4(pv.ps + (int64_t)sj * pv.lds + 4 * q);
+                if (own) cc[u] = cv;
+                else {
+                    cc[u] = ldf4(pv.pt + (int64_t)tj * pv.ldt + 4 * q);
+                    cc[u].x += bias.x; cc[u].y += bias.y; cc[u].z += bias.z; cc[u].w += bias.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                s += wj[u];
+                acc.x = fmaf(wj[u], fmaxf(xv[u].x + cc[u].x, 0.f), acc.x); acc.y = fmaf(wj[u], fmaxf(xv[u].y + cc[u].y, 0.f), acc.y);
+                acc.z = fmaf(wj[u], fmaxf(xv[u].z + cc[u].z, 0.f), acc.z); acc.w = fmaf(wj[u], fmaxf(xv[u].w + cc[u].w, 0.f), acc.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        s += __shfl_xor(s, off, 64);
+        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+    }
+    const float den = s + eps;
+    if (l == 0) s_out[v] = den;
+    if (sg == 0) *reinterpret_cast<float4*>(out + (int64_t)v * O + 4 * q) = make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_agg_bwd_pf_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
+                                                             const float* __restrict__ val,
+                                                             const int* __restrict__ src, const int* __restrict__ tgt,
+                                                             Proj pv, const float* __restrict__ bf, const float* __restrict__ w,
+                                                             const float* __restrict__ den, const float* __restrict__ out,
+                                                             const float* __restrict__ dout, LinComb cot, float cot_scale,
+                                                             int n_rows, float* __restrict__ dz, float* __restrict__ da) {
+    constexpr int O = 4 * LPR, NS = 64 / LPR, U = LPR < 4 ? LPR : 4;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_rows) return;
+    const int l = threadIdx.x & 63, q = l & (LPR - 1), sg = l / LPR;
+    const int b = rowptr[v], end = rowptr[v + 1];
+    const float dn = den[v];
+    const int64_t ro = (int64_t)v * O + 4 * q;
+    const float4 ov = ldf4(out + ro);
+    float4 g;
+    if (cot.n > 0) {
+        const float4 c = lc_load4(cot, ro);
+        g = make_float4(ov.x > 0.f ? cot_scale * c.x : 0.f, ov.y > 0.f ? cot_scale * c.y : 0.f,
+                        ov.z > 0.f ? cot_scale * c.z : 0.f, ov.w > 0.f ? cot_scale * c.w : 0.f);
+    } else g = ldf4(dout + ro);
+    const float4 dA = make_float4(g.x / dn, g.y / dn, g.z / dn, g.w / dn);
+    float dot = (g.x * ov.x + g.y * ov.y) + (g.z * ov.z + g.w * ov.w);
+#pragma unroll
+    for (int off = LPR >> 1; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+    const float dsum = -dot / dn;
+    const float4 bias = bf ? ldf4(bf + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cv = ldf4(pv.pt + (int64_t)v * pv.ldt + 4 * q);
+    cv.x += bias.x; cv.y += bias.y; cv.z += bias.z; cv.w += bias.w;
+    for (int base = b; base < end; base += 64) {
+        const int k = base + l;
+        int e = 0, sc = 0, tg = v; float we = 0.f, vv = 0.f;
+        if (k < end) { e = eid ? eid[k] : k; sc = src[e]; tg = tgt[e]; we = w[e]; vv = val ? val[k] : 1.f; }
+        const bool own = __all(tg == v);
+        const int cnt = end - base;
+        for (int u0 = 0; u0 < LPR; u0 += U) {
+            if (u0 * NS >= cnt) break;
+            float4 xv[U], cc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = (u0 + u) * NS + sg;
+                const int sj = __shfl(sc, j, 64), tj = __shfl(tg, j, 64);
+                xv[u] = ldf4(pv.ps + (int64_t)sj * pv.lds + 4 * q);
+                if (own) cc[u] = cv;
+                else {
+                    cc[u] = ldf4(pv.pt + (int64_t)tj * pv.ldt + 4 * q);
+                    cc[u].x += bias.x; cc[u].y += bias.y; cc[u].z += bias.z; cc[u].w += bias.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = (u0 + u) * NS + sg;
+                const int ej = __shfl(e, j, 64);
+                const float wej = __shfl(we, j, 64), vj = __shfl(vv, j, 64);
+                const float4 z = make_float4(xv[u].x + cc[u].x, xv[u].y + cc[u].y, xv[u].z + cc[u].z, xv[u].w + cc[u].w);
+                float part = (dA.x * fmaxf(z.x, 0.f) + dA.y * fmaxf(z.y, 0.f)) + (dA.z * fmaxf(z.z, 0.f) + dA.w * fmaxf(z.w, 0.f));
+#pragma unroll
+                for (int off = LPR >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+                if (j < cnt) {
+                    const float sc2 = vj * wej;
+                    *reinterpret_cast<float4*>(dz + (int64_t)ej * O + 4 * q) =
+                        make_float4(z.x > 0.f ? sc2 * dA.x : 0.f, z.y > 0.f ? sc2 * dA.y : 0.f,
+                                    z.z > 0.f ? sc2 * dA.z : 0.f, z.w > 0.f ? sc2 * dA.w : 0.f);
+                    if (q == 0) da[ej] = vj * (part + dsum) * wej;
+                }
+            }
+        }
+    }
+}
+
+// both incidence sums of the VJP (over the edges leaving a node and over those entering it), prefetched the same way
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_scatter_pf_kernel(const int* __restrict__ rp_s, const int* __restrict__ e_s,
+                                                             const int* __restrict__ rp_t, const int* __restrict__ e_t,
+                                                             const float* __restrict__ dz, const float* __restrict__ da,
+                                                             int n_rows, float* __restrict__ dps, int64_t lds,
+                                                             float* __restrict__ dpt, int64_t ldt, float* __restrict__ das,
+                                                             float* __restrict__ dat, int64_t lda) {
+    constexpr int O = 4 * LPR, NS = 64 / LPR, U = LPR < 4 ? LPR : 4;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_rows) return;
+    const int l = threadIdx.x & 63, q = l & (LPR - 1), sg = l / LPR;
+    const int bs = rp_s[v], es = rp_s[v + 1], bt = rp_t[v], et = rp_t[v + 1];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int* ee = side == 0 ? e_s : e_t;
+        const int b = side == 0 ? bs : bt, end = side == 0 ? es : et;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sa = 0.f;
+        for (int base = b; base < end; base += 64) {
+            const int k = base + l;
+            int e = -1;
+            if (k < end) { e = ee[k]; sa += da[e]; }
+            const int cnt = end - base;
+            for (int u0 = 0; u0 < LPR; u0 += U) {
+                if (u0 * NS >= cnt) break;
+                float4 xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ej = __shfl(e, (u0 + u) * NS + sg, 64);
+                    xv[u] = ej >= 0 ? ldf4(dz + (int64_t)ej * O + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { acc.x += xv[u].x; acc.y += xv[u].y; acc.z += xv[u].z; acc.w += xv[u].w; }
+            }
+        }
+        sa = wave_sum(sa);
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+        }
+        float* dp = side == 0 ? dps + (int64_t)v * lds : dpt + (int64_t)v * ldt;
+        if (sg == 0) *reinterpret_cast<float4*>(dp + 4 * q) = acc;
+        if (l == 0) (side == 0 ? das : dat)[(int64_t)v * lda] = sa;
+    }
+}
+
 // ---- large-graph variants: nnz-balanced records, as in the SpMM (csrc/spmm.hip) ---------------------------------
 // Edges are in target-sorted order (the caller passes eid == NULL: edge k IS position k of the CSR), so every
 // per-edge array (a, w, dz, da, src) is read and written as a stream and the only gather is Ps[src_k]: one
@@ -889,6 +1082,16 @@ int check_proj(const Proj& p, int64_t o) {
     return 0;
 }
 
+// the prefetched-index kernels: float4 lanes over o in {4, 8, 16, 32, 64}, 16-byte aligned rows
+// (o >= 16: at 8 columns - eight heads of 8 on the H-fold graph - two lanes per edge leave the prefetch stage mostly idle
+// and the plain wave kernels are faster: 9.2 / 10.5 us against 12.0 / 18.9 us on Citeseer x 8 heads)
+bool pf_ok(const Proj& pv, int64_t o, const void* p0, const void* p1) {
+    if (o != 16 && o != 32 && o != 64) return false;
+    if ((pv.lds % 4) || (pv.ldt % 4)) return false;
+    const uintptr_t al = (uintptr_t)pv.ps | (uintptr_t)pv.pt | (uintptr_t)p0 | (uintptr_t)p1;
+    return !(al & 15);
+}
+
 int launch_logits(const Proj& pv, const float* bw, const int32_t* src, const int32_t* tgt, int64_t n_edges,
                   float* a, float* amax, float* scratch, hipStream_t s) {
     if (n_edges <= kOneBlockEdges) {
@@ -911,6 +1114,14 @@ int launch_agg_fwd(const int32_t* rowptr, const int32_t* eid, const float* val, 
     const int maxc = (int)((o + G - 1) / G);
     const bool wave = n_rows <= kWaveRows;
     const int64_t blocks = wave ? (n_rows + 3) / 4 : (n_rows * G + 255) / 256;
+    if (wave && pf_ok(pv, o, out, bf)) {
+#define GODE_PF(L) hipLaunchKernelGGL(gat_agg_fwd_pf_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, src, tgt, \
+                                      pv, bf, a, amax, eps, (int)n_rows, out, w_out, den_out)
+        switch ((int)o / 4) { case 4: GODE_PF(4); break; case 8: GODE_PF(8); break; default: GODE_PF(16); break; }
+#undef GODE_PF
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
 #define GODE_AGG(M)                                                                                              \
     do {                                                                                                         \
         if (wave) hipLaunchKernelGGL(gat_agg_fwd_wave_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
@@ -932,6 +1143,16 @@ int launch_agg_bwd(const int32_t* rowptr, const int32_t* eid, const float* val, 
     const int maxc = (int)((o + G - 1) / G);
     const bool wave = n_rows <= kWaveRows || cot.n > 0;      // the cotangent-combining form exists as wave kernel only
     const int64_t blocks = wave ? (n_rows + 3) / 4 : (n_rows * G + 255) / 256;
+    bool cot_al = true;
+    for (int j = 0; j < cot.n; ++j) cot_al = cot_al && !(((uintptr_t)cot.ptr[j]) & 15);
+    if (wave && n_rows <= kWaveRows && cot_al && pf_ok(pv, o, out, bf) && !((((uintptr_t)dz) | ((uintptr_t)dout)) & 15)) {
+#define GODE_PF(L) hipLaunchKernelGGL(gat_agg_bwd_pf_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, src, tgt, \
+                                      pv, bf, w, den, out, dout, cot, cot_scale, (int)n_rows, dz, da)
+        switch ((int)o / 4) { case 4: GODE_PF(4); break; case 8: GODE_PF(8); break; default: GODE_PF(16); break; }
+#undef GODE_PF
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
 #define GODE_AGG(M)                                                                                              \
     do {                                                                                                         \
         if (wave) hipLaunchKernelGGL(gat_agg_bwd_wave_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
@@ -1162,6 +1383,15 @@ extern "C" int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* ei
     const int maxc = (int)((o + G - 1) / G);
     const int64_t blocks = (n_rows + 3) / 4;
     hipStream_t s = (hipStream_t)stream;
+    if ((o == 16 || o == 32 || o == 64) && !(ld_s % 4) && !(ld_t % 4) &&
+        !((((uintptr_t)dz) | ((uintptr_t)dps) | ((uintptr_t)dpt)) & 15)) {
+#define GODE_PF(L) hipLaunchKernelGGL(gat_scatter_pf_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr_src, eid_src, \
+                                      rowptr_tgt, eid_tgt, dz, da, (int)n_rows, dps, ld_s, dpt, ld_t, das, dat, ld_a)
+        switch ((int)o / 4) { case 4: GODE_PF(4); break; case 8: GODE_PF(8); break; default: GODE_PF(16); break; }
+#undef GODE_PF
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
 #define GODE_SC(M) hipLaunchKernelGGL(gat_scatter_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr_src, eid_src, \
                                       rowptr_tgt, eid_tgt, dz, da, (int)o, (int)n_rows, G, dps, ld_s, dpt, ld_t, das, dat, ld_a)
     if (maxc <= 1) GODE_SC(1); else if (maxc <= 2) GODE_SC(2); else if (maxc <= 4) GODE_SC(4); else GODE_SC(8);

@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int kGatPartBlocks = 512;        // one or two rows per wave on a citation graph; the closing launch reads them 16 at a time
+constexpr int kGatPartBlocks = 512;        // at d = 16: one or two rows per wave on a citation graph (the closing launch reads 16 partial rows per thread at once)
 
 __device__ __forceinline__ void xor_combine4(float4& v, int from) {
 #pragma unroll
@@ -368,10 +368,13 @@ extern "C" int gode_gat_small_supported(int64_t n_rows, int64_t d, int32_t group
     if (heads < 1) heads = 1;
     return n_rows > 0 && n_rows <= 65536 && heads <= 8 && d % heads == 0 && gat_small_cg(d, groups) > 0;
 }
-extern "C" int64_t gode_gat_small_parts(int64_t n_rows) {
+// a partial row is (2 d + 2 H + 2)(d + 1) floats: 2.4 KB at d = 16, 38 KB at d = 64, H = 8 - the wider the function, the
+// fewer blocks (at d = 64, 512 blocks wrote and re-read 19 MB per stage: 76 us; 128 blocks: 4.9 MB)
+extern "C" int64_t gode_gat_small_parts(int64_t n_rows, int64_t d) {
     int64_t b = (n_rows + 3) / 4;
+    const int64_t cap = d <= 16 ? kGatPartBlocks : (d <= 32 ? kGatPartBlocks / 2 : kGatPartBlocks / 4);
     if (b < 1) b = 1;
-    if (b > kGatPartBlocks) b = kGatPartBlocks;
+    if (b > cap) b = cap;
     return b;
 }
 extern "C" int64_t gode_gat_small_part_len(int64_t d, int64_t heads) {
@@ -429,7 +432,7 @@ extern "C" int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n
     const LinComb lx = make_lincomb(xin), lp = make_lincomb(pre);
     const int cg = gat_small_cg(d, groups);
     const int nl = (int)(2 * heads), nlp = nl <= 4 ? 4 : 16;
-    const dim3 grid((unsigned)gode_gat_small_parts(n_rows));
+    const dim3 grid((unsigned)gode_gat_small_parts(n_rows, d));
 #define GODE_GVJ(DV, CGV, NLV) hipLaunchKernelGGL((gat_dense_vjp_small_kernel<DV, CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                   lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, dPs, dPt, dA2, out_scale, lp, ka, part);
     GODE_GATS_DISPATCH(GODE_GVJ)
@@ -445,7 +448,7 @@ extern "C" int gode_gat_small_finish_f32(const float* part, int64_t n_rows, int6
     if (!part || !ktheta || !kat) return GODE_E_NULLPTR;
     if (n_rows <= 0 || n_rows > 65536 || d <= 0 || heads > 8) return GODE_E_SHAPE;
     GatFinish g;
-    g.part = part; g.n_part = (int)gode_gat_small_parts(n_rows); g.plen = (int)gode_gat_small_part_len(d, heads);
+    g.part = part; g.n_part = (int)gode_gat_small_parts(n_rows, d); g.plen = (int)gode_gat_small_part_len(d, heads);
     g.d = (int)d; g.nl = (int)(2 * heads); g.heads = (int)heads;
     g.out_len = (int)(2 * (d + 1) * d + (d + 1) * 2 * heads + d + heads + 2 * d);
     g.t = t; g.ktheta = ktheta; g.kat = kat;

@@ -196,7 +196,7 @@ def gat_small_supported(n_rows, d, groups, heads=1):
 
 def gat_small_part(n_rows, d, heads, device):
     lib = _lib.load()
-    return torch.empty(lib.gode_gat_small_parts(n_rows), lib.gode_gat_small_part_len(d, heads), dtype=torch.float32, device=device)
+    return torch.empty(lib.gode_gat_small_parts(n_rows, d), lib.gode_gat_small_part_len(d, heads), dtype=torch.float32, device=device)
 
 
 def gat_project_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, Wlog, heads, pt_bias, t, Ps, Pt, A2, x_out=None):
@@ -230,7 +230,7 @@ def gat_dense_vjp_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt
     if tuple(Wsrc.shape) != (d + 1, d) or tuple(Wtgt.shape) != (d + 1, d) or tuple(Wlog.shape) != (d + 1, 2 * heads):
         raise ValueError("gat_dense_vjp_small: weights must be (d+1) x d, (d+1) x d, (d+1) x 2H")
     if dPs.numel() != n_rows * d or dPt.numel() != n_rows * d or dA2.numel() != n_rows * 2 * heads or ka.numel() != n_rows * d or \
-            part.numel() != lib.gode_gat_small_parts(n_rows) * lib.gode_gat_small_part_len(d, heads):
+            part.numel() != lib.gode_gat_small_parts(n_rows, d) * lib.gode_gat_small_part_len(d, heads):
         raise ValueError("gat_dense_vjp_small: buffers have wrong size")
     lc = lincomb(x_terms)
     pre = None
@@ -247,7 +247,7 @@ def gat_dense_vjp_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt
 def gat_small_finish(part, n_rows, d, heads, t, ktheta, kat):
     lib = _lib.load()
     _need(part, "part"); _need(ktheta, "ktheta"); _need(kat, "kat")
-    if part.numel() != lib.gode_gat_small_parts(n_rows) * lib.gode_gat_small_part_len(d, heads) or \
+    if part.numel() != lib.gode_gat_small_parts(n_rows, d) * lib.gode_gat_small_part_len(d, heads) or \
             ktheta.numel() != lib.gode_gat_ode_theta_len_heads(d, heads) or kat.numel() != 1:
         raise ValueError("gat_small_finish: buffers have wrong size")
     check(lib.gode_gat_small_finish_f32(ptr(part), n_rows, d, heads, float(t), ptr(ktheta), ptr(kat), stream_ptr()),

@@ -480,7 +480,7 @@ typedef struct gode_gat_workspace {
     /* second column-sum scratch (gode_colsum_scratch_bytes(n, 2 * max(heads, 1))): with it, and up to 65 536 rows, the
      * reductions that close an adjoint stage run as one launch (gode_reduce_segments_f32); NULL: separate launches */
     void* colsum_scratch2;
-    /* nullable: gode_gat_small_parts(n) * gode_gat_small_part_len(d, heads) floats - with it, and where
+    /* nullable: gode_gat_small_parts(n, d) * gode_gat_small_part_len(d, heads) floats - with it, and where
      * gode_gat_small_supported, the dense half of a stage runs on the one-launch kernels below */
     float* small_part;
 } gode_gat_workspace_t;
@@ -498,7 +498,7 @@ typedef struct gode_gat_workspace {
  *              bf = colsum(dPt), bw_h = colsum(dA2)[2h+1]) and *kat = the a_t derivative, from the partials (fixed order:
  *              deterministic) */
 int     gode_gat_small_supported(int64_t n_rows, int64_t d, int32_t groups, int64_t heads);
-int64_t gode_gat_small_parts(int64_t n_rows);
+int64_t gode_gat_small_parts(int64_t n_rows, int64_t d);
 int64_t gode_gat_small_part_len(int64_t d, int64_t heads);
 int gode_gat_project_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
                                const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
