@@ -159,7 +159,8 @@ template <int D, int NLP> struct GatVjpShape {
     static constexpr int LPR = D / 4, SG = 64 / LPR, NS = D / SG, NSL = (NLP + SG - 1) / SG;
     static constexpr int NIN = 2 * D + NLP;                      // columns of [dPs | dPt | dA2]
     static constexpr int WT = NIN * (D + 4);                     // transposed weights, row stride D + 4
-    static constexpr int PMAX = 2 * (D + 1) * D + (D + 1) * NLP + 2 * D + 1;
+    static constexpr int RS = D + 1, RSL = NLP + 1;              // odd row strides of the block reduction (LDS banks)
+    static constexpr int PMAX = 2 * (D + 1) * RS + (D + 1) * RSL + 2 * D + 1;
     static constexpr int BUF = WT > PMAX ? WT : PMAX;
 };
 
@@ -203,11 +204,28 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
     }
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 cs_s = zero4, cs_t = zero4, cs_l = zero4, dg = zero4, db = zero4;
-    for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {
+    // the next row's operands are requested before the current row is worked on: a row is a chain of ~4 us of dependent
+    // latency (global -> LDS -> products -> shuffles) and a wave owns several rows at d = 64
+    int row = blockIdx.x * 4 + wave;
+    float4 ngs = zero4, ngt = zero4, ngl = zero4, nx = zero4;
+    if (row < n_rows) {
+        const int64_t o0 = (int64_t)row * D + 4 * q;
+        ngs = ld4(dPs + o0); ngt = ld4(dPt + o0);
+        if (has_l) ngl = load_logit4(dA2 + (int64_t)row * nl, 4 * q, nl);
+        nx = lc_load4(xin, o0);
+    }
+    for (; row < n_rows; row += gridDim.x * 4) {
         const int64_t o = (int64_t)row * D + 4 * q;
-        const float4 gs = ld4(dPs + o), gt = ld4(dPt + o);
-        const float4 gl = has_l ? load_logit4(dA2 + (int64_t)row * nl, 4 * q, nl) : zero4;
-        const float4 x = lc_load4(xin, o);
+        const float4 gs = ngs, gt = ngt, gl = ngl, x = nx;
+        {
+            const int nrow = row + gridDim.x * 4;
+            if (nrow < n_rows) {
+                const int64_t o1 = (int64_t)nrow * D + 4 * q;
+                ngs = ld4(dPs + o1); ngt = ld4(dPt + o1);
+                if (has_l) ngl = load_logit4(dA2 + (int64_t)nrow * nl, 4 * q, nl);
+                nx = lc_load4(xin, o1);
+            }
+        }
         if (s == 0) {
             *reinterpret_cast<float4*>(dr + 4 * q) = gs;
             *reinterpret_cast<float4*>(dr + D + 4 * q) = gt;
@@ -230,17 +248,18 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
             add4(db, dy);
             add4(cs_s, gs); add4(cs_t, gt); add4(cs_l, gl);
         }
-        // weight gradients: lane (q, s) owns rows 1 + 4q .. 4q + 4 of the three blocks and columns s NS .. (s NSL ..)
+        // weight gradients: lane (q, s) owns rows 1 + 4q .. 4q + 4 of the three blocks and the columns c = s (mod SG):
+        // interleaved, so that the block reduction below touches 32 different LDS banks per instruction
         const float xv[4] = {xn.x, xn.y, xn.z, xn.w};
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const float a_s = dr[s * NS + i], a_t = dr[D + s * NS + i];
+            const float a_s = dr[s + SG * i], a_t = dr[D + s + SG * i];
 #pragma unroll
             for (int a = 0; a < 4; ++a) { acc_s[a][i] = fmaf(xv[a], a_s, acc_s[a][i]); acc_t[a][i] = fmaf(xv[a], a_t, acc_t[a][i]); }
         }
 #pragma unroll
         for (int i = 0; i < NSL; ++i) {
-            const int c = s * NSL + i;
+            const int c = s + SG * i;
             const float a_l = c < NLP ? dr[2 * D + c] : 0.f;
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc_l[a][i] = fmaf(xv[a], a_l, acc_l[a][i]);
@@ -248,23 +267,27 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();                                             // every wave is done with Wt: the storage becomes the partial
+    // Block reduction in LDS, the four waves in wave order (deterministic).  Layout: rows of D + 1 (NLP + 1) floats - an
+    // ODD stride: for one (a, i) the 64 lanes of a wave write rows 4 q + a + 1 and columns s + SG i, i.e. banks
+    // (4 q (D+1) + s) mod 32 = 4 q + s: all 32 banks, two lanes each.  (With rows of D floats every lane of the wave hit one
+    // of TWO banks: 288 fully serialised LDS instructions per wave and phase, 35 of the kernel's 52 us at d = 64.)
     float* red = buf;
-    const int oL = 2 * nW, oG = oL + (D + 1) * nl, oB = oG + D, oT = oB + D, plen = oT + 1;
-    for (int w = 0; w < 4; ++w) {                                // the four waves add in wave order (deterministic)
+    constexpr int RS = S::RS, RSL = S::RSL, rT = (D + 1) * RS, rL = 2 * rT, rG = rL + (D + 1) * RSL, rB = rG + D, rA = rB + D;
+    for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
-                    const int idx = (1 + 4 * q + a) * D + s * NS + i;
+                    const int idx = (1 + 4 * q + a) * RS + s + SG * i;
                     red[idx] = (w == 0 ? 0.f : red[idx]) + acc_s[a][i];
-                    red[nW + idx] = (w == 0 ? 0.f : red[nW + idx]) + acc_t[a][i];
+                    red[rT + idx] = (w == 0 ? 0.f : red[rT + idx]) + acc_t[a][i];
                 }
 #pragma unroll
                 for (int i = 0; i < NSL; ++i) {
-                    const int c = s * NSL + i;
-                    if (c < nl) {
-                        const int idx = oL + (1 + 4 * q + a) * nl + c;
+                    const int c = s + SG * i;
+                    if (c < NLP) {
+                        const int idx = rL + (1 + 4 * q + a) * RSL + c;
                         red[idx] = (w == 0 ? 0.f : red[idx]) + acc_l[a][i];
                     }
                 }
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
             if (s == 0) {
                 const float c4[4][4] = {{cs_s.x, cs_s.y, cs_s.z, cs_s.w}, {cs_t.x, cs_t.y, cs_t.z, cs_t.w},
                                         {dg.x, dg.y, dg.z, dg.w}, {db.x, db.y, db.z, db.w}};
-                const int base[4] = {0, nW, oG, oB};
+                const int base[4] = {0, rT, rG, rB};
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -283,11 +306,10 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
                 if (has_l) {
                     const float cl[4] = {cs_l.x, cs_l.y, cs_l.z, cs_l.w};
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        if (4 * q + a < nl) {
-                            const int idx = oL + 4 * q + a;
-                            red[idx] = (w == 0 ? 0.f : red[idx]) + cl[a];
-                        }
+                    for (int a = 0; a < 4; ++a) {
+                        const int idx = rL + 4 * q + a;
+                        red[idx] = (w == 0 ? 0.f : red[idx]) + cl[a];
+                    }
                 }
             }
         }
@@ -296,16 +318,24 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
     if (wave == 0) {                                             // the block's share of a_t' = colsums . time rows of the weights
         float v = 0.f;
         for (int c = l; c < 2 * D + nl; c += 64) {
-            const float cs = c < D ? red[c] : (c < 2 * D ? red[nW + c - D] : red[oL + c - 2 * D]);
+            const float cs = c < D ? red[c] : (c < 2 * D ? red[rT + c - D] : red[rL + c - 2 * D]);
             const float w0 = c < D ? Wsrc[c] : (c < 2 * D ? Wtgt[c - D] : Wlog[c - 2 * D]);
             v = fmaf(cs, w0, v);
         }
         v = wave_sum(v);
-        if (l == 0) red[oT] = v;
+        if (l == 0) red[rA] = v;
     }
     __syncthreads();
+    // compact partial row: [dWsrc | dWtgt | dWlog ((D+1) x nl) | dgamma | dbeta | a_t share]
+    const int oL = 2 * nW, oG = oL + (D + 1) * nl, plen = oG + 2 * D + 1;
     float* out = part + (int64_t)blockIdx.x * plen;
-    for (int i = threadIdx.x; i < plen; i += 256) out[i] = red[i];
+    for (int i = threadIdx.x; i < plen; i += 256) {
+        int src;
+        if (i < oL) { const int bI = i >= nW, j = i - bI * nW; src = bI * rT + (j / D) * RS + j % D; }
+        else if (i < oG) { const int j = i - oL; src = rL + (j / nl) * RSL + j % nl; }
+        else src = rG + (i - oG);                               // dgamma, dbeta and the a_t share are contiguous in both
+        out[i] = red[src];
+    }
 }
 
 // k_theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta] (time rows scaled by t) and k_a_t from the block partials:
@@ -369,10 +399,11 @@ extern "C" int gode_gat_small_supported(int64_t n_rows, int64_t d, int32_t group
     return n_rows > 0 && n_rows <= 65536 && heads <= 8 && d % heads == 0 && gat_small_cg(d, groups) > 0;
 }
 // a partial row is (2 d + 2 H + 2)(d + 1) floats: 2.4 KB at d = 16, 38 KB at d = 64, H = 8 - the wider the function, the
-// fewer blocks (at d = 64, 512 blocks wrote and re-read 19 MB per stage: 76 us; 128 blocks: 4.9 MB)
+// fewer blocks.  Measured at d = 64 (Citeseer, 8 heads, training step): 64 / 128 / 256 / 512 blocks 11.2 / 10.2 / 9.8 /
+// 11.0 ms (512 blocks write and re-read 19 MB per stage).
 extern "C" int64_t gode_gat_small_parts(int64_t n_rows, int64_t d) {
     int64_t b = (n_rows + 3) / 4;
-    const int64_t cap = d <= 16 ? kGatPartBlocks : (d <= 32 ? kGatPartBlocks / 2 : kGatPartBlocks / 4);
+    const int64_t cap = d <= 16 ? kGatPartBlocks : kGatPartBlocks / 2;
     if (b < 1) b = 1;
     if (b > cap) b = cap;
     return b;
