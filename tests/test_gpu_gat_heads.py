@@ -531,6 +531,15 @@ def test_one_launch_dense_half_matches_multi_launch_path(golden, heads, d, metho
             for a, b in zip(res[1][2], res[0][2]):
                 assert b.abs().max().item() < 1e-3 or rel(a, b) <= 0.1, "parameter gradient"
         return
+    if method == "dopri5":
+        # two fp32 runs of an adaptive solve take accept / reject decisions that move with rounding (and at one channel per
+        # group GroupNorm returns beta + noise x 316): the gradients agree in norm, not entry by entry
+        def rel(a, b):
+            return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        assert rel(res[1][1], res[0][1]) <= 5e-2, "dx"
+        for a, b in zip(res[1][2], res[0][2]):
+            assert b.abs().max().item() < 1e-3 or rel(a, b) <= 5e-2, "parameter gradient"
+        return
     close(res[1][1], res[0][1], gtol, "dx")
     for a, b in zip(res[1][2], res[0][2]):
         close(a, b, gtol, "parameter gradient")
