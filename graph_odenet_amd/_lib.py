@@ -196,6 +196,9 @@ SIGNATURES = {
                                                ctypes.POINTER(c_p), ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_p, c_p, c_p,
                                                c_p, ctypes.POINTER(GatWorkspace), ctypes.c_double, ctypes.c_double, c_f,
                                                c_f, c_p, c_p, c_p]),
+    "gode_lstm_cell_supported": (c_i, [c_i64, c_i64, c_i64]),
+    "gode_lstm_cell_f32_fwd": (c_i, [c_p] * 7 + [c_i64] * 3 + [c_p] * 4),
+    "gode_lstm_cell_f32_bwd": (c_i, [c_p] * 9 + [c_i64] * 3 + [c_p] * 8),
     "gode_gru_wgrad_parts": (c_i64, [c_i64]),
     "gode_gru_cell_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_gru_cell_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,

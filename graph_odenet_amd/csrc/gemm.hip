@@ -756,7 +756,7 @@ __global__ __launch_bounds__(1024, 1) void wgrad_split_kernel(LinComb xin, int n
                                                              const float* __restrict__ dS, int has_time,
                                                              float* __restrict__ dW_part)
 {
-    constexpr int D = 128, NJ = 8, R = 32, NP = 4;
+    constexpr int D = 128, R = 32, NP = 4;
     constexpr int QS = 36, GRP = 4 * QS, PIECE = 4 * GRP;          // in 16-byte chunks
     constexpr int PIECE_B = PIECE * 16, BUF_B = 6 * PIECE_B;       // one buffer: X pieces, then dS pieces
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -645,6 +645,48 @@ def edge_matvec_bwd(edge_row, edge_val, src, A, X, dM, want_dA=True, want_dx=Tru
 
 
 # ---- QC node update: fused GRU cell ---------------------------------------------------------------
+def lstm_cell_supported(B, I, H):
+    return bool(_lib.load().gode_lstm_cell_supported(B, I, H))
+
+
+def lstm_cell_fwd(x, h, c, w_ih, w_hh, b_ih, b_hh, want_gates=True):
+    """(h', c') = LSTMCell(x, (h, c)) with torch.nn.LSTM's parameter layout; returns (h', c', gates[B, 4H] or None)."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (h, "h"), (c, "c"), (w_ih, "weight_ih"), (w_hh, "weight_hh"), (b_ih, "bias_ih"), (b_hh, "bias_hh")):
+        _need(t, nm)
+    B, I = x.shape
+    H = h.shape[1]
+    if tuple(h.shape) != (B, H) or tuple(c.shape) != (B, H) or tuple(w_ih.shape) != (4 * H, I) or tuple(w_hh.shape) != (4 * H, H):
+        raise ValueError("lstm_cell: x B x I, h, c B x H, weight_ih 4H x I, weight_hh 4H x H (got %s %s %s %s %s)"
+                         % (tuple(x.shape), tuple(h.shape), tuple(c.shape), tuple(w_ih.shape), tuple(w_hh.shape)))
+    f = dict(dtype=torch.float32, device=x.device)
+    h_out, c_out = torch.empty(B, H, **f), torch.empty(B, H, **f)
+    gates = torch.empty(B, 4 * H, **f) if want_gates else None
+    check(lib.gode_lstm_cell_f32_fwd(ptr(x), ptr(h), ptr(c), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), B, I, H, ptr(h_out),
+                                     ptr(c_out), ptr(gates), stream_ptr()), "gode_lstm_cell_f32_fwd")
+    return h_out, c_out, gates
+
+
+def lstm_cell_bwd(x, h, c, w_ih, w_hh, gates, c_out, dh_out, dc_out, has_bias=True, want_dx=True, want_dh=True):
+    """Returns (dx, dh, dc, dw_ih, dw_hh, db_ih, db_hh)."""
+    lib = _lib.load()
+    for t, nm in ((gates, "gates"), (c_out, "c_out"), (dh_out, "dh_out"), (dc_out, "dc_out")):
+        _need(t, nm)
+    B, I = x.shape
+    H = h.shape[1]
+    f = dict(dtype=torch.float32, device=x.device)
+    dx = torch.empty(B, I, **f) if want_dx else None
+    dh = torch.empty(B, H, **f) if want_dh else None
+    dc = torch.empty(B, H, **f)
+    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+    db_ih = torch.empty(4 * H, **f) if has_bias else None
+    db_hh = torch.empty(4 * H, **f) if has_bias else None
+    check(lib.gode_lstm_cell_f32_bwd(ptr(x), ptr(h), ptr(c), ptr(w_ih), ptr(w_hh), ptr(gates), ptr(c_out), ptr(dh_out), ptr(dc_out),
+                                     B, I, H, ptr(dx), ptr(dh), ptr(dc), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh),
+                                     stream_ptr()), "gode_lstm_cell_f32_bwd")
+    return dx, dh, dc, dw_ih, dw_hh, db_ih, db_hh
+
+
 def gru_cell_fwd(x, m, w_ih, w_hh, b_ih, b_hh, want_gates=True):
     """out = GRUCell([x | m], x) with torch.nn.GRUCell's parameter layout; returns (out, gates[n, 4h] or None)."""
     lib = _lib.load()

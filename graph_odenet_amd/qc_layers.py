@@ -154,11 +154,12 @@ GRU_MAX_ROWS = 65535 * 64        # grid.y of the weight-gradient launch (64-row 
 
 def gru_update(cell, x, m):
     """cell(torch.cat([x, m], 1), x) for cell = nn.GRUCell(2h, h), fused.  Outside the fused kernels' limits (h > 640,
-    more than 4.19 M rows) the update is the module's own call on the
+    more than 4.19 M rows, a state that is not fp32 on the GPU) the update is the module's own call on the
     concatenated input - the reference's line (QC/mpnn.py:30) on the GPU library path - instead of an error."""
     if cell.input_size != 2 * cell.hidden_size or x.shape[1] != cell.hidden_size:
         raise ValueError("gru_update: the update cell must be GRUCell(2h, h) on n x h states")
-    if cell.hidden_size > GRU_MAX_H or x.shape[0] > GRU_MAX_ROWS:
+    if cell.hidden_size > GRU_MAX_H or x.shape[0] > GRU_MAX_ROWS or not x.is_cuda or x.dtype != torch.float32 or \
+            m.dtype != torch.float32:
         return cell(torch.cat([x, m], 1), x)
     return _GruUpdateFn.apply(x, m, cell.weight_ih, cell.weight_hh, getattr(cell, "bias_ih", None),
                               getattr(cell, "bias_hh", None))

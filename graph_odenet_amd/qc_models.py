@@ -182,10 +182,34 @@ class _SegmentAttentionFn(torch.autograd.Function):
         return None, dx, dq
 
 
+class _LstmCellFn(torch.autograd.Function):
+    """(h', c') = LSTMCell(x, (h, c)) on an nn.LSTM's own layer-0 parameters (QC/set2set.py:44-47,61): one launch forward,
+    one backward (csrc/lstm.hip) - no library GEMM on a 20-row batch."""
+
+    @staticmethod
+    def forward(ctx, x, h, c, w_ih, w_hh, b_ih, b_hh):
+        x, h, c = x.contiguous(), h.contiguous(), c.contiguous()
+        w_ih, w_hh = w_ih.contiguous(), w_hh.contiguous()
+        h_out, c_out, gates = ops.lstm_cell_fwd(x, h, c, w_ih, w_hh, b_ih, b_hh)
+        ctx.has_bias = b_ih is not None
+        ctx.save_for_backward(x, h, c, w_ih, w_hh, gates, c_out)
+        return h_out, c_out
+
+    @staticmethod
+    def backward(ctx, dh_out, dc_out):
+        x, h, c, w_ih, w_hh, gates, c_out = ctx.saved_tensors
+        dh_out = dh_out.contiguous() if dh_out is not None else None
+        dc_out = dc_out.contiguous() if dc_out is not None else None
+        dx, dh, dc, dw_ih, dw_hh, db_ih, db_hh = ops.lstm_cell_bwd(
+            x, h, c, w_ih, w_hh, gates, c_out, dh_out, dc_out, has_bias=ctx.has_bias,
+            want_dx=ctx.needs_input_grad[0], want_dh=ctx.needs_input_grad[1])
+        return dx, dh, (dc if ctx.needs_input_grad[2] else None), dw_ih, dw_hh, db_ih, db_hh
+
+
 class Set2Set(nn.Module):
     """Set2Set pooling (Vinyals et al. 2015) with the reference's parameters (`lstm`).  The per-graph softmax loop of
-    the reference is one kernel per processing step (csrc/segment.hip); the single-layer LSTM step runs as a fused
-    cell on the same `lstm.*` parameters (gate order i, f, g, o as in nn.LSTM)."""
+    the reference is one kernel per processing step (csrc/segment.hip); the single-layer LSTM step runs as the fused
+    cell of csrc/lstm.hip on the same `lstm.*` parameters (gate order i, f, g, o as in nn.LSTM)."""
 
     def __init__(self, in_channels, processing_steps, num_layers=1):
         super().__init__()
@@ -198,7 +222,11 @@ class Set2Set(nn.Module):
             q, h = self.lstm(q_star.unsqueeze(0), h)
             return q.view(q_star.shape[0], self.in_channels), h
         l = self.lstm
-        hx, cx = torch.lstm_cell(q_star, (h[0][0], h[1][0]), l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)
+        if q_star.is_cuda and q_star.dtype == torch.float32 and \
+                ops.lstm_cell_supported(q_star.shape[0], self.out_channels, self.in_channels):
+            hx, cx = _LstmCellFn.apply(q_star, h[0][0], h[1][0], l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)
+        else:                                # outside the fused cell's limits: the library cell on the same parameters
+            hx, cx = torch.lstm_cell(q_star, (h[0][0], h[1][0]), l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)
         return hx, (hx.unsqueeze(0), cx.unsqueeze(0))
 
     def forward(self, x, batch):

@@ -522,6 +522,22 @@ int gode_gat_ode_dopri5_step_adjoint(const gode_gat_odefunc_t* f, const float* y
                                      const gode_gat_workspace_t* ws, double t, double h, float rtol, float atol,
                                      double* sums /* 4 */, void* err_scratch, void* stream);
 
+/* ---- Set2Set readout: LSTM cell, one launch per direction (csrc/lstm.hip; replaces the single-layer `self.lstm` step of
+ * QC/set2set.py:44-47,61 = torch.lstm_cell: two library GEMMs + a cell kernel forward, four GEMMs + reductions backward).
+ * x: B x I, h, c: B x H, w_ih: 4H x I, w_hh: 4H x H, b_ih, b_hh: 4H (nullable), gate order i, f, g, o as torch.nn.LSTM.
+ * fwd: h_out, c_out (B x H); gates (nullable; B x 4H) receives the four activations per unit - what the backward reads.
+ * bwd: dh_out, dc_out (B x H, either nullable = zero) -> dx (B x I, nullable), dh (nullable), dc (B x H), dw_ih, dw_hh and
+ * db_ih, db_hh (nullable).  Fixed summation order.  supported: B (4H + 5) + 16 H <= 24 576 and 6 (I + H) + 256 <= 24 576
+ * (floats of LDS). */
+int gode_lstm_cell_supported(int64_t B, int64_t I, int64_t H);
+int gode_lstm_cell_f32_fwd(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
+                           const float* b_ih, const float* b_hh, int64_t B, int64_t I, int64_t H, float* h_out,
+                           float* c_out, float* gates, void* stream);
+int gode_lstm_cell_f32_bwd(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
+                           const float* gates, const float* c_out, const float* dh_out, const float* dc_out, int64_t B,
+                           int64_t I, int64_t H, float* dx, float* dh, float* dc, float* dw_ih, float* dw_hh,
+                           float* db_ih, float* db_hh, void* stream);
+
 /* ---- QC node update: fused GRU cell (replaces nn.GRUCell(2h, h) applied to ([x | m], x), QC/mpnn.py:12,30) -----
  * x, m: n x h (state and aggregated messages; the concatenation [x | m] is never formed).  w_ih: 3h x 2h, w_hh: 3h x h,
  * b_ih, b_hh: 3h (nullable), gate order r, z, n as torch.nn.GRUCell.  out: n x h.  gates (nullable; n x 4h) receives

@@ -772,3 +772,33 @@ def test_gat_native_dopri5_step_matches_python_driver(golden, d):
     tol = 1e-4 if d == 16 else 1e-5
     for a, b in zip(res[True][2], res[False][2]):
         close(a, b, tol, "param grad")
+
+
+@pytest.mark.parametrize("B,I,H", [(20, 146, 73), (1, 8, 4), (64, 146, 73), (7, 300, 100), (3, 5, 3)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_fused_lstm_cell_vs_float64(B, I, H, bias):
+    """csrc/lstm.hip: the LSTM cell of the Set2Set readout (QC/set2set.py:44-47,61; torch.nn.LSTM's layout and gate order)
+    as one launch forward and one backward, against torch.lstm_cell in float64 on the CPU: h', c', and the gradients of
+    x, h, c, both weight matrices and both biases under cotangents on BOTH outputs (the next processing step reads h' and
+    c') and on h' alone."""
+    from graph_odenet_amd import ops
+    from graph_odenet_amd.qc_models import _LstmCellFn
+    if not ops.lstm_cell_supported(B, I, H):
+        pytest.skip("outside the fused cell's limits")
+    g = torch.Generator().manual_seed(B + 3 * I + 7 * H)
+    mk = lambda *s: torch.randn(*s, generator=g)                                                     # noqa: E731
+    x, h, c = mk(B, I), mk(B, H), mk(B, H)
+    w_ih, w_hh = mk(4 * H, I) / I ** 0.5, mk(4 * H, H) / H ** 0.5
+    b_ih, b_hh = (mk(4 * H), mk(4 * H)) if bias else (None, None)
+    gh, gc = mk(B, H), mk(B, H)
+    for use_gc in (True, False):
+        ref_in = [t.double().requires_grad_(True) if t is not None else None for t in (x, h, c, w_ih, w_hh, b_ih, b_hh)]
+        rh, rc = torch.lstm_cell(ref_in[0], (ref_in[1], ref_in[2]), ref_in[3], ref_in[4], ref_in[5], ref_in[6])
+        ((rh * gh.double()).sum() + ((rc * gc.double()).sum() if use_gc else 0.0)).backward()
+        dev_in = [t.to(dev()).requires_grad_(True) if t is not None else None for t in (x, h, c, w_ih, w_hh, b_ih, b_hh)]
+        oh, oc = _LstmCellFn.apply(*dev_in)
+        close(oh, rh, 2e-6, "h'"); close(oc, rc, 2e-6, "c'")
+        ((oh * gh.to(dev())).sum() + ((oc * gc.to(dev())).sum() if use_gc else 0.0)).backward()
+        for a, b, nm in zip(dev_in, ref_in, ("dx", "dh", "dc", "dw_ih", "dw_hh", "db_ih", "db_hh")):
+            if a is not None:
+                close(a.grad, b.grad, 4e-6 * max(1.0, B ** 0.5), nm)
