@@ -166,6 +166,11 @@ SIGNATURES = {
     "gode_gat_heads_scratch_bytes": (c_i64, [c_i64, c_i64]),
     "gode_gat_logits_heads_f32": (c_i, [ctypes.POINTER(GatProj), c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "gode_gat_maxpath_heads_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p]),
+    "gode_gat_heads_parts": (c_i64, [c_i64]),
+    "gode_gat_logits_heads_raw_f32": (c_i, [ctypes.POINTER(GatProj), c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "gode_gat_agg_heads_f32_fwd": (c_i, [ctypes.POINTER(Graph), c_p, c_p, ctypes.POINTER(GatProj), c_i64, c_p, c_p, c_p, c_i64,
+                                         c_i64, c_f, c_p, c_p, c_p, c_p]),
+    "gode_gat_maxpath_heads_raw_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p]),
     "gode_gat_scatter_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64,
                                    c_p]),
     "gode_time_row_fixup_f32": (c_i, [c_p, c_p, c_i64, c_f, c_p, c_i, c_p]),

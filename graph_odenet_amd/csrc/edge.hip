@@ -25,6 +25,19 @@ struct Proj {
 };
 Proj proj_of(const gode_gat_proj_t* p) { return Proj{p->ps, p->ld_s, p->pt, p->ld_t, p->as, p->at, p->ld_a}; }
 
+// H-fold graphs (gat_heads.py): the maximum a virtual row's logits are shifted by is its HEAD's maximum (row % H).  The
+// logits launch leaves per-block partial maxima (pmax[block * H + head]); the consumers reduce their head's partials
+// themselves - one more load level inside a kernel instead of a launch that rewrites every logit (7.3 us x 129 per
+// Citeseer step).  H == 0: one global maximum at amax[0].
+struct HeadMax { const float* pmax; int n_part; int H; };
+__device__ __forceinline__ float shift_of(const HeadMax& hm, const float* amax, int row, int lane) {
+    if (hm.H <= 0) return amax[0];
+    const int h = row % hm.H;
+    float m = -INFINITY;
+    for (int b = lane; b < hm.n_part; b += 64) m = fmaxf(m, hm.pmax[b * hm.H + h]);
+    return wave_max(m);
+}
+
 __device__ __forceinline__ float block_max(float v) {
     __shared__ float sm[4];
     v = wave_max(v);
@@ -168,13 +181,13 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_wave_kernel(const int* __rest
                                                                const int* __restrict__ src, const int* __restrict__ tgt,
                                                                Proj pv, int o,
                                                                const float* __restrict__ bf, const float* __restrict__ a,
-                                                               const float* __restrict__ amax, float eps, int n_rows, int G,
+                                                               const float* __restrict__ amax, HeadMax hm, float eps, int n_rows, int G,
                                                                float* __restrict__ out, float* __restrict__ w_out,
                                                                float* __restrict__ s_out) {
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= n_rows) return;
     const int l = threadIdx.x & 63, lane = l & (G - 1), sg = l / G, ns = 64 / G;
-    const float m = amax[0];
+    const float m = shift_of(hm, amax, v, l);
     float acc[MAXC], bias[MAXC];
 #pragma unroll
     for (int q = 0; q < MAXC; ++q) { acc[q] = 0.f; const int c = lane + q * G; bias[q] = (bf && c < o) ? bf[c] : 0.f; }
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_pf_kernel(const int* __restri
                                                              const float* __restrict__ val,
                                                              const int* __restrict__ src, const int* __restrict__ tgt,
                                                              Proj pv, const float* __restrict__ bf, const float* __restrict__ a,
-                                                             const float* __restrict__ amax, float eps, int n_rows,
+                                                             const float* __restrict__ amax, HeadMax hm, float eps, int n_rows,
                                                              float* __restrict__ out, float* __restrict__ w_out,
                                                              float* __restrict__ s_out) {
     constexpr int O = 4 * LPR, NS = 64 / LPR, U = LPR < 4 ? LPR : 4;
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_pf_kernel(const int* __restri
     if (v >= n_rows) return;
     const int l = threadIdx.x & 63, q = l & (LPR - 1), sg = l / LPR;
     const int b = rowptr[v], end = rowptr[v + 1];
-    const float m = amax[0];
+    const float m = shift_of(hm, amax, v, l);
     const float4 bias = bf ? ldf4(bf + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 cv = ldf4(pv.pt + (int64_t)v * pv.ldt + 4 * q);
     cv.x += bias.x; cv.y += bias.y; cv.z += bias.z; cv.w += bias.w;
@@ -1026,18 +1039,25 @@ __global__ __launch_bounds__(256) void gat_logits_heads_shift_kernel(const int* 
 // per block and head: sum of da and first edge whose shifted logit is 0 (the head's arg-max)
 __global__ __launch_bounds__(256) void gat_maxpath_heads_part_kernel(const float* __restrict__ a, const float* __restrict__ da,
                                                                      const int* __restrict__ tgt, int n_edges, int H,
-                                                                     float* __restrict__ psum, int* __restrict__ pidx) {
+                                                                     float* __restrict__ psum, int* __restrict__ pidx,
+                                                                     const float* __restrict__ pmax, int n_pmax) {
     extern __shared__ float col[];                    // [H][256]: thread t accumulates its own column
     __shared__ int hidx[kMaxHeads];
+    __shared__ float hmx[kMaxHeads];                  // the value an arg-max logit has: 0 (shifted logits) or the head's maximum (raw)
     for (int h = 0; h < H; ++h) col[h * 256 + threadIdx.x] = 0.f;
-    if (threadIdx.x < H) hidx[threadIdx.x] = INT32_MAX;
+    if (threadIdx.x < H) {
+        hidx[threadIdx.x] = INT32_MAX;
+        float m = 0.f;
+        if (pmax) { m = -INFINITY; for (int b = 0; b < n_pmax; ++b) m = fmaxf(m, pmax[b * H + threadIdx.x]); }
+        hmx[threadIdx.x] = m;
+    }
     __syncthreads();
     const int per = (n_edges + gridDim.x - 1) / gridDim.x;
     const int lo = blockIdx.x * per, hi = min(n_edges, lo + per);
     for (int e = lo + threadIdx.x; e < hi; e += 256) {
         const int h = tgt[e] % H;
         col[h * 256 + threadIdx.x] += da[e];
-        if (a[e] == 0.f) atomicMin(&hidx[h], e);
+        if (a[e] == hmx[h]) atomicMin(&hidx[h], e);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1109,14 +1129,15 @@ int launch_logits(const Proj& pv, const float* bw, const int32_t* src, const int
 
 int launch_agg_fwd(const int32_t* rowptr, const int32_t* eid, const float* val, const int32_t* src, const int32_t* tgt,
                    const Proj& pv, int64_t o, const float* bf, const float* a, const float* amax, float eps,
-                   int64_t n_rows, float* out, float* w_out, float* den_out, hipStream_t s) {
+                   int64_t n_rows, float* out, float* w_out, float* den_out, hipStream_t s, HeadMax hm = HeadMax{nullptr, 0, 0}) {
     const int G = pow2_group((int)o);
     const int maxc = (int)((o + G - 1) / G);
     const bool wave = n_rows <= kWaveRows;
+    if (hm.H > 0 && !wave) return GODE_E_UNSUPPORTED;          // per-head partial maxima: wave kernels only
     const int64_t blocks = wave ? (n_rows + 3) / 4 : (n_rows * G + 255) / 256;
     if (wave && pf_ok(pv, o, out, bf)) {
 #define GODE_PF(L) hipLaunchKernelGGL(gat_agg_fwd_pf_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, src, tgt, \
-                                      pv, bf, a, amax, eps, (int)n_rows, out, w_out, den_out)
+                                      pv, bf, a, amax, hm, eps, (int)n_rows, out, w_out, den_out)
         switch ((int)o / 4) { case 4: GODE_PF(4); break; case 8: GODE_PF(8); break; default: GODE_PF(16); break; }
 #undef GODE_PF
         GODE_LAUNCH_CHECK();
@@ -1125,7 +1146,7 @@ int launch_agg_fwd(const int32_t* rowptr, const int32_t* eid, const float* val, 
 #define GODE_AGG(M)                                                                                              \
     do {                                                                                                         \
         if (wave) hipLaunchKernelGGL(gat_agg_fwd_wave_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
-                                     src, tgt, pv, (int)o, bf, a, amax, eps, (int)n_rows, G, out, w_out, den_out); \
+                                     src, tgt, pv, (int)o, bf, a, amax, hm, eps, (int)n_rows, G, out, w_out, den_out); \
         else hipLaunchKernelGGL(gat_agg_fwd_kernel<M>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, \
                                 src, tgt, pv, (int)o, bf, a, amax, eps, (int)n_rows, G, out, w_out, den_out);     \
     } while (0)
@@ -1308,11 +1329,14 @@ int head_blocks(int64_t n_edges) {
 }
 }  // namespace
 
+// three regions of kHeadBlocks * heads entries: partial sums, partial arg-max indices (the max-path step), partial maxima
+// (kept from the logits launch to the max-path launch of an adjoint stage on the raw-logit route)
 extern "C" int64_t gode_gat_heads_scratch_bytes(int64_t n_edges, int64_t heads) {
     (void)n_edges;
     if (heads < 1) heads = 1;
-    return (int64_t)kHeadBlocks * heads * (int64_t)(sizeof(float) + sizeof(int));
+    return (int64_t)kHeadBlocks * heads * (int64_t)(2 * sizeof(float) + sizeof(int));
 }
+extern "C" int64_t gode_gat_heads_parts(int64_t n_edges) { return head_blocks(n_edges); }
 
 extern "C" int gode_gat_logits_heads_f32(const gode_gat_proj_t* proj, const float* bw, const int32_t* src,
                                          const int32_t* tgt, int64_t n_edges, int64_t heads, float* a, float* hmax,
@@ -1362,7 +1386,73 @@ extern "C" int gode_gat_maxpath_heads_f32(const float* a, float* da, int64_t n_e
     { const int rc = gode_set_lds_once((const void*)gat_maxpath_heads_part_kernel, (size_t)heads * 256 * sizeof(float));
       if (rc) return rc; }
     hipLaunchKernelGGL(gat_maxpath_heads_part_kernel, dim3(nb), dim3(256), (size_t)heads * 256 * sizeof(float), s, a,
-                       (const float*)da, tgt, (int)n_edges, (int)heads, psum, pidx);
+                       (const float*)da, tgt, (int)n_edges, (int)heads, psum, pidx, (const float*)nullptr, 0);
+    GODE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gat_maxpath_heads_final_kernel, dim3(1), dim3(64), 0, s, (const float*)psum, (const int*)pidx, nb,
+                       (int)heads, da, (int)n_edges, tgt, dat, ld_dat);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the raw-logit route of the H-head function: no launch that shifts the logits ---------------------------------
+// logits_heads_raw: a[e] = As[src] + At[tgt] + bw[head] and the per-block partial maxima (third scratch region);
+// agg_heads_fwd: the aggregation with every row shifted by its head's maximum, reduced from those partials in the kernel;
+// maxpath_heads_raw: the max-path step on raw logits (arg-max = first edge whose logit equals its head's maximum).
+extern "C" int gode_gat_logits_heads_raw_f32(const gode_gat_proj_t* proj, const float* bw, const int32_t* src,
+                                             const int32_t* tgt, int64_t n_edges, int64_t heads, float* a, void* scratch,
+                                             void* stream) {
+    if (!proj) return GODE_E_NULLPTR;
+    if (n_edges < 0 || heads < 1) return GODE_E_SHAPE;
+    if (heads > kMaxHeads) return GODE_E_UNSUPPORTED;
+    if (n_edges > INT32_MAX) return GODE_E_RANGE;
+    if (n_edges == 0) return 0;
+    const Proj pv = proj_of(proj);
+    if (!pv.as || !pv.at || !src || !tgt || !a || !scratch) return GODE_E_NULLPTR;
+    if (pv.lda < 1) return GODE_E_SHAPE;
+    const int nb = head_blocks(n_edges);
+    float* pmax = (float*)scratch + 2 * (int64_t)kHeadBlocks * heads;
+    hipLaunchKernelGGL(gat_logits_heads_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pv, bw, src, tgt, (int)n_edges,
+                       (int)heads, a, pmax);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_gat_agg_heads_f32_fwd(const gode_graph_t* mt, const int32_t* src, const int32_t* tgt,
+                                          const gode_gat_proj_t* proj, int64_t o, const float* bf, const float* a,
+                                          const void* scratch, int64_t n_edges, int64_t heads, float eps, float* out,
+                                          float* w_out, float* den_out, void* stream) {
+    if (!mt || !proj || !scratch) return GODE_E_NULLPTR;
+    const int64_t n_rows = mt->n_rows;
+    if (n_rows < 0 || o <= 0 || heads < 1 || n_edges < 0) return GODE_E_SHAPE;
+    if (heads > kMaxHeads) return GODE_E_UNSUPPORTED;
+    if (n_rows == 0) return 0;
+    if (!mt->rowptr || !out || !den_out) return GODE_E_NULLPTR;
+    if (mt->nnz > 0 && (!src || !tgt || !a || !w_out)) return GODE_E_NULLPTR;
+    if (n_rows > INT32_MAX || o > 512) return (o > 512) ? GODE_E_UNSUPPORTED : GODE_E_RANGE;
+    const Proj pv = proj_of(proj);
+    int rc = check_proj(pv, o); if (rc) return rc;
+    HeadMax hm;
+    hm.pmax = (const float*)scratch + 2 * (int64_t)kHeadBlocks * heads; hm.n_part = n_edges > 0 ? head_blocks(n_edges) : 0; hm.H = (int)heads;
+    return launch_agg_fwd(mt->rowptr, mt->col, mt->val, src, tgt, pv, o, bf, a, nullptr, eps, n_rows, out, w_out, den_out,
+                          (hipStream_t)stream, hm);
+}
+
+extern "C" int gode_gat_maxpath_heads_raw_f32(const float* a, float* da, int64_t n_edges, int64_t heads, const int32_t* tgt,
+                                              float* dat, int64_t ld_dat, void* scratch, void* stream) {
+    if (n_edges < 0 || heads < 1) return GODE_E_SHAPE;
+    if (heads > kMaxHeads) return GODE_E_UNSUPPORTED;
+    if (n_edges > INT32_MAX) return GODE_E_RANGE;
+    if (n_edges == 0) return 0;
+    if (!a || !da || !tgt || !scratch) return GODE_E_NULLPTR;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = head_blocks(n_edges);
+    float* psum = (float*)scratch;
+    int* pidx = (int*)(psum + (int64_t)kHeadBlocks * heads);
+    const float* pmax = psum + 2 * (int64_t)kHeadBlocks * heads;
+    { const int rc = gode_set_lds_once((const void*)gat_maxpath_heads_part_kernel, (size_t)heads * 256 * sizeof(float));
+      if (rc) return rc; }
+    hipLaunchKernelGGL(gat_maxpath_heads_part_kernel, dim3(nb), dim3(256), (size_t)heads * 256 * sizeof(float), s, a,
+                       (const float*)da, tgt, (int)n_edges, (int)heads, psum, pidx, pmax, nb);
     GODE_LAUNCH_CHECK();
     hipLaunchKernelGGL(gat_maxpath_heads_final_kernel, dim3(1), dim3(64), 0, s, (const float*)psum, (const int*)pidx, nb,
                        (int)heads, da, (int)n_edges, tgt, dat, ld_dat);

@@ -63,6 +63,11 @@ inline bool small_dense(const gode_gat_odefunc_t* f) {
     return gode_opt_small_fused() && gode_gat_small_supported(f->n, f->d, f->groups, n_heads(f));
 }
 
+// the same condition as gat_heads.GatHeadsField.raw_logits (the Python and the C driver issue the same launches)
+inline bool raw_logits(const gode_gat_odefunc_t* f) {
+    return f->n * n_heads(f) <= 65536 && f->n_edges > 8192 && small_dense(f);
+}
+
 // Ps, Pt, A2 of the stage input; a multi-term input is combined once (x_out) and read back as one array afterwards
 int project(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lincomb_t* yin, float t, void* stream) {
     const int64_t n = f->n, d = f->d;
@@ -93,6 +98,11 @@ int eval_forward(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
     const gode_gat_proj_t pr = proj_of(f, w);
     const int64_t H = n_heads(f);
     if (H > 1) {     // logits shifted by their head's maximum (so the aggregation runs with amax = 0), biases in Pt
+        if (raw_logits(f)) {     // launch-bound graphs: no launch that shifts the logits (csrc/edge.hip, HeadMax)
+            GODE_TRY(gode_gat_logits_heads_raw_f32(&pr, f->bw, f->src, f->tgt, f->n_edges, H, w->a, w->heads_scratch, stream));
+            return gode_gat_agg_heads_f32_fwd(&f->mt, f->src, f->tgt, &pr, f->d / H, w->zeros, w->a, w->heads_scratch, f->n_edges, H,
+                                              f->eps, ky, w->wgt, w->den, stream);
+        }
         GODE_TRY(gode_gat_logits_heads_f32(&pr, f->bw, f->src, f->tgt, f->n_edges, H, w->a, nullptr, w->heads_scratch, stream));
         return gode_gat_agg_f32_fwd(&f->mt, f->src, f->tgt, &pr, f->d / H, w->zeros, w->a, w->zeros, f->eps, ky, w->wgt, w->den,
                                     stream);
@@ -112,7 +122,10 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
     GODE_TRY(gode_gat_agg_f32_bwd(&f->mt, f->src, f->tgt, &pr, o, H > 1 ? w->zeros : f->bf, w->wgt, w->den, ky, nullptr, &ain,
                                   -1.f, w->dz, w->da, w->dPt, o, w->dA2 + 1, 2, &did, stream));
     if (f->n_edges > 0) {
-        if (H > 1)
+        if (H > 1 && raw_logits(f))
+            GODE_TRY(gode_gat_maxpath_heads_raw_f32(w->a, w->da, f->n_edges, H, f->tgt, did ? w->dA2 + 1 : nullptr, 2,
+                                                    w->heads_scratch, stream));
+        else if (H > 1)
             GODE_TRY(gode_gat_maxpath_heads_f32(w->a, w->da, f->n_edges, H, f->tgt, did ? w->dA2 + 1 : nullptr, 2,
                                                 w->heads_scratch, stream));
         else

@@ -304,9 +304,18 @@ class GatHeadsField(GatOdeField):
     def _forward(self, t, y_terms, out):
         s, w, eg = self.s, self.w, self.s.eg
         terms = self._project(t, y_terms)
+        if self.raw_logits():
+            # launch-bound graphs: no launch that shifts the logits - the aggregation reduces its head's partial maxima
+            ops.gat_logits_heads_raw(w.proj, eg.src, eg.tgt, s.heads, w.a, w.heads_scratch, bw=s.bw)
+            ops.gat_agg_heads_fwd(eg, w.proj, s.o, w.bf0, w.a, w.heads_scratch, s.heads, s.eps, out.view(s.n * s.heads, s.o),
+                                  w.wgt, w.den)
+            return terms
         ops.gat_logits_heads(w.proj, eg.src, eg.tgt, s.heads, w.a, bw=s.bw)
         ops.gat_agg_fwd(eg, w.proj, s.o, w.bf0, w.a, w.zero, s.eps, out.view(s.n * s.heads, s.o), w.wgt, w.den)
         return terms
+
+    def raw_logits(self):
+        return self.s.n * self.s.heads <= 65536 and self.s.eg.E > 8192 and self.small()
 
 
 class GatHeadsAdjointField(GatHeadsField):
@@ -342,7 +351,8 @@ class GatHeadsAdjointField(GatHeadsField):
         xt = self._forward(t, terms[0], out[0])
         g = s.views(out[3])
         ops.gat_vjp(eg, w.proj, o, w.bf0, w.a, w.zero, w.wgt, w.den, out[0].view(nv, o), w.dz, w.da, w.dPs.view(nv, o),
-                    w.dPt.view(nv, o), w.dA2.view(nv, 2), cot_terms=terms[1], cot_scale=-1.0, heads=H)
+                    w.dPt.view(nv, o), w.dA2.view(nv, 2), cot_terms=terms[1], cot_scale=-1.0, heads=H,
+                    raw_scratch=w.heads_scratch if self.raw_logits() else None)
         if self.small():
             ops.gat_dense_vjp_small(xt, n, d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, H, w.dPs, w.dPt, w.dA2,
                                     out[1], w.small_part)

@@ -530,8 +530,31 @@ def gat_logits_heads(proj, src, tgt, heads, a, hmax=None, bw=None):
                                         stream_ptr()), "gode_gat_logits_heads_f32")
 
 
+def gat_logits_heads_raw(proj, src, tgt, heads, a, scratch, bw=None):
+    """Raw logits of the H-fold graph (+ bw[head]) and per-block partial maxima in `scratch` (caller-owned, at least
+    gode_gat_heads_scratch_bytes; it must stay untouched until the stage's gat_vjp(..., raw_scratch=scratch))."""
+    lib = _lib.load()
+    _need(a, "a"); _need(bw, "bw"); _need(scratch, "scratch", torch.uint8)
+    E = src.numel()
+    if scratch.numel() * scratch.element_size() < lib.gode_gat_heads_scratch_bytes(E, heads):
+        raise ValueError("gat_logits_heads_raw: scratch too small")
+    check(lib.gode_gat_logits_heads_raw_f32(ctypes.byref(proj), ptr(bw), ptr(src), ptr(tgt), E, int(heads), ptr(a), ptr(scratch),
+                                            stream_ptr()), "gode_gat_logits_heads_raw_f32")
+
+
+def gat_agg_heads_fwd(eg, proj, o, bf, a, scratch, heads, eps, out, w, den):
+    """gat_agg_fwd on the H-fold graph with every row shifted by its head's maximum (reduced in the kernel from the partial
+    maxima gat_logits_heads_raw left in `scratch`)."""
+    lib = _lib.load()
+    _need(out, "out"); _need(w, "w"); _need(den, "den"); _need(bf, "bf"); _need(scratch, "scratch", torch.uint8)
+    gs = _edge_csr(eg, o + 4)
+    check(lib.gode_gat_agg_heads_f32_fwd(ctypes.byref(gs), ptr(eg.src), ptr(eg.tgt), ctypes.byref(proj), o, ptr(bf), ptr(a),
+                                         ptr(scratch), eg.E, int(heads), float(eps), ptr(out), ptr(w), ptr(den), stream_ptr()),
+          "gode_gat_agg_heads_f32_fwd")
+
+
 def gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=None, cot_terms=None, cot_scale=1.0,
-            heads=1):
+            heads=1, raw_scratch=None):
     """Vector-Jacobian product of the edge-attention aggregation w.r.t. the projections: fills dz[E, o], da[E] (with the
     path through the global maximum folded in), dPs, dPt (N x o) and dA2 (N x 2).  The cotangent is `dout`, or
     cot_scale * (sum cot_terms) masked by out > 0.  heads > 1: `eg` is the H-fold graph, `a` holds logits shifted
@@ -553,7 +576,11 @@ def gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=N
                                    ptr(den), ptr(out), ptr(dout), ctypes.byref(lc) if lc is not None else None,
                                    float(cot_scale), ptr(dz), ptr(da), ptr(dPt), o, at_ptr, 2, ctypes.byref(did),
                                    stream_ptr()), "gode_gat_agg_f32_bwd")
-    if eg.E > 0 and heads > 1:
+    if eg.E > 0 and heads > 1 and raw_scratch is not None:         # raw logits + partial maxima (gat_logits_heads_raw)
+        big = bool(did.value)
+        check(lib.gode_gat_maxpath_heads_raw_f32(ptr(a), ptr(da), eg.E, int(heads), ptr(eg.tgt), at_ptr if big else None, 2,
+                                                 ptr(raw_scratch), stream_ptr()), "gode_gat_maxpath_heads_raw_f32")
+    elif eg.E > 0 and heads > 1:
         big = bool(did.value)
         sc = _scratch(a.device, lib.gode_gat_heads_scratch_bytes(eg.E, heads))
         check(lib.gode_gat_maxpath_heads_f32(ptr(a), ptr(da), eg.E, int(heads), ptr(eg.tgt), at_ptr if big else None, 2,

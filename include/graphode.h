@@ -322,6 +322,19 @@ int gode_gat_logits_heads_f32(const gode_gat_proj_t* proj, const float* bw /* nu
                               float* hmax, void* scratch, void* stream);
 int gode_gat_maxpath_heads_f32(const float* a, float* da, int64_t n_edges, int64_t heads, const int32_t* tgt,
                                float* dat, int64_t ld_dat, void* scratch, void* stream);
+/* The same three steps WITHOUT the launch that shifts the logits (launch-bound graphs): logits_heads_raw leaves raw logits in
+ * a and per-block partial maxima in `scratch` (which must then stay untouched until the stage's max-path step);
+ * agg_heads_fwd is gode_gat_agg_f32_fwd on the H-fold graph with every virtual row shifted by its head's maximum, reduced
+ * from those partials inside the kernel (same arithmetic: exp(a - max)); maxpath_heads_raw is the max-path step on raw
+ * logits (e* = the first edge whose logit EQUALS its head's maximum).  Up to 65 536 virtual rows. */
+int64_t gode_gat_heads_parts(int64_t n_edges);
+int gode_gat_logits_heads_raw_f32(const gode_gat_proj_t* proj, const float* bw, const int32_t* src, const int32_t* tgt,
+                                  int64_t n_edges, int64_t heads, float* a, void* scratch, void* stream);
+int gode_gat_agg_heads_f32_fwd(const gode_graph_t* mt, const int32_t* src, const int32_t* tgt, const gode_gat_proj_t* proj,
+                               int64_t o, const float* bf, const float* a, const void* scratch, int64_t n_edges,
+                               int64_t heads, float eps, float* out, float* w_out, float* den_out, void* stream);
+int gode_gat_maxpath_heads_raw_f32(const float* a, float* da, int64_t n_edges, int64_t heads, const int32_t* tgt,
+                                   float* dat, int64_t ld_dat, void* scratch, void* stream);
 /* dps[v,:] = sum_{e: src_e = v} dz[e,:], dpt[v,:] = sum_{e: tgt_e = v} dz[e,:], das / dat likewise from da; the
  * incidence lists are CSR (rowptr over nodes, eid = edge ids in increasing order). */
 int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* eid_src, const int32_t* rowptr_tgt,
