@@ -19,6 +19,19 @@ __global__ __launch_bounds__(256) void lincomb4_kernel(float* out, LinComb lc, i
         *reinterpret_cast<float4*>(out + i * 4) = r;
     }
 }
+// Up to four combinations of different lengths in ONE launch (the solution combine of an adjoint state [y, a, a_t, theta]
+// on a launch-bound graph: four launches of ~4.4 us each per RK step otherwise); blockIdx.y selects the combination.
+struct MultiLC { float* out[4]; LinComb lc[4]; int64_t n[4]; int vec[4]; };
+__global__ __launch_bounds__(256) void lincomb_multi_kernel(MultiLC m) {
+    const int c = blockIdx.y;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m.vec[c]) {
+        for (const int64_t n4 = m.n[c] / 4; i < n4; i += stride) *reinterpret_cast<float4*>(m.out[c] + i * 4) = lc_load4(m.lc[c], i * 4);
+    } else {
+        for (; i < m.n[c]; i += stride) m.out[c][i] = lc_load1(m.lc[c], i);
+    }
+}
 __global__ __launch_bounds__(256) void lincomb1_kernel(float* out, LinComb lc, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -364,6 +377,29 @@ extern "C" int gode_lincomb_f32(float* out, const gode_lincomb_t* lc, int64_t n,
         int64_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(lincomb1_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, d, n);
     }
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_lincomb_multi_f32(float* const* outs, const gode_lincomb_t* lcs, const int64_t* ns, int32_t count, void* stream) {
+    if (!outs || !lcs || !ns) return GODE_E_NULLPTR;
+    if (count < 1 || count > 4) return GODE_E_RANGE;
+    MultiLC m;
+    int64_t longest = 0;
+    for (int c = 0; c < 4; ++c) { m.out[c] = nullptr; m.lc[c] = make_lincomb(nullptr); m.n[c] = 0; m.vec[c] = 0; }
+    for (int c = 0; c < count; ++c) {
+        if (ns[c] < 0) return GODE_E_SHAPE;
+        if (ns[c] == 0) continue;
+        if (!outs[c]) return GODE_E_NULLPTR;
+        int rc = check_lincomb(&lcs[c], true); if (rc) return rc;
+        m.out[c] = outs[c]; m.lc[c] = make_lincomb(&lcs[c]); m.n[c] = ns[c];
+        m.vec[c] = (ns[c] % 4 == 0 && !(((uintptr_t)outs[c]) & 15) && lincomb_aligned16(&lcs[c])) ? 1 : 0;
+        const int64_t work = m.vec[c] ? ns[c] / 4 : ns[c];
+        if (work > longest) longest = work;
+    }
+    if (longest == 0) return 0;
+    int64_t blocks = (longest + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(lincomb_multi_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, (hipStream_t)stream, m);
     GODE_LAUNCH_CHECK();
     return 0;
 }

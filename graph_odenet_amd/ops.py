@@ -100,6 +100,26 @@ def lincomb_(out, terms):
     return out
 
 
+def lincomb_multi_(outs, terms_list):
+    """outs[c] = sum_j coef_cj * tensor_cj for up to four components of different lengths, in ONE launch."""
+    lib = _lib.load()
+    k = len(outs)
+    if k != len(terms_list) or not 1 <= k <= 4:
+        raise ValueError("lincomb_multi: one term list per output, at most four")
+    lcs = (_lib.LinComb * k)()
+    ptrs = (ctypes.c_void_p * k)()
+    ns = (ctypes.c_int64 * k)()
+    for c, (out, terms) in enumerate(zip(outs, terms_list)):
+        _need(out, "out")
+        if _need_terms(terms, "lincomb") != out.numel():
+            raise ValueError("lincomb_multi: size mismatch in component %d" % c)
+        lcs[c] = lincomb(terms)
+        ptrs[c] = out.data_ptr()
+        ns[c] = out.numel()
+    check(lib.gode_lincomb_multi_f32(ptrs, lcs, ns, k, stream_ptr()), "gode_lincomb_multi_f32")
+    return outs
+
+
 _red_scratch = {}
 _retired = []      # outgrown scratch buffers stay allocated: captured HIP graphs may still hold their addresses
 

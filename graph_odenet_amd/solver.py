@@ -113,11 +113,20 @@ def integrate_rk4(field, y, t0, t1, n_steps, work=None):
         else:
             field.eval(t + RK38_C[3] * h, _stage_terms(y, ks, RK38_A[3], h), ks[3])
         nfe += 4
+        todo = []
         for c in range(nc):
             if c in done:
                 y[c], ks[3][c] = ks[3][c], y[c]        # ks[3][c] already holds the new solution
             else:
-                ops.lincomb_(y[c], [(1.0, y[c])] + [(h * RK38_B[s], ks[s][c]) for s in range(4)])
+                todo.append(c)
+        # the remaining components in one launch per group of four (an adjoint state has four: one launch instead of four)
+        for g0 in range(0, len(todo), 4):
+            grp = todo[g0:g0 + 4]
+            terms = [[(1.0, y[c])] + [(h * RK38_B[s], ks[s][c]) for s in range(4)] for c in grp]
+            if len(grp) == 1:
+                ops.lincomb_(y[grp[0]], terms[0])
+            else:
+                ops.lincomb_multi_([y[c] for c in grp], terms)
     return nfe
 
 

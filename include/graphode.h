@@ -112,6 +112,9 @@ int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* va
 /* ---- Runge-Kutta elementwise steps -------------------------------------- */
 /* out[i] = sum_j lc.coef[j]*lc.ptr[j][i],  i < n.  out may alias any ptr[j]. */
 int gode_lincomb_f32(float* out, const gode_lincomb_t* lc /* host */, int64_t n, void* stream);
+/* up to four such combinations of different lengths in one launch (the components of an adjoint state) */
+int gode_lincomb_multi_f32(float* const* outs /* host[count] */, const gode_lincomb_t* lcs /* host[count] */,
+                           const int64_t* ns /* host[count] */, int32_t count, void* stream);
 
 /* dopri5 acceptance test (torchdiffeq _compute_error_ratio):
  *   err = sum_j elc.coef[j]*elc.ptr[j][i];  tol = atol + rtol*max(|y0[i]|,|y1[i]|)

@@ -721,3 +721,28 @@ def test_one_launch_adam_matches_torch_adam():
     o_new = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in got], **kw)
     o_new.load_state_dict(sd)                                     # torch's keys: step, exp_avg, exp_avg_sq
     assert float(o_new.state[o_new.param_groups[0]["params"][0]]["step"]) == 8.0
+
+
+def test_lincomb_multi_one_launch_for_four_components():
+    """gode_lincomb_multi_f32: the solution combine of an adjoint state [y, a, a_t, theta] as one launch - components of
+    different lengths (one of them a single float, one not a multiple of four), in place on the first term, bit for bit the
+    result of four gode_lincomb_f32 launches."""
+    from graph_odenet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    sizes = [3327 * 16, 3327 * 16, 1, 611]
+    D = dev()
+    ys = [torch.randn(n, generator=g).to(D) for n in sizes]
+    ks = [[torch.randn(n, generator=g).to(D) for n in sizes] for _ in range(4)]
+    coefs = [0.125, 0.375, 0.375, 0.125]
+    want = []
+    for c in range(4):
+        o = ys[c].clone()
+        ops.lincomb_(o, [(1.0, o)] + [(coefs[s], ks[s][c]) for s in range(4)])
+        want.append(o)
+    got = [y.clone() for y in ys]
+    ops.lincomb_multi_(got, [[(1.0, got[c])] + [(coefs[s], ks[s][c]) for s in range(4)] for c in range(4)])
+    for c in range(4):
+        assert torch.equal(got[c], want[c]), c
+    two = [ys[0].clone(), ys[3].clone()]
+    ops.lincomb_multi_(two, [[(2.0, ys[0])], [(1.0, ys[3]), (-1.0, ks[0][3])]])
+    assert torch.equal(two[0], 2.0 * ys[0]) and torch.allclose(two[1], ys[3] - ks[0][3], atol=0, rtol=0)
