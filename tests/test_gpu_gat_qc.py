@@ -802,3 +802,39 @@ def test_fused_lstm_cell_vs_float64(B, I, H, bias):
         for a, b, nm in zip(dev_in, ref_in, ("dx", "dh", "dc", "dw_ih", "dw_hh", "db_ih", "db_hh")):
             if a is not None:
                 close(a.grad, b.grad, 4e-6 * max(1.0, B ** 0.5), nm)
+
+
+@pytest.mark.parametrize("o", [8, 16, 64])
+def test_gat_layer_with_an_aggregation_matrix_that_disagrees_with_tgt(o):
+    """`Mtgt` is an INPUT of the reference's layer (GAT/layers.py:31,53-55), not derived from `tgt`: the messages and logits
+    read x[tgt_e], the sums run over the rows of Mtgt.  Its loaders always pass the incidence of tgt, but a caller may not
+    (EdgeGraph.canonical False: edge-id indirection, per-edge target projections).  Rows of Mtgt here are a random
+    re-assignment of the edges, values not 1, one 90-edge row; widths on both sides of the prefetched-index kernels
+    (o >= 16) and the plain wave kernels (o = 8).  Forward and all gradients against the oracle layer in float64."""
+    from graph_odenet_amd.gat_layers import GraphConvolution
+    from graph_odenet_amd.gat_layers import edge_graph
+    from oracle import layers_ref as R
+    gen = torch.Generator().manual_seed(40 + o)
+    n, E, i = 300, 1500, 12
+    src, tgt = torch.randint(0, n, (E,), generator=gen), torch.randint(0, n, (E,), generator=gen)
+    rows = torch.randint(0, n - 10, (E,), generator=gen)             # where each edge is summed: NOT its tgt
+    rows[:90] = 7                                                     # one long row (two 64-slot chunks)
+    vals = torch.rand(E, generator=gen) + 0.5
+    Mtgt = torch.sparse_coo_tensor(torch.stack([rows, torch.arange(E)]), vals, (n, E)).coalesce()
+    x = torch.randn(n, i, generator=gen)
+    layer = GraphConvolution(i, o)
+    P = [p.detach().double().requires_grad_(True) for p in (layer.f.weight, layer.f.bias, layer.w.weight, layer.w.bias)]
+    x64 = x.double().requires_grad_(True)
+    ref = R.gat_layer(x64, src, tgt, Mtgt.double(), *P)
+    gout = torch.randn(n, o, generator=gen)
+    ref.backward(gout.double())
+    layer = layer.to(dev())
+    xd = x.to(dev()).requires_grad_(True)
+    sd, td, Md = src.to(dev()), tgt.to(dev()), Mtgt.to(dev())
+    assert not edge_graph(sd, td, Md).canonical
+    out = layer(xd, sd, td, Md)
+    close(out, ref, 2e-5, "forward")
+    out.backward(gout.to(dev()))
+    close(xd.grad, x64.grad, 5e-5, "dx")
+    for p, q, nm in zip((layer.f.weight, layer.f.bias, layer.w.weight, layer.w.bias), P, ("f.weight", "f.bias", "w.weight", "w.bias")):
+        close(p.grad, q.grad, 5e-5, nm)
