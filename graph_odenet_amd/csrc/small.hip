@@ -168,7 +168,7 @@ __device__ __forceinline__ float4 gn_backward4(const float4 x, const float4 dy, 
 
 // ---------------------------------------------------------------------------------------------------------------
 // VJP: dS_i = sum_j aT_ij dZ_j;  ka_i = (sum pre)_i + out_scale * GN'(x_i)^T (dS_i W1^T);  block partial row
-// part[block] = [ colsum(dS) | sum_i xn_i^T dS_i  ((D+1) x D, row 0 = time row) | colsum(dZ) | dgamma | dbeta ]
+// part[block] = [ sum_i [1|xn_i]^T dS_i  ((D+1) x D, row 0 = colsum(dS): the time row) | colsum(dZ) | dgamma | dbeta | a_t' share ]
 // ---------------------------------------------------------------------------------------------------------------
 template <int D, int CG>
 __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restrict__ rowptrT, const int* __restrict__ colT,
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
                                                            float* __restrict__ ka, float* __restrict__ part)
 {
     constexpr int LPR = D / 4, SG = 64 / LPR, NS = D / SG, PU = 4;     // NS = columns of dW per lane (1, 4, 16)
-    constexpr int PLEN = (D + 1) * D + 3 * D;
+    constexpr int PLEN = (D + 1) * D + 3 * D + 1;                 // ... | the block's share of a_t' = colsum(dS) . W[0, :]
     __shared__ __attribute__((aligned(16))) float Wt[D * (D + 4)];           // Wt[n][k] = W1[k][n], row stride D + 4
     __shared__ __attribute__((aligned(16))) float dsrow[4][D];
     __shared__ float red[PLEN];
@@ -285,6 +285,13 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
         }
         __syncthreads();
     }
+    if (wave == 0) {                                             // a_t' share: the closing launch then only adds columns
+        float v = 0.f;
+        for (int c = l; c < D; c += 64) v = fmaf(red[c], W[c], v);
+        v = wave_sum(v);
+        if (l == 0) red[PLEN - 1] = v;
+    }
+    __syncthreads();
     float* out = part + (int64_t)blockIdx.x * PLEN;
     for (int i = threadIdx.x; i < PLEN; i += 256) out[i] = red[i];
 }
@@ -294,56 +301,78 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
 // their stage derivatives need not exist as vectors).  Outputs: the (d+1) d + 3 d entries of [W | b | gamma | beta] (row
 // 0 of W - the time row - scaled by the stage time) and a_t = sum_s wb[s] colsum(dS_s) . W[0, :]  (last block).
 struct Finish4 { const float* part[4]; float wb[4]; float ts[4]; };
-// 1 024 threads: 32 part-groups x 32 outputs; a thread has at most 4 x 8 loads (256 partial rows), all independent and in
-// flight together - the launch is one memory round trip, not a loop of them (8 part-groups took 34 us)
-__global__ __launch_bounds__(1024) void small_finish4_kernel(Finish4 g, int n_part, int plen, int d, const float* __restrict__ W0,
-                                                            float* __restrict__ theta, int out_len)
+// 1 024 threads: 32 part-groups x 32 outputs; a thread has 4 x 8 loads per round of 256 partial rows, all independent and
+// in flight together - the launch is one memory round trip, not a loop of them (8 part-groups took 34 us).  Output
+// out_len is a_t: the sum of the blocks' shares (last column of a partial row).
+__global__ __launch_bounds__(1024) void small_finish4_kernel(Finish4 g, int n_part, int plen, int d, float* __restrict__ theta, int out_len)
 {
     __shared__ float sm[32][33];
     const int jj = threadIdx.x & 31, qq = threadIdx.x >> 5;
-    const bool time_block = blockIdx.x == gridDim.x - 1;
-    float at = 0.f;
-    const int n_chunks = time_block ? (d + 31) / 32 : 1;
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        const int j = time_block ? ch * 32 + jj : (int)blockIdx.x * 32 + jj;
-        const int lim = time_block ? d : out_len;
-        float v = 0.f;
-        if (j < lim) {
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int p0 = qq; p0 < n_part; p0 += 256) {
-                float x[4][8];
+    const int j = (int)blockIdx.x * 32 + jj;
+    const int src = j < out_len ? j : (j == out_len ? plen - 1 : -1);
+    float v = 0.f;
+    if (src >= 0) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p0 = qq; p0 < n_part; p0 += 256) {
+            float x[4][8];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int p = p0 + 32 * u;
-                        x[s][u] = p < n_part ? g.part[s][(int64_t)p * plen + j] : 0.f;
-                    }
+                for (int u = 0; u < 8; ++u) {
+                    const int p = p0 + 32 * u;
+                    x[s][u] = p < n_part ? g.part[s][(int64_t)p * plen + src] : 0.f;
+                }
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) a[s] += x[s][u];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float sc = (!time_block && j < d) ? g.wb[s] * g.ts[s] : g.wb[s];
-                v = fmaf(sc, a[s], v);
-            }
+                for (int u = 0; u < 8; ++u) a[s] += x[s][u];
         }
-        sm[qq][jj] = v;
-        __syncthreads();
-        if (qq == 0 && j < lim) {
-            float tsum = sm[0][jj];
 #pragma unroll
-            for (int k = 1; k < 32; ++k) tsum += sm[k][jj];
-            if (time_block) at = fmaf(tsum, W0[j], at);
-            else theta[j] += tsum;
+        for (int s = 0; s < 4; ++s) {
+            const float sc = j < d ? g.wb[s] * g.ts[s] : g.wb[s];       // j < d: the time row of W, scaled by the stage time
+            v = fmaf(sc, a[s], v);
         }
-        __syncthreads();
     }
-    if (time_block && qq == 0) {
-        for (int o = 16; o > 0; o >>= 1) at += __shfl_xor(at, o, 64);
-        if (jj == 0) theta[out_len] += at;
+    sm[qq][jj] = v;
+    __syncthreads();
+    if (qq == 0 && src >= 0) {
+        float tsum = sm[0][jj];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) tsum += sm[k][jj];
+        theta[j] += tsum;
+    }
+}
+
+// one stage: ktheta[j] = (j < d ? t : 1) * sum_p part[p][j], ktheta[out_len] = a_t' = sum_p part[p][plen - 1]; the same
+// shape of launch (an adaptive step closes every stage by itself; the segment-reduction kernel it used walked the partial
+// rows 8 at a time: 34 us for Pubmed's 1 024 rows)
+__global__ __launch_bounds__(1024) void small_finish1_kernel(const float* __restrict__ part, int n_part, int plen, int d, float t,
+                                                            float* __restrict__ ktheta, int out_len)
+{
+    __shared__ float sm[32][33];
+    const int jj = threadIdx.x & 31, qq = threadIdx.x >> 5;
+    const int j = (int)blockIdx.x * 32 + jj;
+    const int src = j < out_len ? j : (j == out_len ? plen - 1 : -1);
+    float v = 0.f;
+    if (src >= 0) {
+        for (int p0 = qq; p0 < n_part; p0 += 32 * 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = p0 + 32 * u;
+                x[u] = p < n_part ? part[(int64_t)p * plen + src] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v += x[u];
+        }
+    }
+    sm[qq][jj] = v;
+    __syncthreads();
+    if (qq == 0 && src >= 0) {
+        float tsum = sm[0][jj];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) tsum += sm[k][jj];
+        ktheta[j] = j < d ? t * tsum : tsum;
     }
 }
 
@@ -361,13 +390,18 @@ int64_t feval_blocks(int64_t n) { int64_t b = (n + 3) / 4; if (b < 1) b = 1; if 
 
 }  // namespace
 
+// one partial row per block: 256 blocks up to 4 096 rows (Cora, Citeseer: 2-3 rows per wave), then rows / 16 up to 1 024
+// (Pubmed's 19 717 rows: 5 rows per wave instead of 19; 40 -> 17 us per VJP launch)
 extern "C" int64_t gode_gcn_small_parts(int64_t n_rows) {
     int64_t b = (n_rows + 3) / 4;
+    int64_t cap = n_rows / 16;
+    if (cap < kSmallPartBlocks) cap = kSmallPartBlocks;
+    if (cap > 4 * kSmallPartBlocks) cap = 4 * kSmallPartBlocks;
     if (b < 1) b = 1;
-    if (b > kSmallPartBlocks) b = kSmallPartBlocks;
+    if (b > cap) b = cap;
     return b;
 }
-extern "C" int64_t gode_gcn_small_part_len(int64_t d) { return (d + 1) * d + 3 * d; }
+extern "C" int64_t gode_gcn_small_part_len(int64_t d) { return (d + 1) * d + 3 * d + 1; }
 
 extern "C" int gode_gcn_small_supported(int64_t n_rows, int64_t d, int32_t groups) {
     return n_rows > 0 && n_rows <= 65536 && small_cg(d, groups) > 0;
@@ -426,18 +460,17 @@ extern "C" int gode_gcn_vjp_small_f32(const gode_gcn_odefunc_t* f, const gode_li
 }
 
 // theta-k = [ W ((d+1) d, row 0 = t * colsum(dS)) | b | gamma | beta | a_t ] from the block partials of
-// gode_gcn_vjp_small_f32, in one launch (a_t = colsum(dS) . W[0, :])
+// gode_gcn_vjp_small_f32, in one launch
 extern "C" int gode_gcn_small_finish_f32(const gode_gcn_odefunc_t* f, const float* part, float* ktheta, float t, void* stream)
 {
     if (!f || !part || !ktheta) return GODE_E_NULLPTR;
-    const int64_t d = f->d, nW = (d + 1) * d, P = nW + 3 * d + 1, plen = gode_gcn_small_part_len(d);
+    const int64_t d = f->d, out_len = (d + 1) * d + 3 * d, plen = gode_gcn_small_part_len(d);
     const int64_t parts = gode_gcn_small_parts(f->n);
-    gode_reduce_seg_t sg[4] = {};
-    sg[0] = {ktheta, part, parts, plen, 0, 1, nW, f->W, d};
-    sg[1] = {ktheta + nW, part, parts, plen, nW, 1, d, nullptr, 0};
-    sg[2] = {ktheta + nW + d, part, parts, plen, nW + d, 1, d, nullptr, 0};
-    sg[3] = {ktheta + nW + 2 * d, part, parts, plen, nW + 2 * d, 1, d, nullptr, 0};
-    return gode_reduce_segments_f32(sg, 4, t, ktheta + (P - 1), stream);
+    const int64_t blocks = (out_len + 1 + 31) / 32;
+    hipLaunchKernelGGL(small_finish1_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, part, (int)parts, (int)plen,
+                       (int)d, t, ktheta, (int)out_len);
+    GODE_LAUNCH_CHECK();
+    return 0;
 }
 
 // theta += sum_s wb[s] * (stage derivative of the small components from the block partials of stage s), s < 4:
@@ -446,13 +479,13 @@ extern "C" int gode_gcn_small_finish4_f32(const gode_gcn_odefunc_t* f, const flo
                                           const float* ts /* host[4] */, void* stream)
 {
     if (!f || !part || !theta || !wb || !ts) return GODE_E_NULLPTR;
-    const int64_t d = f->d, nW = (d + 1) * d, out_len = nW + 3 * d, plen = gode_gcn_small_part_len(d);
+    const int64_t d = f->d, out_len = (d + 1) * d + 3 * d, plen = gode_gcn_small_part_len(d);
     const int64_t parts = gode_gcn_small_parts(f->n);
     Finish4 g;
     for (int s = 0; s < 4; ++s) { g.part[s] = part + (int64_t)s * parts * plen; g.wb[s] = wb[s]; g.ts[s] = ts[s]; }
-    const int64_t blocks = (out_len + 31) / 32 + 1;
+    const int64_t blocks = (out_len + 1 + 31) / 32;
     hipLaunchKernelGGL(small_finish4_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, g, (int)parts, (int)plen,
-                       (int)d, f->W, theta, (int)out_len);
+                       (int)d, theta, (int)out_len);
     GODE_LAUNCH_CHECK();
     return 0;
 }

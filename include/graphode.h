@@ -419,7 +419,7 @@ typedef struct gode_rk4_workspace {
  * everything after the gather row-local (csrc/small.hip).  gode_gcn_feval_small_f32: out = (sum pre) + alpha * relu(z),
  * Y2 (nullable) = (sum cot) * [z > 0].  gode_gcn_vjp_small_f32: ka = (sum pre) + out_scale * GN'(x)^T ((A^T dZ) W1^T) and
  * one block partial row per block in `part` (gode_gcn_small_parts(n) rows of gode_gcn_small_part_len(d) floats:
- * [ [1|xn]^T dS ((d+1) x d) | colsum(dZ) | dgamma | dbeta ]); gode_gcn_small_finish_f32 reduces them into a theta-k
+ * [ [1|xn]^T dS ((d+1) x d) | colsum(dZ) | dgamma | dbeta | the block's share of a_t ]); gode_gcn_small_finish_f32 adds them into a theta-k
  * vector [W | b | gamma | beta | a_t] (row 0 of W scaled by t, a_t = colsum(dS) . W[0,:]).  The rk4 / dopri5 drivers below
  * take this path by themselves (option "small_fused", default 1).  GODE_E_UNSUPPORTED outside the shapes above. */
 int     gode_gcn_small_supported(int64_t n_rows, int64_t d, int32_t groups);
