@@ -30,12 +30,15 @@ Proj proj_of(const gode_gat_proj_t* p) { return Proj{p->ps, p->ld_s, p->pt, p->l
 // themselves - one more load level inside a kernel instead of a launch that rewrites every logit (7.3 us x 129 per
 // Citeseer step).  H == 0: one global maximum at amax[0].
 struct HeadMax { const float* pmax; int n_part; int H; };
-__device__ __forceinline__ float shift_of(const HeadMax& hm, const float* amax, int row, int lane) {
+// `width` lanes (a power of two: the whole wave, or the lanes that share a row when a wave works on several rows) reduce
+// together; `lane` is the lane's index inside its group.
+__device__ __forceinline__ float shift_of(const HeadMax& hm, const float* amax, int row, int lane, int width = 64) {
     if (hm.H <= 0) return amax[0];
     const int h = row % hm.H;
     float m = -INFINITY;
-    for (int b = lane; b < hm.n_part; b += 64) m = fmaxf(m, hm.pmax[b * hm.H + h]);
-    return wave_max(m);
+    for (int b = lane; b < hm.n_part; b += width) m = fmaxf(m, hm.pmax[b * hm.H + h]);
+    for (int off = width >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    return m;
 }
 
 __device__ __forceinline__ float block_max(float v) {
@@ -289,7 +292,10 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_wave_kernel(const int* __rest
 // to back, so a hub costs about as many round trips as a leaf.
 __device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int LPR>
+// GW = lanes that share a row: 64 (a wave per row) or 16 (four rows per wave, for narrow rows: eight heads of 8 columns on
+// the H-fold graph are 26 616 virtual rows of ~4 edges - a wave per row left three quarters of the prefetch lanes idle).  A
+// chunk is GW CSR slots; NS = GW / LPR edges are gathered per trip.
+template <int LPR, int GW>
 __global__ __launch_bounds__(256) void gat_agg_fwd_pf_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                              const float* __restrict__ val,
                                                              const int* __restrict__ src, const int* __restrict__ tgt,
@@ -297,19 +303,19 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_pf_kernel(const int* __restri
                                                              const float* __restrict__ amax, HeadMax hm, float eps, int n_rows,
                                                              float* __restrict__ out, float* __restrict__ w_out,
                                                              float* __restrict__ s_out) {
-    constexpr int O = 4 * LPR, NS = 64 / LPR, U = LPR < 4 ? LPR : 4;
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (v >= n_rows) return;
-    const int l = threadIdx.x & 63, q = l & (LPR - 1), sg = l / LPR;
+    constexpr int O = 4 * LPR, NS = GW / LPR, U = LPR < 4 ? LPR : 4, RPW = 64 / GW;
+    const int l = threadIdx.x & 63, gl = l & (GW - 1), q = gl & (LPR - 1), sg = gl / LPR;
+    const int v = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + l / GW;
+    if (v >= n_rows) return;                                   // whole groups leave together
     const int b = rowptr[v], end = rowptr[v + 1];
-    const float m = shift_of(hm, amax, v, l);
+    const float m = shift_of(hm, amax, v, gl, GW);
     const float4 bias = bf ? ldf4(bf + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 cv = ldf4(pv.pt + (int64_t)v * pv.ldt + 4 * q);
     cv.x += bias.x; cv.y += bias.y; cv.z += bias.z; cv.w += bias.w;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float s = 0.f;
-    for (int base = b; base < end; base += 64) {
-        const int k = base + l;
+    for (int base = b; base < end; base += GW) {
+        const int k = base + gl;
         int sc = 0, tg = v; float we = 0.f;
         if (k < end) {
             const int e = eid ? eid[k] : k;
@@ -318,19 +324,18 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_pf_kernel(const int* __restri
             w_out[e] = w;
             we = (val ? val[k] : 1.f) * w;
         }
-        const bool own = __all(tg == v);                       // canonical incidence: every edge of the row targets the row
         const int cnt = end - base;
         for (int u0 = 0; u0 < LPR; u0 += U) {
             if (u0 * NS >= cnt) break;
             float4 xv[U], cc[U]; float wj[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = (u0 + u) * NS + sg;              // < 64; lanes beyond the row carry weight 0 and row 0
-                const int sj = __shfl(sc, j, 64), tj = __shfl(tg, j, 64);
-                wj[u] = __shfl(we, j, 64);
+                const int j = (u0 + u) * NS + sg;              // < GW; slots beyond the row carry weight 0 and row 0
+                const int sj = __shfl(sc, j, GW), tj = __shfl(tg, j, GW);
+                wj[u] = __shfl(we, j, GW);
                 xv[u] = ldf4(pv.ps + (int64_t)sj * pv.lds + 4 * q);
-                if (own) cc[u] = cv;
-                else {
+                cc[u] = cv;
+                if (tj != v) {                                 // an aggregation matrix that disagrees with tgt (never from the reference's loaders)
                     cc[u] = ldf4(pv.pt + (int64_t)tj * pv.ldt + 4 * q);
                     cc[u].x += bias.x; cc[u].y += bias.y; cc[u].z += bias.z; cc[u].w += bias.w;
                 }
@@ -344,17 +349,17 @@ __global__ __launch_bounds__(256) void gat_agg_fwd_pf_kernel(const int* __restri
         }
     }
 #pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
+    for (int off = LPR; off < GW; off <<= 1) {
         s += __shfl_xor(s, off, 64);
         acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
         acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
     }
     const float den = s + eps;
-    if (l == 0) s_out[v] = den;
+    if (gl == 0) s_out[v] = den;
     if (sg == 0) *reinterpret_cast<float4*>(out + (int64_t)v * O + 4 * q) = make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den);
 }
 
-template <int LPR>
+template <int LPR, int GW>
 __global__ __launch_bounds__(256) void gat_agg_bwd_pf_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                              const float* __restrict__ val,
                                                              const int* __restrict__ src, const int* __restrict__ tgt,
@@ -362,10 +367,10 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_pf_kernel(const int* __restri
                                                              const float* __restrict__ den, const float* __restrict__ out,
                                                              const float* __restrict__ dout, LinComb cot, float cot_scale,
                                                              int n_rows, float* __restrict__ dz, float* __restrict__ da) {
-    constexpr int O = 4 * LPR, NS = 64 / LPR, U = LPR < 4 ? LPR : 4;
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int O = 4 * LPR, NS = GW / LPR, U = LPR < 4 ? LPR : 4, RPW = 64 / GW;
+    const int l = threadIdx.x & 63, gl = l & (GW - 1), q = gl & (LPR - 1), sg = gl / LPR;
+    const int v = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + l / GW;
     if (v >= n_rows) return;
-    const int l = threadIdx.x & 63, q = l & (LPR - 1), sg = l / LPR;
     const int b = rowptr[v], end = rowptr[v + 1];
     const float dn = den[v];
     const int64_t ro = (int64_t)v * O + 4 * q;
@@ -384,11 +389,10 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_pf_kernel(const int* __restri
     const float4 bias = bf ? ldf4(bf + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 cv = ldf4(pv.pt + (int64_t)v * pv.ldt + 4 * q);
     cv.x += bias.x; cv.y += bias.y; cv.z += bias.z; cv.w += bias.w;
-    for (int base = b; base < end; base += 64) {
-        const int k = base + l;
+    for (int base = b; base < end; base += GW) {
+        const int k = base + gl;
         int e = 0, sc = 0, tg = v; float we = 0.f, vv = 0.f;
         if (k < end) { e = eid ? eid[k] : k; sc = src[e]; tg = tgt[e]; we = w[e]; vv = val ? val[k] : 1.f; }
-        const bool own = __all(tg == v);
         const int cnt = end - base;
         for (int u0 = 0; u0 < LPR; u0 += U) {
             if (u0 * NS >= cnt) break;
@@ -396,10 +400,10 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_pf_kernel(const int* __restri
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int j = (u0 + u) * NS + sg;
-                const int sj = __shfl(sc, j, 64), tj = __shfl(tg, j, 64);
+                const int sj = __shfl(sc, j, GW), tj = __shfl(tg, j, GW);
                 xv[u] = ldf4(pv.ps + (int64_t)sj * pv.lds + 4 * q);
-                if (own) cc[u] = cv;
-                else {
+                cc[u] = cv;
+                if (tj != v) {
                     cc[u] = ldf4(pv.pt + (int64_t)tj * pv.ldt + 4 * q);
                     cc[u].x += bias.x; cc[u].y += bias.y; cc[u].z += bias.z; cc[u].w += bias.w;
                 }
@@ -407,8 +411,8 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_pf_kernel(const int* __restri
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int j = (u0 + u) * NS + sg;
-                const int ej = __shfl(e, j, 64);
-                const float wej = __shfl(we, j, 64), vj = __shfl(vv, j, 64);
+                const int ej = __shfl(e, j, GW);
+                const float wej = __shfl(we, j, GW), vj = __shfl(vv, j, GW);
                 const float4 z = make_float4(xv[u].x + cc[u].x, xv[u].y + cc[u].y, xv[u].z + cc[u].z, xv[u].w + cc[u].w);
                 float part = (dA.x * fmaxf(z.x, 0.f) + dA.y * fmaxf(z.y, 0.f)) + (dA.z * fmaxf(z.z, 0.f) + dA.w * fmaxf(z.w, 0.f));
 #pragma unroll
@@ -426,17 +430,17 @@ __global__ __launch_bounds__(256) void gat_agg_bwd_pf_kernel(const int* __restri
 }
 
 // both incidence sums of the VJP (over the edges leaving a node and over those entering it), prefetched the same way
-template <int LPR>
+template <int LPR, int GW>
 __global__ __launch_bounds__(256) void gat_scatter_pf_kernel(const int* __restrict__ rp_s, const int* __restrict__ e_s,
                                                              const int* __restrict__ rp_t, const int* __restrict__ e_t,
                                                              const float* __restrict__ dz, const float* __restrict__ da,
                                                              int n_rows, float* __restrict__ dps, int64_t lds,
                                                              float* __restrict__ dpt, int64_t ldt, float* __restrict__ das,
                                                              float* __restrict__ dat, int64_t lda) {
-    constexpr int O = 4 * LPR, NS = 64 / LPR, U = LPR < 4 ? LPR : 4;
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int O = 4 * LPR, NS = GW / LPR, U = LPR < 4 ? LPR : 4, RPW = 64 / GW;
+    const int l = threadIdx.x & 63, gl = l & (GW - 1), q = gl & (LPR - 1), sg = gl / LPR;
+    const int v = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + l / GW;
     if (v >= n_rows) return;
-    const int l = threadIdx.x & 63, q = l & (LPR - 1), sg = l / LPR;
     const int bs = rp_s[v], es = rp_s[v + 1], bt = rp_t[v], et = rp_t[v + 1];
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
@@ -444,8 +448,8 @@ __global__ __launch_bounds__(256) void gat_scatter_pf_kernel(const int* __restri
         const int b = side == 0 ? bs : bt, end = side == 0 ? es : et;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float sa = 0.f;
-        for (int base = b; base < end; base += 64) {
-            const int k = base + l;
+        for (int base = b; base < end; base += GW) {
+            const int k = base + gl;
             int e = -1;
             if (k < end) { e = ee[k]; sa += da[e]; }
             const int cnt = end - base;
@@ -454,22 +458,23 @@ __global__ __launch_bounds__(256) void gat_scatter_pf_kernel(const int* __restri
                 float4 xv[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int ej = __shfl(e, (u0 + u) * NS + sg, 64);
+                    const int ej = __shfl(e, (u0 + u) * NS + sg, GW);
                     xv[u] = ej >= 0 ? ldf4(dz + (int64_t)ej * O + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) { acc.x += xv[u].x; acc.y += xv[u].y; acc.z += xv[u].z; acc.w += xv[u].w; }
             }
         }
-        sa = wave_sum(sa);
 #pragma unroll
-        for (int off = LPR; off < 64; off <<= 1) {
+        for (int off = 1; off < GW; off <<= 1) sa += __shfl_xor(sa, off, 64);
+#pragma unroll
+        for (int off = LPR; off < GW; off <<= 1) {
             acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
             acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
         }
         float* dp = side == 0 ? dps + (int64_t)v * lds : dpt + (int64_t)v * ldt;
         if (sg == 0) *reinterpret_cast<float4*>(dp + 4 * q) = acc;
-        if (l == 0) (side == 0 ? das : dat)[(int64_t)v * lda] = sa;
+        if (gl == 0) (side == 0 ? das : dat)[(int64_t)v * lda] = sa;
     }
 }
 
@@ -1102,11 +1107,11 @@ int check_proj(const Proj& p, int64_t o) {
     return 0;
 }
 
-// the prefetched-index kernels: float4 lanes over o in {4, 8, 16, 32, 64}, 16-byte aligned rows
-// (o >= 16: at 8 columns - eight heads of 8 on the H-fold graph - two lanes per edge leave the prefetch stage mostly idle
-// and the plain wave kernels are faster: 9.2 / 10.5 us against 12.0 / 18.9 us on Citeseer x 8 heads)
+// the prefetched-index kernels: float4 lanes over o in {4, 8, 16, 32, 64} (4 and 8: four rows per wave), 16-byte aligned rows
+// (o = 8 - eight heads of 8 on the H-fold graph - runs four rows per wave, GW = 16: with a wave per row two lanes per edge left
+// the prefetch stage mostly idle and the plain wave kernels were faster, 9.2 / 10.5 us against 12.0 / 18.9 us on Citeseer)
 bool pf_ok(const Proj& pv, int64_t o, const void* p0, const void* p1) {
-    if (o != 16 && o != 32 && o != 64) return false;
+    if (o != 4 && o != 8 && o != 16 && o != 32 && o != 64) return false;
     if ((pv.lds % 4) || (pv.ldt % 4)) return false;
     const uintptr_t al = (uintptr_t)pv.ps | (uintptr_t)pv.pt | (uintptr_t)p0 | (uintptr_t)p1;
     return !(al & 15);
@@ -1136,9 +1141,9 @@ int launch_agg_fwd(const int32_t* rowptr, const int32_t* eid, const float* val, 
     if (hm.H > 0 && !wave) return GODE_E_UNSUPPORTED;          // per-head partial maxima: wave kernels only
     const int64_t blocks = wave ? (n_rows + 3) / 4 : (n_rows * G + 255) / 256;
     if (wave && pf_ok(pv, o, out, bf)) {
-#define GODE_PF(L) hipLaunchKernelGGL(gat_agg_fwd_pf_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, src, tgt, \
-                                      pv, bf, a, amax, hm, eps, (int)n_rows, out, w_out, den_out)
-        switch ((int)o / 4) { case 4: GODE_PF(4); break; case 8: GODE_PF(8); break; default: GODE_PF(16); break; }
+#define GODE_PF(L, W) hipLaunchKernelGGL((gat_agg_fwd_pf_kernel<L, W>), dim3((unsigned)((n_rows + 4 * (64 / W) - 1) / (4 * (64 / W)))), dim3(256), 0, s, \
+                                         rowptr, eid, val, src, tgt, pv, bf, a, amax, hm, eps, (int)n_rows, out, w_out, den_out)
+        switch ((int)o / 4) { case 1: GODE_PF(1, 16); break; case 2: GODE_PF(2, 16); break; case 4: GODE_PF(4, 64); break; case 8: GODE_PF(8, 64); break; default: GODE_PF(16, 64); break; }
 #undef GODE_PF
         GODE_LAUNCH_CHECK();
         return 0;
@@ -1167,9 +1172,9 @@ int launch_agg_bwd(const int32_t* rowptr, const int32_t* eid, const float* val, 
     bool cot_al = true;
     for (int j = 0; j < cot.n; ++j) cot_al = cot_al && !(((uintptr_t)cot.ptr[j]) & 15);
     if (wave && n_rows <= kWaveRows && cot_al && pf_ok(pv, o, out, bf) && !((((uintptr_t)dz) | ((uintptr_t)dout)) & 15)) {
-#define GODE_PF(L) hipLaunchKernelGGL(gat_agg_bwd_pf_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr, eid, val, src, tgt, \
-                                      pv, bf, w, den, out, dout, cot, cot_scale, (int)n_rows, dz, da)
-        switch ((int)o / 4) { case 4: GODE_PF(4); break; case 8: GODE_PF(8); break; default: GODE_PF(16); break; }
+#define GODE_PF(L, W) hipLaunchKernelGGL((gat_agg_bwd_pf_kernel<L, W>), dim3((unsigned)((n_rows + 4 * (64 / W) - 1) / (4 * (64 / W)))), dim3(256), 0, s, \
+                                         rowptr, eid, val, src, tgt, pv, bf, w, den, out, dout, cot, cot_scale, (int)n_rows, dz, da)
+        switch ((int)o / 4) { case 1: GODE_PF(1, 16); break; case 2: GODE_PF(2, 16); break; case 4: GODE_PF(4, 64); break; case 8: GODE_PF(8, 64); break; default: GODE_PF(16, 64); break; }
 #undef GODE_PF
         GODE_LAUNCH_CHECK();
         return 0;
@@ -1473,11 +1478,11 @@ extern "C" int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* ei
     const int maxc = (int)((o + G - 1) / G);
     const int64_t blocks = (n_rows + 3) / 4;
     hipStream_t s = (hipStream_t)stream;
-    if ((o == 16 || o == 32 || o == 64) && !(ld_s % 4) && !(ld_t % 4) &&
+    if ((o == 4 || o == 8 || o == 16 || o == 32 || o == 64) && !(ld_s % 4) && !(ld_t % 4) &&
         !((((uintptr_t)dz) | ((uintptr_t)dps) | ((uintptr_t)dpt)) & 15)) {
-#define GODE_PF(L) hipLaunchKernelGGL(gat_scatter_pf_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, s, rowptr_src, eid_src, \
-                                      rowptr_tgt, eid_tgt, dz, da, (int)n_rows, dps, ld_s, dpt, ld_t, das, dat, ld_a)
-        switch ((int)o / 4) { case 4: GODE_PF(4); break; case 8: GODE_PF(8); break; default: GODE_PF(16); break; }
+#define GODE_PF(L, W) hipLaunchKernelGGL((gat_scatter_pf_kernel<L, W>), dim3((unsigned)((n_rows + 4 * (64 / W) - 1) / (4 * (64 / W)))), dim3(256), 0, s, \
+                                         rowptr_src, eid_src, rowptr_tgt, eid_tgt, dz, da, (int)n_rows, dps, ld_s, dpt, ld_t, das, dat, ld_a)
+        switch ((int)o / 4) { case 1: GODE_PF(1, 16); break; case 2: GODE_PF(2, 16); break; case 4: GODE_PF(4, 64); break; case 8: GODE_PF(8, 64); break; default: GODE_PF(16, 64); break; }
 #undef GODE_PF
         GODE_LAUNCH_CHECK();
         return 0;
