@@ -264,8 +264,20 @@ def lincomb(terms):
     return lc
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def current_stream_handle(device_index=None):
+    """hipStream_t of torch's current stream on the (current) device as an int.  torch.cuda.current_stream() builds a
+    Stream object (~10 us); this is the raw query underneath it (~0.3 us) - every launch through the ABI asks once, and an
+    eager QC step or an adaptive solve makes hundreds of them."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device() if device_index is None else device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(current_stream_handle())
 
 
 def ptr(t):

@@ -127,7 +127,7 @@ _retired = []      # outgrown scratch buffers stay allocated: captured HIP graph
 def _scratch(device, nbytes):
     """Reduction scratch of the CURRENT stream of `device`: launches on one stream are ordered, so they can share a
     buffer; two streams (or two threads on their own streams) each get their own."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _lib.current_stream_handle(device.index if device.index is not None else torch.cuda.current_device()))
     buf = _red_scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
