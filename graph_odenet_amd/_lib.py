@@ -135,7 +135,9 @@ SIGNATURES = {
     "gode_gat_project_small_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p,
                                          c_i64, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
     "gode_gat_dense_vjp_small_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p,
-                                           c_i64, c_p, c_p, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p]),
+                                           c_i64, c_p, c_p, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "gode_gat_maxpath_heads_part_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "gode_gat_heads_block_cap": (c_i64, []),
     "gode_gat_small_finish_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     "gode_gcn_small_supported": (c_i, [c_i64, c_i64, ctypes.c_int32]),
     "gode_gcn_small_parts": (c_i64, [c_i64]),

@@ -1442,6 +1442,28 @@ extern "C" int gode_gat_agg_heads_f32_fwd(const gode_graph_t* mt, const int32_t*
                           (hipStream_t)stream, hm);
 }
 
+// the first half only: per-block sums of da and arg-max candidates stay in `scratch`; gode_gat_dense_vjp_small_f32 closes the
+// step itself (it subtracts the heads' sums from the two dA2 entries the arg-max edge feeds, when it loads those rows)
+extern "C" int gode_gat_maxpath_heads_part_f32(const float* a, const float* da, int64_t n_edges, int64_t heads,
+                                               const int32_t* tgt, void* scratch, void* stream) {
+    if (n_edges < 0 || heads < 1) return GODE_E_SHAPE;
+    if (heads > kMaxHeads) return GODE_E_UNSUPPORTED;
+    if (n_edges > INT32_MAX) return GODE_E_RANGE;
+    if (n_edges == 0) return 0;
+    if (!a || !da || !tgt || !scratch) return GODE_E_NULLPTR;
+    const int nb = head_blocks(n_edges);
+    float* psum = (float*)scratch;
+    int* pidx = (int*)(psum + (int64_t)kHeadBlocks * heads);
+    const float* pmax = psum + 2 * (int64_t)kHeadBlocks * heads;
+    { const int rc = gode_set_lds_once((const void*)gat_maxpath_heads_part_kernel, (size_t)heads * 256 * sizeof(float));
+      if (rc) return rc; }
+    hipLaunchKernelGGL(gat_maxpath_heads_part_kernel, dim3(nb), dim3(256), (size_t)heads * 256 * sizeof(float), (hipStream_t)stream, a,
+                       da, tgt, (int)n_edges, (int)heads, psum, pidx, pmax, nb);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int64_t gode_gat_heads_block_cap(void) { return kHeadBlocks; }
+
 extern "C" int gode_gat_maxpath_heads_raw_f32(const float* a, float* da, int64_t n_edges, int64_t heads, const int32_t* tgt,
                                               float* dat, int64_t ld_dat, void* scratch, void* stream) {
     if (n_edges < 0 || heads < 1) return GODE_E_SHAPE;

@@ -122,7 +122,9 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
     GODE_TRY(gode_gat_agg_f32_bwd(&f->mt, f->src, f->tgt, &pr, o, H > 1 ? w->zeros : f->bf, w->wgt, w->den, ky, nullptr, &ain,
                                   -1.f, w->dz, w->da, w->dPt, o, w->dA2 + 1, 2, &did, stream));
     if (f->n_edges > 0) {
-        if (H > 1 && raw_logits(f))
+        if (H > 1 && raw_logits(f) && !did && w->small_part)     // first half; the dense VJP launch below closes the step
+            GODE_TRY(gode_gat_maxpath_heads_part_f32(w->a, w->da, f->n_edges, H, f->tgt, w->heads_scratch, stream));
+        else if (H > 1 && raw_logits(f))
             GODE_TRY(gode_gat_maxpath_heads_raw_f32(w->a, w->da, f->n_edges, H, f->tgt, did ? w->dA2 + 1 : nullptr, 2,
                                                     w->heads_scratch, stream));
         else if (H > 1)
@@ -145,7 +147,9 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
     }
     if (w->small_part && small_dense(f)) {      // k_a and all parameter-gradient partials in one launch, one more to close
         GODE_TRY(gode_gat_dense_vjp_small_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, f->Wtgt, f->Wlog, H,
-                                              w->dPs, w->dPt, w->dA2, 1.f, nullptr, ka, w->small_part, stream));
+                                              w->dPs, w->dPt, w->dA2, 1.f, nullptr, ka, w->small_part,
+                                              (H > 1 && raw_logits(f) && !did && f->n_edges > 0) ? w->heads_scratch : nullptr, f->src, f->tgt,
+                                              f->n_edges, stream));
         return gode_gat_small_finish_f32(w->small_part, n, d, H, t, kth, kat, stream);
     }
     float* g_src = kth; float* g_tgt = kth + nW; float* g_log = kth + 2 * nW;

@@ -155,6 +155,12 @@ __global__ __launch_bounds__(256) void gat_project_small_kernel(LinComb xin, int
 // part[block] = [ dWsrc ((D+1) x D, row 0 = colsum dPs) | dWtgt (row 0 = colsum dPt) | dWlog ((D+1) x nl, row 0 = colsum dA2)
 //                 | dgamma | dbeta | colsums . [Wsrc[0] | Wtgt[0] | Wlog[0]] ]
 // ---------------------------------------------------------------------------------------------------------------
+// The path of the gradient through each head's maximum (GAT/layers.py:47), closed here instead of in a launch of its own:
+// the max-path step left per-block sums of da (psum) and arg-max candidates (pidx) per head; head h's sum T_h is taken off
+// the two dA2 entries its arg-max edge e* feeds - (src(e*), column 2 h) and (tgt(e*), column 2 h + 1) - when those rows are
+// loaded.  On the H-fold graph src / tgt are virtual indices (node * H + head).  psum == NULL: nothing to do.
+struct MaxFix { const float* psum; const int* pidx; int n_part; const int* esrc; const int* etgt; int n_edges; int H; };
+
 template <int D, int NLP> struct GatVjpShape {
     static constexpr int LPR = D / 4, SG = 64 / LPR, NS = D / SG, NSL = (NLP + SG - 1) / SG;
     static constexpr int NIN = 2 * D + NLP;                      // columns of [dPs | dPt | dA2]
@@ -171,15 +177,26 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
                                                                  const float* __restrict__ Wlog, int nl,
                                                                  const float* __restrict__ dPs, const float* __restrict__ dPt,
                                                                  const float* __restrict__ dA2, float out_scale, LinComb pre,
-                                                                 float* __restrict__ ka, float* __restrict__ part)
+                                                                 float* __restrict__ ka, float* __restrict__ part, MaxFix mf)
 {
     using S = GatVjpShape<D, NLP>;
     constexpr int LPR = S::LPR, SG = S::SG, NS = S::NS, NSL = S::NSL, NIN = S::NIN, nW = (D + 1) * D;
     // Wt[c][k] = W(k + 1, c) over the 2 D + NLP input columns c; the same storage holds the block partial afterwards
     __shared__ __attribute__((aligned(16))) float buf[S::BUF];
     __shared__ __attribute__((aligned(16))) float dsrow[4][NIN];
+    __shared__ float mpT[8];
+    __shared__ int mpS[8], mpD[8];
     float* Wt = buf;
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
+    if (threadIdx.x < 8) {
+        float tsum = 0.f; int f = INT32_MAX;
+        if (mf.psum && (int)threadIdx.x < mf.H)
+            for (int b = 0; b < mf.n_part; ++b) { tsum += mf.psum[b * mf.H + threadIdx.x]; f = min(f, mf.pidx[b * mf.H + threadIdx.x]); }
+        const bool hit = mf.psum && f < mf.n_edges;
+        mpT[threadIdx.x] = hit ? tsum : 0.f;
+        mpS[threadIdx.x] = hit ? mf.esrc[f] / mf.H : -1;
+        mpD[threadIdx.x] = hit ? mf.etgt[f] / mf.H : -1;
+    }
     for (int i = threadIdx.x; i < D * D; i += 256) {
         const int k = i / D, c = i % D;
         Wt[c * (D + 4) + k] = Wsrc[(int64_t)(k + 1) * D + c];
@@ -216,7 +233,17 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
     }
     for (; row < n_rows; row += gridDim.x * 4) {
         const int64_t o = (int64_t)row * D + 4 * q;
-        const float4 gs = ngs, gt = ngt, gl = ngl, x = nx;
+        const float4 gs = ngs, gt = ngt, x = nx;
+        float4 gl = ngl;
+        if (mf.psum && has_l) {                                  // max-path fix of this row's logit cotangents (see MaxFix)
+            float gv[4] = {gl.x, gl.y, gl.z, gl.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int c = 4 * q + a, h = (c >> 1) & 7;
+                if (c < nl && row == ((c & 1) ? mpD[h] : mpS[h])) gv[a] -= mpT[h];
+            }
+            gl = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        }
         {
             const int nrow = row + gridDim.x * 4;
             if (nrow < n_rows) {
@@ -451,7 +478,8 @@ extern "C" int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n
                                             const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
                                             const float* Wlog, int64_t heads, const float* dPs, const float* dPt,
                                             const float* dA2, float out_scale, const gode_lincomb_t* pre, float* ka,
-                                            float* part, void* stream)
+                                            float* part, const void* maxpath_scratch, const int32_t* esrc,
+                                            const int32_t* etgt, int64_t n_edges, void* stream)
 {
     if (heads < 1) heads = 1;
     if (!xin || !Wsrc || !Wtgt || !Wlog || !dPs || !dPt || !dA2 || !ka || !part) return GODE_E_NULLPTR;
@@ -463,9 +491,17 @@ extern "C" int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n
     const LinComb lx = make_lincomb(xin), lp = make_lincomb(pre);
     const int cg = gat_small_cg(d, groups);
     const int nl = (int)(2 * heads), nlp = nl <= 4 ? 4 : 16;
+    MaxFix mf = {nullptr, nullptr, 0, nullptr, nullptr, 0, (int)heads};
+    if (maxpath_scratch && n_edges > 0) {
+        if (!esrc || !etgt) return GODE_E_NULLPTR;
+        if (n_edges > INT32_MAX) return GODE_E_RANGE;
+        const int64_t cap = gode_gat_heads_block_cap();
+        mf.psum = (const float*)maxpath_scratch; mf.pidx = (const int*)(mf.psum + cap * heads);
+        mf.n_part = (int)gode_gat_heads_parts(n_edges); mf.esrc = esrc; mf.etgt = etgt; mf.n_edges = (int)n_edges;
+    }
     const dim3 grid((unsigned)gode_gat_small_parts(n_rows, d));
 #define GODE_GVJ(DV, CGV, NLV) hipLaunchKernelGGL((gat_dense_vjp_small_kernel<DV, CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
-                                                  lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, dPs, dPt, dA2, out_scale, lp, ka, part);
+                                                  lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, dPs, dPt, dA2, out_scale, lp, ka, part, mf);
     GODE_GATS_DISPATCH(GODE_GVJ)
 #undef GODE_GVJ
     GODE_LAUNCH_CHECK();

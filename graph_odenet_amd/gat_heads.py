@@ -352,10 +352,12 @@ class GatHeadsAdjointField(GatHeadsField):
         g = s.views(out[3])
         ops.gat_vjp(eg, w.proj, o, w.bf0, w.a, w.zero, w.wgt, w.den, out[0].view(nv, o), w.dz, w.da, w.dPs.view(nv, o),
                     w.dPt.view(nv, o), w.dA2.view(nv, 2), cot_terms=terms[1], cot_scale=-1.0, heads=H,
-                    raw_scratch=w.heads_scratch if self.raw_logits() else None)
+                    raw_scratch=w.heads_scratch if self.raw_logits() else None, defer_maxpath=self.raw_logits())
         if self.small():
+            # (on the raw-logit route the per-head max-path sums are taken off dA2 inside this launch)
             ops.gat_dense_vjp_small(xt, n, d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, H, w.dPs, w.dPt, w.dA2,
-                                    out[1], w.small_part)
+                                    out[1], w.small_part,
+                                    maxfix=(w.heads_scratch, eg.src, eg.tgt) if self.raw_logits() and eg.E > 0 else None)
             ops.gat_small_finish(w.small_part, n, d, H, t, out[3], out[2])
             return
         from .gat_ode import MERGED_FINISH_MAX_ROWS

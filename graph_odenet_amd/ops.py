@@ -239,8 +239,9 @@ def gat_project_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, 
 
 
 def gat_dense_vjp_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, Wlog, heads, dPs, dPt, dA2, ka, part,
-                        out_scale=1.0, pre_terms=None):
-    """k_a and the block partials of every parameter gradient of a GAT adjoint stage in one launch (csrc/gat_small.hip)."""
+                        out_scale=1.0, pre_terms=None, maxfix=None):
+    """k_a and the block partials of every parameter gradient of a GAT adjoint stage in one launch (csrc/gat_small.hip).
+    maxfix = (scratch, esrc, etgt): close the per-head max-path step that gat_vjp(..., defer_maxpath=True) left open."""
     lib = _lib.load()
     for tns, nm in ((gamma, "gamma"), (beta, "beta"), (Wsrc, "Wsrc"), (Wtgt, "Wtgt"), (Wlog, "Wlog"), (dPs, "dPs"), (dPt, "dPt"),
                     (dA2, "dA2"), (ka, "ka"), (part, "part")):
@@ -260,7 +261,9 @@ def gat_dense_vjp_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt
         pre = lincomb(pre_terms)
     check(lib.gode_gat_dense_vjp_small_f32(ctypes.byref(lc), n_rows, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(Wsrc), ptr(Wtgt),
                                            ptr(Wlog), heads, ptr(dPs), ptr(dPt), ptr(dA2), float(out_scale),
-                                           ctypes.byref(pre) if pre is not None else None, ptr(ka), ptr(part), stream_ptr()),
+                                           ctypes.byref(pre) if pre is not None else None, ptr(ka), ptr(part),
+                                           ptr(maxfix[0]) if maxfix else None, ptr(maxfix[1]) if maxfix else None,
+                                           ptr(maxfix[2]) if maxfix else None, maxfix[1].numel() if maxfix else 0, stream_ptr()),
           "gode_gat_dense_vjp_small_f32")
 
 
@@ -574,7 +577,7 @@ def gat_agg_heads_fwd(eg, proj, o, bf, a, scratch, heads, eps, out, w, den):
 
 
 def gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=None, cot_terms=None, cot_scale=1.0,
-            heads=1, raw_scratch=None):
+            heads=1, raw_scratch=None, defer_maxpath=False):
     """Vector-Jacobian product of the edge-attention aggregation w.r.t. the projections: fills dz[E, o], da[E] (with the
     path through the global maximum folded in), dPs, dPt (N x o) and dA2 (N x 2).  The cotangent is `dout`, or
     cot_scale * (sum cot_terms) masked by out > 0.  heads > 1: `eg` is the H-fold graph, `a` holds logits shifted
@@ -596,7 +599,11 @@ def gat_vjp(eg, proj, o, bf, a, amax, w, den, out, dz, da, dPs, dPt, dA2, dout=N
                                    ptr(den), ptr(out), ptr(dout), ctypes.byref(lc) if lc is not None else None,
                                    float(cot_scale), ptr(dz), ptr(da), ptr(dPt), o, at_ptr, 2, ctypes.byref(did),
                                    stream_ptr()), "gode_gat_agg_f32_bwd")
-    if eg.E > 0 and heads > 1 and raw_scratch is not None:         # raw logits + partial maxima (gat_logits_heads_raw)
+    if eg.E > 0 and heads > 1 and raw_scratch is not None and defer_maxpath and not did.value:
+        # first half only; gat_dense_vjp_small(..., maxfix=(raw_scratch, eg.src, eg.tgt)) closes the step
+        check(lib.gode_gat_maxpath_heads_part_f32(ptr(a), ptr(da), eg.E, int(heads), ptr(eg.tgt), ptr(raw_scratch), stream_ptr()),
+              "gode_gat_maxpath_heads_part_f32")
+    elif eg.E > 0 and heads > 1 and raw_scratch is not None:       # raw logits + partial maxima (gat_logits_heads_raw)
         big = bool(did.value)
         check(lib.gode_gat_maxpath_heads_raw_f32(ptr(a), ptr(da), eg.E, int(heads), ptr(eg.tgt), at_ptr if big else None, 2,
                                                  ptr(raw_scratch), stream_ptr()), "gode_gat_maxpath_heads_raw_f32")

@@ -338,6 +338,11 @@ int gode_gat_agg_heads_f32_fwd(const gode_graph_t* mt, const int32_t* src, const
                                int64_t heads, float eps, float* out, float* w_out, float* den_out, void* stream);
 int gode_gat_maxpath_heads_raw_f32(const float* a, float* da, int64_t n_edges, int64_t heads, const int32_t* tgt,
                                    float* dat, int64_t ld_dat, void* scratch, void* stream);
+/* the first half of maxpath_heads_raw only (per-block sums and arg-max candidates left in `scratch`): the step is closed by
+ * gode_gat_dense_vjp_small_f32(..., maxpath_scratch = scratch, ...) */
+int gode_gat_maxpath_heads_part_f32(const float* a, const float* da, int64_t n_edges, int64_t heads, const int32_t* tgt,
+                                    void* scratch, void* stream);
+int64_t gode_gat_heads_block_cap(void);
 /* dps[v,:] = sum_{e: src_e = v} dz[e,:], dpt[v,:] = sum_{e: tgt_e = v} dz[e,:], das / dat likewise from da; the
  * incidence lists are CSR (rowptr over nodes, eid = edge ids in increasing order). */
 int gode_gat_scatter_f32(const int32_t* rowptr_src, const int32_t* eid_src, const int32_t* rowptr_tgt,
@@ -523,7 +528,11 @@ int gode_gat_project_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_
 int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
                                  const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
                                  const float* Wlog, int64_t heads, const float* dPs, const float* dPt, const float* dA2,
-                                 float out_scale, const gode_lincomb_t* pre, float* ka, float* part, void* stream);
+                                 float out_scale, const gode_lincomb_t* pre, float* ka, float* part,
+                                 const void* maxpath_scratch /* nullable: the scratch gode_gat_maxpath_heads_part_f32 filled;
+                                 the per-head max-path sums are then taken off the two dA2 entries of each head's arg-max
+                                 edge while the rows are loaded */, const int32_t* esrc, const int32_t* etgt, int64_t n_edges,
+                                 void* stream);
 int gode_gat_small_finish_f32(const float* part, int64_t n_rows, int64_t d, int64_t heads, float t, float* ktheta,
                               float* kat, void* stream);
 

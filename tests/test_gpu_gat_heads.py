@@ -543,3 +543,60 @@ def test_one_launch_dense_half_matches_multi_launch_path(golden, heads, d, metho
     close(res[1][1], res[0][1], gtol, "dx")
     for a, b in zip(res[1][2], res[0][2]):
         close(a, b, gtol, "parameter gradient")
+
+
+@pytest.mark.parametrize("d,H", [(64, 8), (32, 4), (16, 2)])
+def test_dense_vjp_closes_the_max_path_step_bit_for_bit(d, H):
+    """The path of the gradient through each head's maximum (GAT/layers.py:47) on the raw-logit route: the max-path launch
+    leaves per-block sums of da and arg-max candidates, and gode_gat_dense_vjp_small_f32 takes head h's sum T_h off
+    dA2[src(e*), 2h] and dA2[tgt(e*), 2h+1] while it loads those rows.  Against the same launch on a dA2 that was corrected
+    beforehand: every output identical bit for bit (the term is of size eps / (sum + eps) in a real solve and would hide
+    under any parity tolerance)."""
+    from graph_odenet_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(d + H)
+    n, E = 700, 9000                                            # virtual edges E * 1: indices are node * H + head
+    D = dev()
+    f = dict(dtype=torch.float32, device=D)
+    x = torch.randn(n, d, generator=g).to(D)
+    gamma, beta = (1 + 0.3 * torch.randn(d, generator=g)).to(D), (0.3 * torch.randn(d, generator=g)).to(D)
+    Wsrc, Wtgt = (torch.randn(d + 1, d, generator=g) / d ** 0.5).to(D), (torch.randn(d + 1, d, generator=g) / d ** 0.5).to(D)
+    Wlog = (torch.randn(d + 1, 2 * H, generator=g) / d ** 0.5).to(D)
+    dPs, dPt, dA2 = torch.randn(n, d, generator=g).to(D), torch.randn(n, d, generator=g).to(D), torch.randn(n, 2 * H, generator=g).to(D)
+    heads_of = torch.arange(E) % H
+    esrc = (torch.randint(0, n, (E,), generator=g) * H + heads_of).to(torch.int32)
+    etgt = (torch.randint(0, n, (E,), generator=g) * H + heads_of).to(torch.int32)
+    cap, n_part = lib.gode_gat_heads_block_cap(), lib.gode_gat_heads_parts(E)
+    psum = torch.zeros(cap * H)
+    psum[:n_part * H] = torch.randn(n_part * H, generator=g)
+    pidx = torch.full((cap * H,), 2 ** 31 - 1, dtype=torch.int32)
+    first = {}
+    for h in range(H if H > 2 else 1):                          # (at H = 2 one head has no arg-max candidate: nothing to take off)
+        cand = torch.randint(0, E // H, (3,), generator=g) * H + h
+        for b, e in zip(torch.randint(0, n_part, (3,), generator=g).tolist(), cand.tolist()):
+            pidx[b * H + h] = min(int(pidx[b * H + h]), e)
+        first[h] = int(pidx.view(cap, H)[:n_part, h].min())
+    scratch = torch.zeros(lib.gode_gat_heads_scratch_bytes(E, H), dtype=torch.uint8)
+    scratch[:cap * H * 4] = psum.view(torch.uint8)
+    scratch[cap * H * 4:cap * H * 8] = pidx.view(torch.uint8)
+    scratch = scratch.to(D)
+    fixed = dA2.clone()
+    for h, e in first.items():
+        T = torch.zeros((), dtype=torch.float32)
+        for b in range(n_part):                                  # the kernel's order of summation
+            T = T + psum[b * H + h]
+        assert heads_of[e] == h
+        fixed[int(esrc[e]) // H, 2 * h] -= T.to(D)
+        fixed[int(etgt[e]) // H, 2 * h + 1] -= T.to(D)
+    outs = []
+    for da2, mfx in ((fixed, None), (dA2, (scratch, esrc.to(D), etgt.to(D)))):
+        part = ops.gat_small_part(n, d, H, D)
+        ka = torch.empty(n, d, **f)
+        ops.gat_dense_vjp_small([(1.0, x)], n, d, min(32, d), 1e-5, gamma, beta, Wsrc, Wtgt, Wlog, H, dPs, dPt, da2, ka, part, maxfix=mfx)
+        kth = torch.empty(2 * (d + 1) * d + (d + 1) * 2 * H + d + H + 2 * d, **f)
+        kat = torch.empty(1, **f)
+        ops.gat_small_finish(part, n, d, H, 0.3, kth, kat)
+        outs.append((ka, kth, kat))
+    assert not torch.equal(fixed, dA2)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
