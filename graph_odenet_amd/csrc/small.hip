@@ -34,9 +34,9 @@ namespace {
 constexpr int kSmallPartBlocks = 256;
 
 // sum over the sub-groups of a wave (lanes `from` apart and beyond), every lane ends with the total
-__device__ __forceinline__ void xor_combine4(float4& v, int from) {
+__device__ __forceinline__ void xor_combine4(float4& v, int from, int upto = 64) {
 #pragma unroll
-    for (int off = from; off < 64; off <<= 1) {
+    for (int off = from; off < upto; off <<= 1) {
         v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
         v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
     }
@@ -45,7 +45,11 @@ __device__ __forceinline__ void xor_combine4(float4& v, int from) {
 // ---------------------------------------------------------------------------------------------------------------
 // forward: out[i] = (sum pre)[i] + alpha * relu(z_i),  z_i = (sum_j a_ij [t | GN(x_j)]) W + b;  Y2[i] = (sum cot)[i] * [z_i > 0]
 // ---------------------------------------------------------------------------------------------------------------
-template <int D, int CG>
+// GW = lanes that share a row: 64 (a wave per row: citation graphs of a few thousand rows, where a 168-neighbour hub wants the
+// whole wave) or 16 (FOUR rows per wave: from 8 192 rows on the launch is bound by rows in flight - 97 registers allow
+// four waves per SIMD, 4 096 waves on the chip, each a ~4.5 us chain of dependent latencies - Pubmed's 19 717 rows took
+// 26.7 us per launch with a wave per row).
+template <int D, int CG, int GW>
 __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                              const float* __restrict__ val, LinComb xin, int n_rows,
                                                              float eps, const float* __restrict__ gamma,
@@ -54,13 +58,14 @@ __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restr
                                                              LinComb pre, LinComb cot, float* __restrict__ Y2,
                                                              float* __restrict__ out)
 {
-    constexpr int LPR = D / 4, SG = 64 / LPR, PU = 4;          // lanes per row, sub-groups per wave, gathers in flight per lane
+    constexpr int LPR = D / 4, SG = GW / LPR, RPW = 64 / GW, PU = 4;   // lanes per row, sub-groups per row, rows per wave, gathers in flight per lane
     __shared__ __attribute__((aligned(16))) float Ws[(D + 1) * D];
-    __shared__ __attribute__((aligned(16))) float mrow[4][D + 4];            // [0] = t * rowsum, [4 ..] = aggregated GN rows
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
+    __shared__ __attribute__((aligned(16))) float mrow[4][RPW][D + 4];       // [0] = t * rowsum, [4 ..] = aggregated GN rows
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, gl = l & (GW - 1), q = gl & (LPR - 1), s = gl / LPR;
     // the kernel is a chain of dependent memory latencies (row pointer -> column -> operand row): the first row's
     // pointers are requested before the weight block is staged, so that the two round trips overlap
-    int row = blockIdx.x * 4 + wave;
+    const int row0 = (blockIdx.x * 4 + wave) * RPW + l / GW;
+    int row = row0;
     int b = 0, e = 0;
     if (row < n_rows) { b = rowptr[row]; e = rowptr[row + 1]; }
     for (int i = threadIdx.x; i < (D + 1) * D; i += 256) Ws[i] = W[i];
@@ -68,26 +73,26 @@ __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restr
     const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 bi = bias ? ld4(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float* mr = mrow[wave];
-    for (; row < n_rows; row += gridDim.x * 4) {                                    // wave-uniform
-        if (row != (int)(blockIdx.x * 4 + wave)) { b = rowptr[row]; e = rowptr[row + 1]; }
+    float* mr = mrow[wave][l / GW];
+    for (; row < n_rows; row += gridDim.x * 4 * RPW) {                              // uniform over the row's lanes
+        if (row != row0) { b = rowptr[row]; e = rowptr[row + 1]; }
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
         float r = 0.f;
-        // indices and values of 64 non-zeros at once, then the neighbour rows with the indices taken from registers: the
+        // indices and values of GW non-zeros at once, then the neighbour rows with the indices taken from registers: the
         // gathers of a chunk do not depend on each other and issue back to back (a loop of col[j] -> x[col[j]] trips made
         // Cora's 168-neighbour hub set the kernel's duration: 8.2 us)
-        for (int base = b; base < e; base += 64) {
+        for (int base = b; base < e; base += GW) {
             int cj = 0; float av = 0.f;
-            if (base + l < e) { cj = col[base + l]; av = val ? val[base + l] : 1.f; }
+            if (base + gl < e) { cj = col[base + gl]; av = val ? val[base + gl] : 1.f; }
             const int cnt = e - base;
             for (int u0 = 0; u0 < LPR; u0 += PU) {
                 if (u0 * SG >= cnt) break;
                 float4 xv[PU]; float aj[PU];
 #pragma unroll
                 for (int u = 0; u < PU; ++u) {
-                    const int j = (u0 + u) * SG + s;           // < 64; slots beyond the row carry weight 0 and row 0
-                    aj[u] = __shfl(av, j, 64);
-                    xv[u] = lc_load4(xin, (int64_t)__shfl(cj, j, 64) * D + 4 * q);
+                    const int j = (u0 + u) * SG + s;           // < GW; slots beyond the row carry weight 0 and row 0
+                    aj[u] = __shfl(av, j, GW);
+                    xv[u] = lc_load4(xin, (int64_t)__shfl(cj, j, GW) * D + 4 * q);
                 }
 #pragma unroll
                 for (int u = 0; u < PU; ++u) {
@@ -97,9 +102,9 @@ __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restr
                 }
             }
         }
-        xor_combine4(m, LPR);
+        xor_combine4(m, LPR, GW);
 #pragma unroll
-        for (int off = LPR; off < 64; off <<= 1) r += __shfl_xor(r, off, 64);
+        for (int off = LPR; off < GW; off <<= 1) r += __shfl_xor(r, off, 64);
         if (s == 0) {
             *reinterpret_cast<float4*>(mr + 4 + 4 * q) = m;
             if (q == 0) mr[0] = t * r;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restr
             const float4 w = *reinterpret_cast<const float4*>(Ws + k * D + 4 * q);
             z.x = fmaf(mk, w.x, z.x); z.y = fmaf(mk, w.y, z.y); z.z = fmaf(mk, w.z, z.z); z.w = fmaf(mk, w.w, z.w);
         }
-        xor_combine4(z, LPR);
+        xor_combine4(z, LPR, GW);
         if (s == 0) {
             z.x += bi.x; z.y += bi.y; z.z += bi.z; z.w += bi.w;
             float4 y = make_float4(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f), fmaxf(z.z, 0.f), fmaxf(z.w, 0.f));
@@ -170,7 +175,7 @@ __device__ __forceinline__ float4 gn_backward4(const float4 x, const float4 dy, 
 // VJP: dS_i = sum_j aT_ij dZ_j;  ka_i = (sum pre)_i + out_scale * GN'(x_i)^T (dS_i W1^T);  block partial row
 // part[block] = [ sum_i [1|xn_i]^T dS_i  ((D+1) x D, row 0 = colsum(dS): the time row) | colsum(dZ) | dgamma | dbeta | a_t' share ]
 // ---------------------------------------------------------------------------------------------------------------
-template <int D, int CG>
+template <int D, int CG, int GW>
 __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restrict__ rowptrT, const int* __restrict__ colT,
                                                            const float* __restrict__ valT, LinComb xin, int n_rows,
                                                            float eps, const float* __restrict__ gamma,
@@ -178,13 +183,14 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
                                                            const float* __restrict__ dZ, float out_scale, LinComb pre,
                                                            float* __restrict__ ka, float* __restrict__ part)
 {
-    constexpr int LPR = D / 4, SG = 64 / LPR, NS = D / SG, PU = 4;     // NS = columns of dW per lane (1, 4, 16)
+    constexpr int LPR = D / 4, SG = GW / LPR, RPW = 64 / GW, NS = D / SG, PU = 4;     // NS = columns of dW per lane
     constexpr int PLEN = (D + 1) * D + 3 * D + 1;                 // ... | the block's share of a_t' = colsum(dS) . W[0, :]
     __shared__ __attribute__((aligned(16))) float Wt[D * (D + 4)];           // Wt[n][k] = W1[k][n], row stride D + 4
-    __shared__ __attribute__((aligned(16))) float dsrow[4][D];
+    __shared__ __attribute__((aligned(16))) float dsrow[4][RPW][D];
     __shared__ float red[PLEN];
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
-    int row = blockIdx.x * 4 + wave;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, gl = l & (GW - 1), q = gl & (LPR - 1), s = gl / LPR;
+    const int row0 = (blockIdx.x * 4 + wave) * RPW + l / GW;
+    int row = row0;
     int b = 0, e = 0;
     if (row < n_rows) { b = rowptrT[row]; e = rowptrT[row + 1]; }        // requested before the weight block is staged
     for (int i = threadIdx.x; i < D * D; i += 256) {
@@ -194,19 +200,19 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
     __syncthreads();
     const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float* dr = dsrow[wave];
+    float* dr = dsrow[wave][l / GW];
     float acc[4][NS];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int i = 0; i < NS; ++i) acc[a][i] = 0.f;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cz = cs, dg = cs, db = cs;
-    for (; row < n_rows; row += gridDim.x * 4) {
-        if (row != (int)(blockIdx.x * 4 + wave)) { b = rowptrT[row]; e = rowptrT[row + 1]; }
+    for (; row < n_rows; row += gridDim.x * 4 * RPW) {
+        if (row != row0) { b = rowptrT[row]; e = rowptrT[row + 1]; }
         float4 dS = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int base = b; base < e; base += 64) {             // prefetched indices, as in the forward kernel
+        for (int base = b; base < e; base += GW) {             // prefetched indices, as in the forward kernel
             int cj = 0; float av = 0.f;
-            if (base + l < e) { cj = colT[base + l]; av = valT ? valT[base + l] : 1.f; }
+            if (base + gl < e) { cj = colT[base + gl]; av = valT ? valT[base + gl] : 1.f; }
             const int cnt = e - base;
             for (int u0 = 0; u0 < LPR; u0 += PU) {
                 if (u0 * SG >= cnt) break;
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
 #pragma unroll
                 for (int u = 0; u < PU; ++u) {
                     const int j = (u0 + u) * SG + s;
-                    aj[u] = __shfl(av, j, 64);
-                    gv[u] = ld4(dZ + (int64_t)__shfl(cj, j, 64) * D + 4 * q);
+                    aj[u] = __shfl(av, j, GW);
+                    gv[u] = ld4(dZ + (int64_t)__shfl(cj, j, GW) * D + 4 * q);
                 }
 #pragma unroll
                 for (int u = 0; u < PU; ++u) {
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
                 }
             }
         }
-        xor_combine4(dS, LPR);
+        xor_combine4(dS, LPR, GW);
         if (s == 0) *reinterpret_cast<float4*>(dr + 4 * q) = dS;
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
             const float4 w = *reinterpret_cast<const float4*>(Wt + n * (D + 4) + 4 * q);
             dy.x = fmaf(dn, w.x, dy.x); dy.y = fmaf(dn, w.y, dy.y); dy.z = fmaf(dn, w.z, dy.z); dy.w = fmaf(dn, w.w, dy.w);
         }
-        xor_combine4(dy, LPR);
+        xor_combine4(dy, LPR, GW);
         const int64_t o = (int64_t)row * D + 4 * q;
         const float4 x = lc_load4(xin, o);
         float4 xh;
@@ -261,9 +267,25 @@ __global__ __launch_bounds__(256) void gcn_vjp_small_kernel(const int* __restric
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // block partial: the four waves add through LDS in wave order (fixed order: deterministic)
+    // rows of the same wave first (lanes GW apart hold the same entries of the partial row: fixed xor order) ...
+    if (RPW > 1) {
+#pragma unroll
+        for (int off = GW; off < 64; off <<= 1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) acc[a][i] += __shfl_xor(acc[a][i], off, 64);
+            cs.x += __shfl_xor(cs.x, off, 64); cs.y += __shfl_xor(cs.y, off, 64); cs.z += __shfl_xor(cs.z, off, 64); cs.w += __shfl_xor(cs.w, off, 64);
+            cz.x += __shfl_xor(cz.x, off, 64); cz.y += __shfl_xor(cz.y, off, 64); cz.z += __shfl_xor(cz.z, off, 64); cz.w += __shfl_xor(cz.w, off, 64);
+            dg.x += __shfl_xor(dg.x, off, 64); dg.y += __shfl_xor(dg.y, off, 64); dg.z += __shfl_xor(dg.z, off, 64); dg.w += __shfl_xor(dg.w, off, 64);
+            db.x += __shfl_xor(db.x, off, 64); db.y += __shfl_xor(db.y, off, 64); db.z += __shfl_xor(db.z, off, 64); db.w += __shfl_xor(db.w, off, 64);
+        }
+    }
+    // ... then the four waves add through LDS in wave order (fixed order: deterministic); with several rows per wave the
+    // first row group writes for the wave
+    const bool writer = l < GW;
     for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+        if (wave == w && writer) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -386,7 +408,9 @@ int small_cg(int64_t d, int32_t groups) {
     return (cg == 1 || cg == 2 || cg == 4) ? (int)cg : -1;
 }
 
-int64_t feval_blocks(int64_t n) { int64_t b = (n + 3) / 4; if (b < 1) b = 1; if (b > 2048) b = 2048; return b; }
+// four rows per wave from 8 192 rows on (see gcn_feval_small_kernel)
+bool rows4(int64_t n) { return n >= 8192; }
+int64_t feval_blocks(int64_t n) { const int64_t per = rows4(n) ? 16 : 4; int64_t b = (n + per - 1) / per; if (b < 1) b = 1; if (b > 2048) b = 2048; return b; }
 
 }  // namespace
 
@@ -427,11 +451,14 @@ extern "C" int gode_gcn_feval_small_f32(const gode_gcn_odefunc_t* f, const gode_
     const int64_t d = f->d;
     const int cg = small_cg(d, f->groups);
     const dim3 grid((unsigned)feval_blocks(f->n));
-#define GODE_FEV(DV, CGV) hipLaunchKernelGGL((gcn_feval_small_kernel<DV, CGV>), grid, dim3(256), 0, (hipStream_t)stream,         \
+    const bool r4 = rows4(f->n);
+#define GODE_FEV(DV, CGV) if (r4) GODE_FEV_(DV, CGV, 16) else GODE_FEV_(DV, CGV, 64)
+#define GODE_FEV_(DV, CGV, GWV) hipLaunchKernelGGL((gcn_feval_small_kernel<DV, CGV, GWV>), grid, dim3(256), 0, (hipStream_t)stream,         \
                                              f->A.rowptr, f->A.col, f->A.val, lx, (int)f->n, f->eps, f->gamma, f->beta, f->W,    \
                                              f->b, t, alpha, lp, lcot, Y2, out);
     GODE_SMALL_DISPATCH(GODE_FEV)
 #undef GODE_FEV
+#undef GODE_FEV_
     GODE_LAUNCH_CHECK();
     return 0;
 }
@@ -450,11 +477,14 @@ extern "C" int gode_gcn_vjp_small_f32(const gode_gcn_odefunc_t* f, const gode_li
     const int64_t d = f->d;
     const int cg = small_cg(d, f->groups);
     const dim3 grid((unsigned)gode_gcn_small_parts(f->n));
-#define GODE_VJS(DV, CGV) hipLaunchKernelGGL((gcn_vjp_small_kernel<DV, CGV>), grid, dim3(256), 0, (hipStream_t)stream,           \
+    const bool r4 = rows4(f->n);
+#define GODE_VJS(DV, CGV) if (r4) GODE_VJS_(DV, CGV, 16) else GODE_VJS_(DV, CGV, 64)
+#define GODE_VJS_(DV, CGV, GWV) hipLaunchKernelGGL((gcn_vjp_small_kernel<DV, CGV, GWV>), grid, dim3(256), 0, (hipStream_t)stream,           \
                                              f->AT.rowptr, f->AT.col, f->AT.val, lx, (int)f->n, f->eps, f->gamma, f->beta, f->W, \
                                              dZ, out_scale, lp, ka, part);
     GODE_SMALL_DISPATCH(GODE_VJS)
 #undef GODE_VJS
+#undef GODE_VJS_
     GODE_LAUNCH_CHECK();
     return 0;
 }
