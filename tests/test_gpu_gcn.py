@@ -967,9 +967,10 @@ def test_graph_convolution_sparse_features_and_padded_classes():
     assert L.sparse_features(xdense) is None
 
 
+@pytest.mark.parametrize("n", [1500, 9000])          # a wave per row / four rows per wave (from 8 192 rows on)
 @pytest.mark.parametrize("d", [16, 32])
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])
-def test_fused_small_graph_path_matches_multi_launch_path(d, method):
+def test_fused_small_graph_path_matches_multi_launch_path(d, method, n):
     """csrc/small.hip (launch-bound graphs: one launch per f-eval, one per VJP, by re-association - everything after the
     gather is row-local) against the multi-launch path of the large graphs (option small_fused 0) through the same ODE
     block, C drivers and Python drivers: states to 1e-5, gradients to the noise floor of the width (one channel per
@@ -978,9 +979,8 @@ def test_fused_small_graph_path_matches_multi_launch_path(d, method):
     from graph_odenet_amd import _lib, models, odeint as OI
     lib = _lib.load()
     torch.manual_seed(d)
-    n = 1500
-    r = torch.cat([torch.randint(0, n - 10, (6000,)), torch.zeros(300, dtype=torch.long)])     # rows n-10.. have no entry
-    c = torch.cat([torch.randint(0, n, (6000,)), torch.randperm(n)[:300]])
+    r = torch.cat([torch.randint(0, n - 10, (4 * n,)), torch.zeros(300, dtype=torch.long)])     # rows n-10.. have no entry
+    c = torch.cat([torch.randint(0, n, (4 * n,)), torch.randperm(n)[:300]])
     key = torch.unique(r * n + c)
     r, c = key // n, key % n
     v = torch.rand(key.numel()) + 0.1
@@ -1014,7 +1014,7 @@ def test_fused_small_graph_path_matches_multi_launch_path(d, method):
     ref = res[(0, True)]
     # two fp32 summation orders through 16-64 relu / GroupNorm stages: the same bars as the Cora test gives the widths
     # with 1 or 2 channels per group (noise_floor_check slack 20: rstd up to 316 amplifies every rounding)
-    gtol = 5e-3
+    gtol = 5e-3 if (method == "rk4" or n < 8192) else 1e-2       # adaptive steps on 9 000 rows: 5.5e-3 measured (accept / reject noise)
     for key_ in ((1, True), (1, False)):
         got = res[key_]
         close(got[0], ref[0], 1e-5 if method == "rk4" else 1e-4, "state %s" % (key_,))
