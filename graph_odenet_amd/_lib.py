@@ -69,7 +69,7 @@ class GatOdeFunc(ctypes.Structure):
                 ("n_edges", ctypes.c_int64), ("n", ctypes.c_int64), ("d", ctypes.c_int64), ("groups", ctypes.c_int32),
                 ("eps_gn", ctypes.c_float), ("eps", ctypes.c_float), ("Wsrc", ctypes.c_void_p), ("Wtgt", ctypes.c_void_p),
                 ("Wlog", ctypes.c_void_p), ("bf", ctypes.c_void_p), ("bw", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
-                ("beta", ctypes.c_void_p), ("heads", ctypes.c_int32)]
+                ("beta", ctypes.c_void_p), ("heads", ctypes.c_int32), ("Wpacked", ctypes.c_void_p)]
 
 
 class GatWorkspace(ctypes.Structure):
@@ -133,9 +133,11 @@ SIGNATURES = {
     "gode_gat_small_parts": (c_i64, [c_i64, c_i64]),
     "gode_gat_small_part_len": (c_i64, [c_i64, c_i64]),
     "gode_gat_project_small_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p,
-                                         c_i64, c_p, c_f, c_p, c_p, c_p, c_p, c_p]),
+                                         c_i64, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "gode_gat_small_pack_len": (c_i64, [c_i64, c_i64]),
+    "gode_gat_small_pack_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p]),
     "gode_gat_dense_vjp_small_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p,
-                                           c_i64, c_p, c_p, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+                                           c_i64, c_p, c_p, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "gode_gat_maxpath_heads_part_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_gat_heads_block_cap": (c_i64, []),
     "gode_gat_small_finish_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),

@@ -75,7 +75,7 @@ int project(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, gode_lin
     const int64_t Hh = n_heads(f);
     if (small_dense(f)) {                       // launch-bound graphs: the three products (and the bias add) as one launch
         GODE_TRY(gode_gat_project_small_f32(yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, f->Wtgt, f->Wlog, Hh,
-                                            Hh > 1 ? f->bf : nullptr, t, w->Ps, w->Pt, w->A2, xo, stream));
+                                            Hh > 1 ? f->bf : nullptr, t, w->Ps, w->Pt, w->A2, xo, f->Wpacked, stream));
         if (xo) { yin->n = 1; yin->coef[0] = 1.f; yin->ptr[0] = xo; }
         return 0;
     }
@@ -149,7 +149,7 @@ int eval_adjoint(const gode_gat_odefunc_t* f, const gode_gat_workspace_t* w, god
         GODE_TRY(gode_gat_dense_vjp_small_f32(&yin, n, d, f->groups, f->eps_gn, f->gamma, f->beta, f->Wsrc, f->Wtgt, f->Wlog, H,
                                               w->dPs, w->dPt, w->dA2, 1.f, nullptr, ka, w->small_part,
                                               (H > 1 && raw_logits(f) && !did && f->n_edges > 0) ? w->heads_scratch : nullptr, f->src, f->tgt,
-                                              f->n_edges, stream));
+                                              f->n_edges, f->Wpacked, stream));
         return gode_gat_small_finish_f32(w->small_part, n, d, H, t, kth, kat, stream);
     }
     float* g_src = kth; float* g_tgt = kth + nW; float* g_log = kth + 2 * nW;

@@ -80,6 +80,40 @@ __device__ __forceinline__ float4 load_logit4(const float* __restrict__ p, int c
     return v;
 }
 
+// LEN floats (a multiple of 4, 16-byte aligned on both sides) from global memory into LDS with every load of a thread in
+// flight before its first store.  (Staging the d = 64 blocks element by element, transposing on the way, was a chain of
+// ~40 dependent round trips: 8 of the 33 us of the dense VJP launch, measured with s_memrealtime stamps.)
+template <int LEN>
+__device__ __forceinline__ void stage_copy(float* __restrict__ dst, const float* __restrict__ src) {
+    constexpr int N4 = LEN / 4, NIT = (N4 + 255) / 256;
+    float4 tmp[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) { const int i = threadIdx.x + 256 * j; if (i < N4) tmp[j] = ld4(src + 4 * i); }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) { const int i = threadIdx.x + 256 * j; if (i < N4) *reinterpret_cast<float4*>(dst + 4 * i) = tmp[j]; }
+}
+
+// the two LDS images of the weights, formed ONCE per solve (the weights do not change inside one): [ Wall | WtAll ],
+//   Wall  (d+1) x (2d + NLP):  row k = [Wsrc[k] | Wtgt[k] | Wlog[k] | 0 ..]                      (projection kernel)
+//   WtAll (2d + NLP) x (d+4):  row c = column c of [Wsrc | Wtgt | Wlog] without the time row, 4 pad floats   (VJP kernel)
+__global__ __launch_bounds__(256) void gat_small_pack_kernel(const float* __restrict__ Wsrc, const float* __restrict__ Wtgt,
+                                                            const float* __restrict__ Wlog, int d, int nl, int nlp,
+                                                            float* __restrict__ out)
+{
+    const int ws = 2 * d + nlp, n_all = (d + 1) * ws, n_t = ws * (d + 4);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_all + n_t; i += gridDim.x * 256) {
+        float v = 0.f;
+        if (i < n_all) {
+            const int k = i / ws, c = i % ws;
+            v = c < d ? Wsrc[k * d + c] : (c < 2 * d ? Wtgt[k * d + c - d] : (c - 2 * d < nl ? Wlog[k * nl + c - 2 * d] : 0.f));
+        } else {
+            const int j = i - n_all, c = j / (d + 4), k = j % (d + 4);
+            if (k < d) v = c < d ? Wsrc[(k + 1) * d + c] : (c < 2 * d ? Wtgt[(k + 1) * d + c - d] : (c - 2 * d < nl ? Wlog[(k + 1) * nl + c - 2 * d] : 0.f));
+        }
+        out[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // projections:  [Ps | Pt | A2][i] = [t | GN(x_i)] [Wsrc | Wtgt | Wlog]     (NLP = logit columns padded to 4 or 16)
 // ---------------------------------------------------------------------------------------------------------------
@@ -88,6 +122,7 @@ __global__ __launch_bounds__(256) void gat_project_small_kernel(LinComb xin, int
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ Wsrc, const float* __restrict__ Wtgt,
                                                                const float* __restrict__ Wlog, int nl,
+                                                               const float* __restrict__ packed,
                                                                const float* __restrict__ pt_bias, float t,
                                                                float* __restrict__ Ps, float* __restrict__ Pt,
                                                                float* __restrict__ A2, float* __restrict__ xout)
@@ -96,14 +131,17 @@ __global__ __launch_bounds__(256) void gat_project_small_kernel(LinComb xin, int
     __shared__ __attribute__((aligned(16))) float Wall[(D + 1) * WS];
     __shared__ __attribute__((aligned(16))) float mrow[4][D + 4];            // [0] = t, [4 ..] = the normalised row
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, q = l & (LPR - 1), s = l / LPR;
-    for (int i = threadIdx.x; i < (D + 1) * D; i += 256) {
-        const int k = i / D, c = i % D;
-        Wall[k * WS + c] = Wsrc[i];
-        Wall[k * WS + D + c] = Wtgt[i];
-    }
-    for (int i = threadIdx.x; i < (D + 1) * NLP; i += 256) {
-        const int k = i / NLP, c = i % NLP;
-        Wall[k * WS + 2 * D + c] = c < nl ? Wlog[k * nl + c] : 0.f;
+    if (packed) stage_copy<(D + 1) * WS>(Wall, packed);           // the block as gode_gat_small_pack_f32 laid it out
+    else {
+        for (int i = threadIdx.x; i < (D + 1) * D; i += 256) {
+            const int k = i / D, c = i % D;
+            Wall[k * WS + c] = Wsrc[i];
+            Wall[k * WS + D + c] = Wtgt[i];
+        }
+        for (int i = threadIdx.x; i < (D + 1) * NLP; i += 256) {
+            const int k = i / NLP, c = i % NLP;
+            Wall[k * WS + 2 * D + c] = c < nl ? Wlog[k * nl + c] : 0.f;
+        }
     }
     __syncthreads();
     const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -177,7 +215,8 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
                                                                  const float* __restrict__ Wlog, int nl,
                                                                  const float* __restrict__ dPs, const float* __restrict__ dPt,
                                                                  const float* __restrict__ dA2, float out_scale, LinComb pre,
-                                                                 float* __restrict__ ka, float* __restrict__ part, MaxFix mf)
+                                                                 float* __restrict__ ka, float* __restrict__ part, MaxFix mf,
+                                                                 const float* __restrict__ packed_t)
 {
     using S = GatVjpShape<D, NLP>;
     constexpr int LPR = S::LPR, SG = S::SG, NS = S::NS, NSL = S::NSL, NIN = S::NIN, nW = (D + 1) * D;
@@ -197,14 +236,17 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
         mpS[threadIdx.x] = hit ? mf.esrc[f] / mf.H : -1;
         mpD[threadIdx.x] = hit ? mf.etgt[f] / mf.H : -1;
     }
-    for (int i = threadIdx.x; i < D * D; i += 256) {
-        const int k = i / D, c = i % D;
-        Wt[c * (D + 4) + k] = Wsrc[(int64_t)(k + 1) * D + c];
-        Wt[(D + c) * (D + 4) + k] = Wtgt[(int64_t)(k + 1) * D + c];
-    }
-    for (int i = threadIdx.x; i < D * NLP; i += 256) {
-        const int k = i / NLP, c = i % NLP;
-        Wt[(2 * D + c) * (D + 4) + k] = c < nl ? Wlog[(int64_t)(k + 1) * nl + c] : 0.f;
+    if (packed_t) stage_copy<S::WT>(Wt, packed_t);               // the transposed image of gode_gat_small_pack_f32
+    else {
+        for (int i = threadIdx.x; i < D * D; i += 256) {
+            const int k = i / D, c = i % D;
+            Wt[c * (D + 4) + k] = Wsrc[(int64_t)(k + 1) * D + c];
+            Wt[(D + c) * (D + 4) + k] = Wtgt[(int64_t)(k + 1) * D + c];
+        }
+        for (int i = threadIdx.x; i < D * NLP; i += 256) {
+            const int k = i / NLP, c = i % NLP;
+            Wt[(2 * D + c) * (D + 4) + k] = c < nl ? Wlog[(int64_t)(k + 1) * nl + c] : 0.f;
+        }
     }
     __syncthreads();
     const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -353,22 +395,18 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
         if (l == 0) red[rA] = v;
     }
     __syncthreads();
-    // compact partial row: [dWsrc | dWtgt | dWlog ((D+1) x nl) | dgamma | dbeta | a_t share]
-    const int oL = 2 * nW, oG = oL + (D + 1) * nl, plen = oG + 2 * D + 1;
-    float* out = part + (int64_t)blockIdx.x * plen;
-    for (int i = threadIdx.x; i < plen; i += 256) {
-        int src;
-        if (i < oL) { const int bI = i >= nW, j = i - bI * nW; src = bI * rT + (j / D) * RS + j % D; }
-        else if (i < oG) { const int j = i - oL; src = rL + (j / nl) * RSL + j % nl; }
-        else src = rG + (i - oG);                               // dgamma, dbeta and the a_t share are contiguous in both
-        out[i] = red[src];
-    }
+    // the partial row leaves in the LDS layout (rows of D + 1 / NLP + 1 floats): a straight copy here, the index arithmetic
+    // once per OUTPUT in the closing launch instead of once per element and block (two runtime divisions each: 5 of the
+    // 33 us of this launch at d = 64)
+    constexpr int PLENP = S::PMAX;
+    float* out = part + (int64_t)blockIdx.x * PLENP;
+    for (int i = threadIdx.x; i < PLENP; i += 256) out[i] = red[i];
 }
 
 // k_theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta] (time rows scaled by t) and k_a_t from the block partials:
 // 1 024 threads = 32 part-groups x 32 outputs, 16 loads per thread in flight together (512 partial rows: one round).
 struct GatFinish {
-    const float* part; int n_part, plen, d, nl, heads, out_len;
+    const float* part; int n_part, plen, d, nl, nlp, heads, out_len;
     float t; float* ktheta; float* kat;
 };
 __global__ __launch_bounds__(1024) void gat_small_finish_kernel(GatFinish g)
@@ -378,13 +416,15 @@ __global__ __launch_bounds__(1024) void gat_small_finish_kernel(GatFinish g)
     const int j = (int)blockIdx.x * 32 + jj;
     const int d = g.d, nW = (d + 1) * d, nL = (d + 1) * g.nl;
     const int oBf = 2 * nW + nL, oBw = oBf + d, oGm = oBw + g.heads;     // theta offsets; gamma, beta are contiguous in both
+    // partial rows are in the VJP kernel's LDS layout: two (d+1) x (d+1) blocks, one (d+1) x (NLP+1) block, dgamma, dbeta, a_t
+    const int RS = d + 1, RSL = g.nlp + 1, rT = (d + 1) * RS, rL = 2 * rT, rG = rL + (d + 1) * RSL;
     int src = -1; float scale = 1.f;
     if (j < g.out_len) {
-        if (j < 2 * nW) { src = j; if (j % nW < d) scale = g.t; }
-        else if (j < oBf) { src = j; if (j - 2 * nW < g.nl) scale = g.t; }
-        else if (j < oBw) src = nW + (j - oBf);                          // bf = colsum(dPt): the time row of the Wtgt block
-        else if (j < oGm) src = 2 * nW + 2 * (j - oBw) + 1;              // bw_h = colsum(dA2)[2h + 1]
-        else src = 2 * nW + nL + (j - oGm);                             // dgamma | dbeta
+        if (j < 2 * nW) { const int b = j >= nW, jj = j - b * nW, r = jj / d; src = b * rT + r * RS + (jj - r * d); if (r == 0) scale = g.t; }
+        else if (j < oBf) { const int jj = j - 2 * nW, r = jj / g.nl; src = rL + r * RSL + (jj - r * g.nl); if (r == 0) scale = g.t; }
+        else if (j < oBw) src = rT + (j - oBf);                          // bf = colsum(dPt): the time row of the Wtgt block
+        else if (j < oGm) src = rL + 2 * (j - oBw) + 1;                  // bw_h = colsum(dA2)[2h + 1]
+        else src = rG + (j - oGm);                                       // dgamma | dbeta
     } else if (j == g.out_len) src = g.plen - 1;                         // a_t'
     float v = 0.f;
     if (src >= 0) {
@@ -435,9 +475,27 @@ extern "C" int64_t gode_gat_small_parts(int64_t n_rows, int64_t d) {
     if (b > cap) b = cap;
     return b;
 }
-extern "C" int64_t gode_gat_small_part_len(int64_t d, int64_t heads) {
+extern "C" int64_t gode_gat_small_part_len(int64_t d, int64_t heads) {          // the padded layout of the VJP kernel
     if (heads < 1) heads = 1;
-    return 2 * (d + 1) * d + (d + 1) * 2 * heads + 2 * d + 1;
+    const int64_t nlp = 2 * heads <= 4 ? 4 : 16;
+    return 2 * (d + 1) * (d + 1) + (d + 1) * (nlp + 1) + 2 * d + 1;
+}
+extern "C" int64_t gode_gat_small_pack_len(int64_t d, int64_t heads) {
+    if (heads < 1) heads = 1;
+    const int64_t nlp = 2 * heads <= 4 ? 4 : 16, ws = 2 * d + nlp;
+    return (d + 1) * ws + ws * (d + 4);
+}
+extern "C" int gode_gat_small_pack_f32(const float* Wsrc, const float* Wtgt, const float* Wlog, int64_t d, int64_t heads,
+                                       float* packed, void* stream) {
+    if (heads < 1) heads = 1;
+    if (!Wsrc || !Wtgt || !Wlog || !packed) return GODE_E_NULLPTR;
+    if (d <= 0 || d % 16 || d > 64 || heads > 8) return GODE_E_UNSUPPORTED;
+    const int nl = (int)(2 * heads), nlp = nl <= 4 ? 4 : 16;
+    const int64_t total = gode_gat_small_pack_len(d, heads);
+    hipLaunchKernelGGL(gat_small_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Wsrc, Wtgt, Wlog,
+                       (int)d, nl, nlp, packed);
+    GODE_LAUNCH_CHECK();
+    return 0;
 }
 
 #define GODE_GATS_DISPATCH(MACRO)                                                                                   \
@@ -454,20 +512,20 @@ extern "C" int64_t gode_gat_small_part_len(int64_t d, int64_t heads) {
 extern "C" int gode_gat_project_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
                                           const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
                                           const float* Wlog, int64_t heads, const float* pt_bias, float t, float* Ps,
-                                          float* Pt, float* A2, float* x_out, void* stream)
+                                          float* Pt, float* A2, float* x_out, const float* packed, void* stream)
 {
     if (heads < 1) heads = 1;
     if (!xin || !Wsrc || !Wtgt || !Wlog || !Ps || !Pt || !A2) return GODE_E_NULLPTR;
     if (!gode_gat_small_supported(n_rows, d, groups, heads)) return GODE_E_UNSUPPORTED;
     int rc = check_lincomb(xin, true); if (rc) return rc;
     if (!lincomb_aligned16(xin) || ((((uintptr_t)Ps) | ((uintptr_t)Pt) | ((uintptr_t)x_out) | ((uintptr_t)gamma) | ((uintptr_t)beta) |
-                                     ((uintptr_t)pt_bias)) & 15)) return GODE_E_ALIGN;
+                                     ((uintptr_t)pt_bias) | ((uintptr_t)packed)) & 15)) return GODE_E_ALIGN;
     const LinComb lx = make_lincomb(xin);
     const int cg = gat_small_cg(d, groups);
     const int nl = (int)(2 * heads), nlp = nl <= 4 ? 4 : 16;
     const dim3 grid((unsigned)project_blocks(n_rows));
 #define GODE_GPJ(DV, CGV, NLV) hipLaunchKernelGGL((gat_project_small_kernel<DV, CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
-                                                  lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, pt_bias, t, Ps, Pt, A2, x_out);
+                                                  lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, packed, pt_bias, t, Ps, Pt, A2, x_out);
     GODE_GATS_DISPATCH(GODE_GPJ)
 #undef GODE_GPJ
     GODE_LAUNCH_CHECK();
@@ -479,7 +537,7 @@ extern "C" int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n
                                             const float* Wlog, int64_t heads, const float* dPs, const float* dPt,
                                             const float* dA2, float out_scale, const gode_lincomb_t* pre, float* ka,
                                             float* part, const void* maxpath_scratch, const int32_t* esrc,
-                                            const int32_t* etgt, int64_t n_edges, void* stream)
+                                            const int32_t* etgt, int64_t n_edges, const float* packed, void* stream)
 {
     if (heads < 1) heads = 1;
     if (!xin || !Wsrc || !Wtgt || !Wlog || !dPs || !dPt || !dA2 || !ka || !part) return GODE_E_NULLPTR;
@@ -499,9 +557,11 @@ extern "C" int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n
         mf.psum = (const float*)maxpath_scratch; mf.pidx = (const int*)(mf.psum + cap * heads);
         mf.n_part = (int)gode_gat_heads_parts(n_edges); mf.esrc = esrc; mf.etgt = etgt; mf.n_edges = (int)n_edges;
     }
+    if (((uintptr_t)packed) & 15) return GODE_E_ALIGN;
+    const float* packed_t = packed ? packed + (d + 1) * (2 * d + nlp) : nullptr;      // the transposed image follows Wall
     const dim3 grid((unsigned)gode_gat_small_parts(n_rows, d));
 #define GODE_GVJ(DV, CGV, NLV) hipLaunchKernelGGL((gat_dense_vjp_small_kernel<DV, CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
-                                                  lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, dPs, dPt, dA2, out_scale, lp, ka, part, mf);
+                                                  lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, dPs, dPt, dA2, out_scale, lp, ka, part, mf, packed_t);
     GODE_GATS_DISPATCH(GODE_GVJ)
 #undef GODE_GVJ
     GODE_LAUNCH_CHECK();
@@ -516,7 +576,7 @@ extern "C" int gode_gat_small_finish_f32(const float* part, int64_t n_rows, int6
     if (n_rows <= 0 || n_rows > 65536 || d <= 0 || heads > 8) return GODE_E_SHAPE;
     GatFinish g;
     g.part = part; g.n_part = (int)gode_gat_small_parts(n_rows, d); g.plen = (int)gode_gat_small_part_len(d, heads);
-    g.d = (int)d; g.nl = (int)(2 * heads); g.heads = (int)heads;
+    g.d = (int)d; g.nl = (int)(2 * heads); g.nlp = g.nl <= 4 ? 4 : 16; g.heads = (int)heads;
     g.out_len = (int)(2 * (d + 1) * d + (d + 1) * 2 * heads + d + heads + 2 * d);
     g.t = t; g.ktheta = ktheta; g.kat = kat;
     const int blocks = (g.out_len + 1 + 31) / 32;

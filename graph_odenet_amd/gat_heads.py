@@ -175,6 +175,8 @@ class GatHeadsSpec:
         # graphs are launch-bound and keep the compact product.
         self.pad_logits = (egv.base.n >= PAD_LOGITS_MIN_ROWS and d in (16, 32, 64, 128) and 4 < 2 * H <= d)
         self.Wlog_pad = torch.zeros(i, d, **f) if self.pad_logits else None
+        self.Wpacked = None
+        self.n = egv.base.n
         self.refresh()
         self.gamma, self.beta = norm.weight.detach(), norm.bias.detach()
         self.n = egv.base.n
@@ -190,6 +192,9 @@ class GatHeadsSpec:
             self.Wsrc.copy_(Wsrc); self.Wtgt.copy_(Wtgt); self.Wlog.copy_(Wlog); self.bf.copy_(bf); self.bw.copy_(ba[1::2])
             if self.Wlog_pad is not None:
                 self.Wlog_pad[:, :2 * self.heads].copy_(Wlog)
+            if not self.pad_logits:
+                from .gat_ode import _repack
+                _repack(self, self.heads)
 
     def views(self, theta):
         v = {k: theta[a:b] for k, (a, b) in self.off.items()}
@@ -270,6 +275,7 @@ class GatHeadsField(GatOdeField):
         fs.n, fs.d, fs.groups, fs.eps_gn, fs.eps, fs.heads = s.n, s.d, s.groups, s.eps_gn, s.eps, s.heads
         fs.Wsrc, fs.Wtgt, fs.Wlog = s.Wsrc.data_ptr(), s.Wtgt.data_ptr(), s.Wlog.data_ptr()
         fs.bf, fs.bw, fs.gamma, fs.beta = s.bf.data_ptr(), s.bw.data_ptr(), s.gamma.data_ptr(), s.beta.data_ptr()
+        fs.Wpacked = s.Wpacked.data_ptr() if s.Wpacked is not None else None
         ws = _lib.GatWorkspace()
         for k in ("X", "Ps", "Pt", "A2", "a", "wgt", "den", "zeros", "heads_scratch"):
             setattr(ws, k, p(getattr(w, k)))
@@ -289,7 +295,7 @@ class GatHeadsField(GatOdeField):
         terms = [(1.0, w.X)] if x_out is not None else y_terms
         if self.small():
             ops.gat_project_small(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, s.heads, s.bf, t,
-                                  w.Ps, w.Pt, w.A2, x_out=x_out)
+                                  w.Ps, w.Pt, w.A2, x_out=x_out, packed=s.Wpacked)
             return terms
         ops.gn_time_gemm_pair(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, True, t, w.Ps, w.Pt,
                               x_out=x_out)
@@ -357,7 +363,8 @@ class GatHeadsAdjointField(GatHeadsField):
             # (on the raw-logit route the per-head max-path sums are taken off dA2 inside this launch)
             ops.gat_dense_vjp_small(xt, n, d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, H, w.dPs, w.dPt, w.dA2,
                                     out[1], w.small_part,
-                                    maxfix=(w.heads_scratch, eg.src, eg.tgt) if self.raw_logits() and eg.E > 0 else None)
+                                    maxfix=(w.heads_scratch, eg.src, eg.tgt) if self.raw_logits() and eg.E > 0 else None,
+                                    packed=s.Wpacked)
             ops.gat_small_finish(w.small_part, n, d, H, t, out[3], out[2])
             return
         from .gat_ode import MERGED_FINISH_MAX_ROWS

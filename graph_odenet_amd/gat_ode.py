@@ -33,6 +33,17 @@ from .solver import Field
 MERGED_FINISH_MAX_ROWS = 1 << 16
 
 
+def _repack(spec, heads):
+    """Keep spec.Wpacked (csrc/gat_small.hip: gode_gat_small_pack_f32) in step with the weights.  Worth a launch per solve
+    from d = 32 on (at d = 16 the blocks are 2.4 KB and the kernels lay them out themselves)."""
+    if spec.d < 32 or not spec.Wsrc.is_cuda:
+        return
+    lib = _lib.load()
+    if not lib.gode_gat_small_supported(spec.eg.n if hasattr(spec.eg, "n") else spec.n, spec.d, int(spec.groups), heads):
+        return
+    spec.Wpacked = ops.gat_small_pack(spec.Wsrc, spec.Wtgt, spec.Wlog, heads, out=spec.Wpacked)
+
+
 class GatOdeSpec:
     def __init__(self, eg, layer, norm):
         self.eg, self.layer, self.norm = eg, layer, norm
@@ -46,6 +57,7 @@ class GatOdeSpec:
         self.Wsrc = torch.empty(self.i, self.d, dtype=torch.float32, device=dev)
         self.Wtgt = torch.empty(self.i, self.d, dtype=torch.float32, device=dev)
         self.Wlog = torch.empty(self.i, 2, dtype=torch.float32, device=dev)
+        self.Wpacked = None                           # LDS images of the three blocks for the one-launch kernels (d >= 32)
         self.refresh()
         self.bf, self.bw = layer.f.bias.detach(), layer.w.bias.detach()
         self.gamma, self.beta = norm.weight.detach(), norm.bias.detach()
@@ -68,6 +80,8 @@ class GatOdeSpec:
         self.Wtgt.copy_(Wf[:, i:].t())
         self.Wlog[:, 0].copy_(ww[0, :i])
         self.Wlog[:, 1].copy_(ww[0, i:])
+        _repack(self, 1)
+
 
     def views(self, theta):
         o, i = self.d, self.i
@@ -142,6 +156,7 @@ class GatOdeField(Field):
         fs.n, fs.d, fs.groups, fs.eps_gn, fs.eps = s.n, s.d, s.groups, s.eps_gn, s.eps
         fs.Wsrc, fs.Wtgt, fs.Wlog = s.Wsrc.data_ptr(), s.Wtgt.data_ptr(), s.Wlog.data_ptr()
         fs.bf, fs.bw, fs.gamma, fs.beta = s.bf.data_ptr(), s.bw.data_ptr(), s.gamma.data_ptr(), s.beta.data_ptr()
+        fs.Wpacked = s.Wpacked.data_ptr() if s.Wpacked is not None else None
         ws = _lib.GatWorkspace()
         for k in ("X", "Ps", "Pt", "A2", "a", "amax", "wgt", "den", "logits_scratch"):
             setattr(ws, k, p(getattr(w, k)))
@@ -172,7 +187,7 @@ class GatOdeField(Field):
         terms = [(1.0, w.X)] if x_out is not None else y_terms
         if self.small():
             ops.gat_project_small(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, 1, None, t,
-                                  w.Ps, w.Pt, w.A2, x_out=x_out)
+                                  w.Ps, w.Pt, w.A2, x_out=x_out, packed=s.Wpacked)
             return terms
         ops.gn_time_gemm_pair(y_terms, s.n, s.d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, True, t, w.Ps, w.Pt,
                               x_out=x_out)
@@ -237,7 +252,7 @@ class GatOdeAdjointField(GatOdeField):
         if self.small():
             # launch-bound graphs: k_a and the partials of every parameter gradient in one launch, one more to close
             ops.gat_dense_vjp_small(xt, n, o, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, 1, w.dPs, w.dPt, w.dA2,
-                                    out[1], w.small_part)
+                                    out[1], w.small_part, packed=s.Wpacked)
             ops.gat_small_finish(w.small_part, n, o, 1, t, out[3], out[2])
             return
         # bias gradients: sum over edges of dz / da = sum over nodes of the per-target sums just formed (every edge has

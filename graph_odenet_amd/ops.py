@@ -219,7 +219,22 @@ def gat_small_part(n_rows, d, heads, device):
     return torch.empty(lib.gode_gat_small_parts(n_rows, d), lib.gode_gat_small_part_len(d, heads), dtype=torch.float32, device=device)
 
 
-def gat_project_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, Wlog, heads, pt_bias, t, Ps, Pt, A2, x_out=None):
+def gat_small_pack(Wsrc, Wtgt, Wlog, heads, out=None):
+    """The LDS images of the weights for gat_project_small / gat_dense_vjp_small (once per solve; csrc/gat_small.hip)."""
+    lib = _lib.load()
+    _need(Wsrc, "Wsrc"); _need(Wtgt, "Wtgt"); _need(Wlog, "Wlog"); _need(out, "packed")
+    d = Wsrc.shape[1]
+    n = lib.gode_gat_small_pack_len(d, heads)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=Wsrc.device)
+    elif out.numel() != n:
+        raise ValueError("gat_small_pack: packed buffer must hold %d floats" % n)
+    check(lib.gode_gat_small_pack_f32(ptr(Wsrc), ptr(Wtgt), ptr(Wlog), d, heads, ptr(out), stream_ptr()), "gode_gat_small_pack_f32")
+    return out
+
+
+def gat_project_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, Wlog, heads, pt_bias, t, Ps, Pt, A2, x_out=None,
+                      packed=None):
     """Ps, Pt (+ pt_bias), A2 = [t | GN(x)] @ [Wsrc | Wtgt | Wlog] in one launch (x = sum of x_terms, written to x_out)."""
     lib = _lib.load()
     for tns, nm in ((gamma, "gamma"), (beta, "beta"), (Wsrc, "Wsrc"), (Wtgt, "Wtgt"), (Wlog, "Wlog"), (pt_bias, "pt_bias"),
@@ -235,11 +250,11 @@ def gat_project_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, 
     lc = lincomb(x_terms)
     check(lib.gode_gat_project_small_f32(ctypes.byref(lc), n_rows, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(Wsrc), ptr(Wtgt),
                                          ptr(Wlog), heads, ptr(pt_bias), float(t), ptr(Ps), ptr(Pt), ptr(A2), ptr(x_out),
-                                         stream_ptr()), "gode_gat_project_small_f32")
+                                         ptr(packed), stream_ptr()), "gode_gat_project_small_f32")
 
 
 def gat_dense_vjp_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt, Wlog, heads, dPs, dPt, dA2, ka, part,
-                        out_scale=1.0, pre_terms=None, maxfix=None):
+                        out_scale=1.0, pre_terms=None, maxfix=None, packed=None):
     """k_a and the block partials of every parameter gradient of a GAT adjoint stage in one launch (csrc/gat_small.hip).
     maxfix = (scratch, esrc, etgt): close the per-head max-path step that gat_vjp(..., defer_maxpath=True) left open."""
     lib = _lib.load()
@@ -263,7 +278,8 @@ def gat_dense_vjp_small(x_terms, n_rows, d, groups, eps, gamma, beta, Wsrc, Wtgt
                                            ptr(Wlog), heads, ptr(dPs), ptr(dPt), ptr(dA2), float(out_scale),
                                            ctypes.byref(pre) if pre is not None else None, ptr(ka), ptr(part),
                                            ptr(maxfix[0]) if maxfix else None, ptr(maxfix[1]) if maxfix else None,
-                                           ptr(maxfix[2]) if maxfix else None, maxfix[1].numel() if maxfix else 0, stream_ptr()),
+                                           ptr(maxfix[2]) if maxfix else None, maxfix[1].numel() if maxfix else 0, ptr(packed),
+                                           stream_ptr()),
           "gode_gat_dense_vjp_small_f32")
 
 

@@ -483,6 +483,8 @@ typedef struct gode_gat_odefunc {
      * real nodes, d = H * o), Wlog is (d+1) x 2H, bw holds H logit biases, bf (d) is added to the target-side
      * projection, and theta = [Wsrc | Wtgt | Wlog | bf | bw (H) | gamma | beta] (gode_gat_ode_theta_len_heads). */
     int32_t heads;
+    /* nullable: gode_gat_small_pack_f32 of (Wsrc, Wtgt, Wlog), refreshed with them - launch-bound graphs only */
+    const float* Wpacked;
 } gode_gat_odefunc_t;
 
 typedef struct gode_gat_workspace {
@@ -524,7 +526,7 @@ int64_t gode_gat_small_part_len(int64_t d, int64_t heads);
 int gode_gat_project_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
                                const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
                                const float* Wlog, int64_t heads, const float* pt_bias, float t, float* Ps, float* Pt,
-                               float* A2, float* x_out, void* stream);
+                               float* A2, float* x_out, const float* packed /* nullable: gode_gat_small_pack_f32 */, void* stream);
 int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d, int32_t groups, float eps,
                                  const float* gamma, const float* beta, const float* Wsrc, const float* Wtgt,
                                  const float* Wlog, int64_t heads, const float* dPs, const float* dPt, const float* dA2,
@@ -532,9 +534,16 @@ int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int6
                                  const void* maxpath_scratch /* nullable: the scratch gode_gat_maxpath_heads_part_f32 filled;
                                  the per-head max-path sums are then taken off the two dA2 entries of each head's arg-max
                                  edge while the rows are loaded */, const int32_t* esrc, const int32_t* etgt, int64_t n_edges,
-                                 void* stream);
+                                 const float* packed /* nullable: gode_gat_small_pack_f32 */, void* stream);
 int gode_gat_small_finish_f32(const float* part, int64_t n_rows, int64_t d, int64_t heads, float t, float* ktheta,
                               float* kat, void* stream);
+/* The LDS images of [Wsrc | Wtgt | Wlog] both kernels stage (row-major with padded logit columns for project, transposed
+ * without the time row for dense_vjp), formed once per solve - the weights do not change inside one - so that staging is
+ * a straight 16-byte copy: packed holds gode_gat_small_pack_len(d, heads) floats.  Passing NULL for `packed` makes the
+ * kernels lay the images out themselves (element by element). */
+int64_t gode_gat_small_pack_len(int64_t d, int64_t heads);
+int gode_gat_small_pack_f32(const float* Wsrc, const float* Wtgt, const float* Wlog, int64_t d, int64_t heads, float* packed,
+                            void* stream);
 
 int64_t gode_gat_ode_theta_len(int64_t d);
 int64_t gode_gat_ode_theta_len_heads(int64_t d, int64_t heads);

@@ -479,6 +479,19 @@ def test_one_launch_dense_half_vs_float64_autograd(n, d, H):
         scale = max(1.0, want[lo:hi].abs().max().item())
         bad = (got[lo:hi] - want[lo:hi]).abs().max().item()
         assert bad <= tol * scale * max(1.0, n ** 0.5), (nm, bad, scale)
+    # the same launches with the weights' LDS images formed beforehand (gode_gat_small_pack_f32: what the ODE fields do once
+    # per solve from d = 32 on): a different way of staging the same numbers - every output bit for bit the same
+    packed = ops.gat_small_pack(Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H)
+    Ps2, Pt2, A22 = torch.empty_like(Ps), torch.empty_like(Pt), torch.empty_like(A2)
+    ops.gat_project_small(dt, n, d, groups, eps, gamma.to(D), beta.to(D), Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H, bf.to(D), t, Ps2, Pt2, A22,
+                          packed=packed)
+    assert torch.equal(Ps2, Ps) and torch.equal(Pt2, Pt) and torch.equal(A22, A2)
+    part2, ka2 = ops.gat_small_part(n, d, H, D), torch.empty_like(ka)
+    ops.gat_dense_vjp_small([(1.0, X)], n, d, groups, eps, gamma.to(D), beta.to(D), Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H,
+                            dPs.to(D), dPt.to(D), dA2.to(D), ka2, part2, out_scale=-0.5, pre_terms=[(2.0, pre.to(D))], packed=packed)
+    kth2, kat2 = torch.empty_like(kth), torch.empty_like(kat)
+    ops.gat_small_finish(part2, n, d, H, t, kth2, kat2)
+    assert torch.equal(ka2, ka) and torch.equal(kth2, kth) and torch.equal(kat2, kat)
     want_at = (cs[0] * Wsrc[0].double()).sum() + (cs[1] * Wtgt[0].double()).sum() + (cs[2] * Wlog[0].double()).sum()
     assert abs(kat.item() - want_at.item()) <= 4e-6 * max(1.0, abs(want_at.item())) * max(1.0, n ** 0.5)
 
