@@ -106,6 +106,7 @@ SIGNATURES = {
                                 c_i64, c_i64, ctypes.POINTER(SpmmEpilogue), c_p]),
     "gode_lincomb_f32": (c_i, [c_p, ctypes.POINTER(LinComb), c_i64, c_p]),
     "gode_lincomb_multi_f32": (c_i, [c_p, c_p, c_p, ctypes.c_int32, c_p]),
+    "gode_rk_errnorm_multi_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, c_f, c_f, c_p, c_p]),
     "gode_rk_errnorm_scratch_bytes": (c_i64, []),
     "gode_rk_errnorm_f32": (c_i, [c_p, c_p, c_p, ctypes.POINTER(LinComb), c_f, c_f, c_i64, c_p, c_p]),
     "gode_rk_scaled_sumsq_f32": (c_i, [c_p, ctypes.POINTER(LinComb), c_p, c_f, c_f, c_i64, c_p, c_p]),

@@ -265,13 +265,13 @@ extern "C" int gode_gat_ode_dopri5_step_adjoint(const gode_gat_odefunc_t* f, con
     }
     struct Part { const float* y0; float* const* k; float* y1; int64_t len; };
     const Part parts[4] = {{y, ky, y1, nd}, {a, ka, a1, nd}, {a_t, kat, a_t1, 1}, {theta, kth, theta1, P}};
+    // the four solution combines in one launch, the four error sums in one pair (same numbers as the single forms)
+    float* outs[4]; gode_lincomb_t sols[4], errs[4]; int64_t lens[4]; const float* e0[4]; const float* e1[4];
     for (int c = 0; c < 4; ++c) {
-        gode_lincomb_t sol = dp_terms(parts[c].y0, parts[c].k, DPB, 7, h, true);
-        GODE_TRY(gode_lincomb_f32(parts[c].y1, &sol, parts[c].len, stream));
+        outs[c] = parts[c].y1; lens[c] = parts[c].len; e0[c] = parts[c].y0; e1[c] = parts[c].y1;
+        sols[c] = dp_terms(parts[c].y0, parts[c].k, DPB, 7, h, true);
+        errs[c] = dp_terms(nullptr, parts[c].k, DPE, 7, h, false);
     }
-    for (int c = 0; c < 4; ++c) {
-        gode_lincomb_t err = dp_terms(nullptr, parts[c].k, DPE, 7, h, false);
-        GODE_TRY(gode_rk_errnorm_f32(sums + c, parts[c].y0, parts[c].y1, &err, rtol, atol, parts[c].len, err_scratch, stream));
-    }
-    return 0;
+    GODE_TRY(gode_lincomb_multi_f32(outs, sols, lens, 4, stream));
+    return gode_rk_errnorm_multi_f32(sums, e0, e1, errs, lens, 4, rtol, atol, err_scratch, stream);
 }

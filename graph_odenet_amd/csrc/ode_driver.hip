@@ -421,16 +421,20 @@ extern "C" int gode_gcn_ode_dopri5_step_adjoint(const gode_gcn_odefunc_t* f, con
     }
     gode_lincomb_t sy = dp_terms(y, ky, DPB, 7, h, true), sa = dp_terms(a, ka, DPB, 7, h, true),
                    st = dp_terms(theta, kth, DPB, 7, h, true);
-    GODE_TRY(gode_lincomb_f32(y1, &sy, nd, stream));
-    GODE_TRY(gode_lincomb_f32(a1, &sa, nd, stream));
-    GODE_TRY(gode_lincomb_f32(theta1, &st, P, stream));
+    {   // the three solution combines in one launch, the four error sums in one pair (same numbers as the single forms)
+        float* outs[3] = {y1, a1, theta1};
+        const gode_lincomb_t sols[3] = {sy, sa, st};
+        const int64_t lens[3] = {nd, nd, P};
+        GODE_TRY(gode_lincomb_multi_f32(outs, sols, lens, 3, stream));
+    }
     gode_lincomb_t ey = dp_terms(nullptr, ky, DPE, 7, h, false), ea = dp_terms(nullptr, ka, DPE, 7, h, false),
                    et = dp_terms(nullptr, kth, DPE, 7, h, false);
-    GODE_TRY(gode_rk_errnorm_f32(sums + 0, y, y1, &ey, rtol, atol, nd, err_scratch, stream));
-    GODE_TRY(gode_rk_errnorm_f32(sums + 1, a, a1, &ea, rtol, atol, nd, err_scratch, stream));
     // a_t is the last entry of the packed vector, the flattened parameters the P-1 before it
     gode_lincomb_t et_at = et;
     for (int j = 0; j < et_at.n; ++j) et_at.ptr[j] = et.ptr[j] + (P - 1);
-    GODE_TRY(gode_rk_errnorm_f32(sums + 2, theta + (P - 1), theta1 + (P - 1), &et_at, rtol, atol, 1, err_scratch, stream));
-    return gode_rk_errnorm_f32(sums + 3, theta, theta1, &et, rtol, atol, P - 1, err_scratch, stream);
+    const float* e0[4] = {y, a, theta + (P - 1), theta};
+    const float* e1[4] = {y1, a1, theta1 + (P - 1), theta1};
+    const gode_lincomb_t errs[4] = {ey, ea, et_at, et};
+    const int64_t ens[4] = {nd, nd, 1, P - 1};
+    return gode_rk_errnorm_multi_f32(sums, e0, e1, errs, ens, 4, rtol, atol, err_scratch, stream);
 }

@@ -88,6 +88,56 @@ __global__ __launch_bounds__(256) void ratio_sumsq4_kernel(double* part, LinComb
     block_reduce_store(s, part);
 }
 
+// Up to four error-ratio sums in ONE pair of launches (an adaptive step of the adjoint state [y, a, a_t, theta] closes with
+// four of them: eight launches of ~4 us otherwise).  Component c = blockIdx.y keeps the block decomposition it has on its
+// own (nb[c] blocks, the same striding), so every sum is bit for bit the one gode_rk_errnorm_f32 forms.
+struct MultiErr { LinComb lc[4]; const float* y0[4]; const float* y1[4]; int64_t n[4]; int nb[4]; int vec[4]; };
+__global__ __launch_bounds__(256) void ratio_sumsq_multi_kernel(double* part, MultiErr m, float rtol, float atol) {
+    const int c = blockIdx.y;
+    if ((int)blockIdx.x >= m.nb[c]) return;
+    const int64_t stride = (int64_t)m.nb[c] * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float* y0 = m.y0[c]; const float* y1 = m.y1[c];
+    double s = 0.0;
+    if (m.vec[c]) {
+        for (const int64_t n4 = m.n[c] / 4; i < n4; i += stride) {
+            const float4 a = *reinterpret_cast<const float4*>(y0 + i * 4);
+            const float4 b = *reinterpret_cast<const float4*>(y1 + i * 4);
+            const float4 mm = make_float4(fmaxf(fabsf(a.x), fabsf(b.x)), fmaxf(fabsf(a.y), fabsf(b.y)), fmaxf(fabsf(a.z), fabsf(b.z)),
+                                          fmaxf(fabsf(a.w), fabsf(b.w)));
+            const float4 e = lc_load4(m.lc[c], i * 4);
+            const float r0 = e.x / (atol + rtol * mm.x), r1 = e.y / (atol + rtol * mm.y);
+            const float r2 = e.z / (atol + rtol * mm.z), r3 = e.w / (atol + rtol * mm.w);
+            s += ((double)r0 * (double)r0 + (double)r1 * (double)r1) + ((double)r2 * (double)r2 + (double)r3 * (double)r3);
+        }
+    } else {
+        for (; i < m.n[c]; i += stride) {
+            const float e = lc_load1(m.lc[c], i);
+            const float mx = fmaxf(fabsf(y0[i]), fabsf(y1[i]));
+            const float r = e / (atol + rtol * mx);
+            s += (double)r * (double)r;
+        }
+    }
+    __shared__ double sm[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)c * RED_BLOCKS + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ __launch_bounds__(256) void final_sum_multi_kernel(double* out, const double* part, MultiErr m) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < m.nb[c]; i += 256) s += part[(int64_t)c * RED_BLOCKS + i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sm[0];
+}
+
 __global__ __launch_bounds__(256) void final_sum_kernel(double* out, const double* part, int nparts) {
     __shared__ double sm[256];
     double s = 0.0;
@@ -417,7 +467,31 @@ int gode_zero_f32(float* out, int64_t n, void* stream) {
     return 0;
 }
 
-extern "C" int64_t gode_rk_errnorm_scratch_bytes(void) { return (int64_t)RED_BLOCKS * sizeof(double); }
+extern "C" int64_t gode_rk_errnorm_scratch_bytes(void) { return (int64_t)4 * RED_BLOCKS * sizeof(double); }   // four components (multi form)
+
+extern "C" int gode_rk_errnorm_multi_f32(double* out, const float* const* y0, const float* const* y1, const gode_lincomb_t* elcs,
+                                         const int64_t* ns, int32_t count, float rtol, float atol, void* scratch, void* stream) {
+    if (!out || !y0 || !y1 || !elcs || !ns || !scratch) return GODE_E_NULLPTR;
+    if (count < 1 || count > 4) return GODE_E_RANGE;
+    MultiErr m;
+    int nbmax = 0;
+    for (int c = 0; c < 4; ++c) { m.lc[c] = make_lincomb(nullptr); m.y0[c] = m.y1[c] = nullptr; m.n[c] = 0; m.nb[c] = 0; m.vec[c] = 0; }
+    for (int c = 0; c < count; ++c) {
+        if (ns[c] <= 0) return GODE_E_SHAPE;
+        if (!y0[c] || !y1[c]) return GODE_E_NULLPTR;
+        int rc = check_lincomb(&elcs[c], true); if (rc) return rc;
+        m.lc[c] = make_lincomb(&elcs[c]); m.y0[c] = y0[c]; m.y1[c] = y1[c]; m.n[c] = ns[c];
+        m.nb[c] = red_blocks(ns[c]);                           // as gode_rk_errnorm_f32 decomposes this component
+        m.vec[c] = (ns[c] % 4 == 0 && lincomb_aligned16(&elcs[c]) && !((((uintptr_t)y0[c]) | ((uintptr_t)y1[c])) & 15)) ? 1 : 0;
+        if (m.nb[c] > nbmax) nbmax = m.nb[c];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ratio_sumsq_multi_kernel, dim3((unsigned)nbmax, (unsigned)count), dim3(256), 0, s, (double*)scratch, m, rtol, atol);
+    GODE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(final_sum_multi_kernel, dim3((unsigned)count), dim3(256), 0, s, out, (const double*)scratch, m);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int gode_rk_errnorm_f32(double* out, const float* y0, const float* y1, const gode_lincomb_t* elc,
                                    float rtol, float atol, int64_t n, void* scratch, void* stream) {

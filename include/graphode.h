@@ -124,6 +124,11 @@ int64_t gode_rk_errnorm_scratch_bytes(void);
 int gode_rk_errnorm_f32(double* out, const float* y0, const float* y1,
                         const gode_lincomb_t* elc /* host */, float rtol, float atol,
                         int64_t n, void* scratch, void* stream);
+/* up to four such sums (the components of an adjoint state) in one pair of launches; out[count]; every sum is bit for bit
+ * the one gode_rk_errnorm_f32 forms.  scratch: gode_rk_errnorm_scratch_bytes() */
+int gode_rk_errnorm_multi_f32(double* out, const float* const* y0 /* host[count] */, const float* const* y1,
+                              const gode_lincomb_t* elcs /* host[count] */, const int64_t* ns, int32_t count, float rtol,
+                              float atol, void* scratch, void* stream);
 
 /* sum of squares of sum_j lc.coef[j]*lc.ptr[j][i] / (atol + rtol*|y[i]|) (initial-step heuristic), fp64 */
 int gode_rk_scaled_sumsq_f32(double* out, const gode_lincomb_t* lc /* host */, const float* y,

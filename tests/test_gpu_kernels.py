@@ -746,3 +746,28 @@ def test_lincomb_multi_one_launch_for_four_components():
     two = [ys[0].clone(), ys[3].clone()]
     ops.lincomb_multi_(two, [[(2.0, ys[0])], [(1.0, ys[3]), (-1.0, ks[0][3])]])
     assert torch.equal(two[0], 2.0 * ys[0]) and torch.allclose(two[1], ys[3] - ks[0][3], atol=0, rtol=0)
+
+
+def test_errnorm_multi_matches_the_single_form_bit_for_bit():
+    """gode_rk_errnorm_multi_f32: the four error-ratio sums that close an adaptive step of the adjoint state [y, a, a_t, theta]
+    in one pair of launches - every sum identical to gode_rk_errnorm_f32's (same block decomposition per component)."""
+    import ctypes
+    from graph_odenet_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(8)
+    D = dev()
+    sizes = [2708 * 16, 2708 * 16, 1, 323]
+    y0 = [torch.randn(n, generator=g).to(D) for n in sizes]
+    y1 = [torch.randn(n, generator=g).to(D) for n in sizes]
+    ks = [[torch.randn(n, generator=g).to(D) for n in sizes] for _ in range(3)]
+    coef = [0.3, -0.7, 0.11]
+    single = [ops.rk_error_sumsq(y0[c], y1[c], [(coef[j], ks[j][c]) for j in range(3)], 1e-4, 1e-5).item() for c in range(4)]
+    out = torch.empty(4, dtype=torch.float64, device=D)
+    sc = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), dtype=torch.uint8, device=D)
+    lcs = (_lib.LinComb * 4)(*[_lib.lincomb([(coef[j], ks[j][c]) for j in range(3)]) for c in range(4)])
+    p0 = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in y0])
+    p1 = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in y1])
+    ns = (ctypes.c_int64 * 4)(*sizes)
+    _lib.check(lib.gode_rk_errnorm_multi_f32(_lib.ptr(out), p0, p1, lcs, ns, 4, 1e-4, 1e-5, _lib.ptr(sc), _lib.stream_ptr()),
+               "gode_rk_errnorm_multi_f32")
+    assert out.tolist() == single
