@@ -9,10 +9,16 @@ Workload (config C5 of SURVEY.md §8(d), the one the metric is quoted on; fits o
   adjoint backward (64 recomputed f-evals + 64 VJPs), Adam(lr .01, wd 5e-4) step
   (GCN/train_res.py:63-79,126-127).  One "step" = that whole pass over one graph.
 
-Multi-GPU (--gpus N, launched with torch.distributed.run): every rank owns an independent
-R-MAT graph (seed = rank), i.e. a batch of N graphs sharded one per GPU; the only exchange step is
-one flattened RCCL all-reduce of the gradients per step.  scaling = "weak";
-value = N*K / max-over-ranks time.
+Multi-GPU (--gpus N): launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, or bare as
+`python bench.py --gpus N`, which starts the N ranks itself as fresh child processes before any GPU call
+(graph_odenet_amd/launch.py).  Every rank owns an independent R-MAT graph (seed = rank), i.e. a batch of N graphs sharded
+one per GPU; the only exchange step is the RCCL all-reduce of the gradients per step.  scaling = "weak";
+value = N*K / max-over-ranks time.  Under N > 1 the line also carries the two other multi-GPU workloads of SURVEY 8(e),
+measured after (outside) the timed region: `secondary.qc_data_parallel` (C4: batches of 20 molecules per rank, the 57 MB
+bucketed gradient exchange, graphs/s; tools/qc_bench.py) and `secondary.strong_scaling` (the SAME C5 graph row-partitioned
+over the ranks, one all-gather per aggregation; tools/partition_bench.py), and `rccl_ranks` = the ranks that answered a
+checked all-reduce of 1.0.  With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks share the GPUs and exchange
+over gloo; `backend` says which.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (SpMM main
 kernel, HIP events recorded around every launch of the timed region by libgraphode's profiler
@@ -57,7 +63,14 @@ def parse():
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the step times of the other BASELINE.json configurations (Cora / Pubmed / Citeseer-GAT / QC)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the untimed-by-contract extras: per-f-eval times and the 256-eval reading")
+                    help="skip the untimed-by-contract extras: per-f-eval times and the 256-eval reading (N = 1); the QC "
+                         "data-parallel and strong-scaling entries (N > 1)")
+    ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto",
+                    help="auto: nccl (= RCCL) with a GPU per rank, else gloo with the ranks sharing the GPUs (rehearsal)")
+    ap.add_argument("--configs-timeout", type=float, default=420.0, help="seconds allowed to tools/config_bench.py (N = 1)")
+    ap.add_argument("--qc-steps", type=int, default=30, help="timed steps of secondary.qc_data_parallel (N > 1)")
+    ap.add_argument("--secondary-timeout", type=float, default=420.0,
+                    help="N > 1: seconds after which the line is printed without the secondary entries still running")
     return ap.parse_args()
 
 
@@ -198,22 +211,70 @@ def dense_table(lib, cnt, ms, dd, rr, xx, kk, n, hidden, flop, nd4):
     return out
 
 
+def multi_gpu_secondary(args, dev, rank, world, backend):
+    """SURVEY 8(e)'s two other multi-GPU workloads, after the timed region; every rank calls this (collectives inside).
+    An exception on every rank becomes an `error` entry; a hang is the watchdog's business (main)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    out = {}
+    small = args.scale < 20            # rehearsal sizes: keep the QC leg short too
+    try:
+        import qc_bench
+        out["qc_data_parallel"] = qc_bench.run(dev, rank, world, backend, "MPNN_ENN_K_Set2Set",
+                                               steps=max(2, args.qc_steps if not small else min(args.qc_steps, 4)),
+                                               warmup=3 if not small else 1, batch_size=20)
+    except Exception as e:
+        import traceback
+        out["qc_data_parallel"] = {"error": "%s: %s" % (type(e).__name__, e), "where": traceback.format_exc()[-1500:]}
+    torch.cuda.empty_cache()
+    try:
+        import partition_bench
+        out["strong_scaling"] = partition_bench.run(dev, rank, world, backend, args.scale, args.edges, args.nfeat,
+                                                    args.hidden, args.nclass, args.ode_steps, steps=max(1, min(args.steps, 2)),
+                                                    warmup=1)
+    except Exception as e:
+        import traceback
+        out["strong_scaling"] = {"error": "%s: %s" % (type(e).__name__, e), "where": traceback.format_exc()[-1500:]}
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    from graph_odenet_amd import launch
+    if launch.needs_self_launch(args.gpus):
+        # bare `python bench.py --gpus N`: start the N ranks as fresh children BEFORE this process touches the GPU, relay
+        # their output (rank 0 prints the JSON line) and leave with their exit code
+        sys.exit(launch.self_launch(__file__, sys.argv[1:], args.gpus))
+    other_configs = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_configs and not args.no_secondary:
+        # The other BASELINE.json configurations (parity-test cases) with their CPU legs, timed on this box by
+        # tools/config_bench.py in a CHILD process that runs to completion BEFORE this process makes its first GPU call
+        # (a process that has initialised the GPU starts no further programs on this pool).  A fresh process also keeps
+        # the C4 leg's HIP-graph captures of arbitrary autograd away from the process that prints the contract line.
+        import subprocess
+        try:
+            assert not torch.cuda.is_initialized()
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "config_bench.py"), "--one-line"],
+                                capture_output=True, text=True, timeout=args.configs_timeout)
+            lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+            if cp.returncode != 0 or not lines:
+                raise RuntimeError("config_bench.py rc %d: %s" % (cp.returncode, (cp.stderr or cp.stdout)[-400:]))
+            other_configs = json.loads(lines[-1])
+        except Exception as e:
+            other_configs = {"error": "%s: %s" % (type(e).__name__, e)}
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
+    if args.force_dist and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        rank, local_rank, world, backend = 0, 0, 1, "nccl"
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    else:
+        rank, local_rank, world, dev, backend = launch.init_ranks(args.backend)      # includes the checked all-reduce of 1.0
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
+    use_dist = world > 1 or args.force_dist
 
     from graph_odenet_amd import _lib, models, ops
     from graph_odenet_amd import parallel
@@ -344,15 +405,10 @@ def main():
             finally:
                 lib.gode_set_option(b"overlap", 1)
                 lib.gode_prof_destroy(prof2)
-        if not args.no_configs:
-            # the other BASELINE.json configurations (parity-test cases), timed on this box: tools/config_bench.py
-            try:
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import config_bench
-                extras["other_configs"] = config_bench.all_configs(dev)
-            except Exception as e:
-                extras["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if other_configs is not None:
+            extras["other_configs"] = other_configs
 
+    res = None
     if rank == 0:
         res = {
             "metric": "full-graph ODE-GCN forward+backward steps/sec at 64 RK4 evals",
@@ -371,6 +427,11 @@ def main():
             "roofline": roof,
             "roofline_dense": dense,
         }
+        if use_dist:
+            # ranks that answered the checked all-reduce of 1.0 at start-up (launch.init_ranks), and what carried it:
+            # "nccl" = RCCL, one GPU per rank; "gloo" = rehearsal, the ranks share the GPUs of a smaller box
+            res["rccl_ranks"] = dist.get_world_size()
+            res["backend"] = backend
         if extras is not None:
             res["secondary"] = extras
         if world == 1 and not args.no_cpu_baseline:
@@ -378,8 +439,42 @@ def main():
             rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1]).cpu()
             gc = {"n": n, "r": rows, "c": g.col.to(torch.int64).cpu(), "v": g.val.cpu()}
             res["cpu_baseline"] = cpu_baseline(args, gc, sd_cpu, x.cpu())
+
+    if world > 1 and not args.no_secondary:
+        # The two other multi-GPU workloads run AFTER the contract measurement is complete.  They are collective code
+        # that may stall on a node this build has never seen: a watchdog prints the line without them (and ends the
+        # process, on every rank) rather than let a secondary number take the contract line down.
+        import threading
+        lock, done = threading.Lock(), [False]
+
+        def give_up():
+            with lock:
+                if done[0]:
+                    return
+                done[0] = True
+                if rank == 0:
+                    res["secondary"] = {"error": "qc_data_parallel / strong_scaling did not finish within %.0f s"
+                                                 % args.secondary_timeout}
+                    print(json.dumps(res), flush=True)
+                os._exit(0)
+        dog = threading.Timer(args.secondary_timeout + (0.0 if rank == 0 else 15.0), give_up)
+        dog.daemon = True
+        dog.start()
+        del model, opt, bucket, x, labels, idx_train, step
+        g = g_run = None
+        torch.cuda.empty_cache()
+        sec = multi_gpu_secondary(args, dev, rank, world, backend)
+        with lock:
+            dog.cancel()
+            if done[0]:
+                return
+            done[0] = True
+        if rank == 0:
+            res["secondary"] = sec
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

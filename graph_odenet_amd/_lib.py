@@ -127,6 +127,9 @@ SIGNATURES = {
     "gode_rect_wgrad_parts": (c_i64, [c_i64]),
     "gode_rect_wgrad_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p]),
     "gode_gemm_f32": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p, c_i64, c_p]),
+    "gode_cut_pad": (c_i64, [c_i64]),
+    "gode_cut_bf16x3_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p]),
+    "gode_pgemm_bf16x3": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_i64, c_i, c_p]),
     "gode_adam_chunk": (c_i64, []),
     "gode_adam_tick_f32": (c_i, [c_p, c_f, c_f, c_p]),
     "gode_adam_f32": (c_i, [ctypes.POINTER(AdamArgs), ctypes.c_int32, c_p, c_i64, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),

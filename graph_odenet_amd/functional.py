@@ -141,7 +141,8 @@ class Linear(torch.nn.Linear):
 class _Mlp2Fn(torch.autograd.Function):
     """y = relu(x W1 + b1) W2 + b2 - the TransitionMLP of QC/layers.py:67-77, in particular the edge encoder
     (5 -> 2667 -> 5329 on the ~760 edge rows of a QM9 batch: QC/layers.py:79-86) - as two launches forward and five
-    backward of gode_gemm_f32 with bias / relu / relu-mask fused into the epilogues:
+    backward of gode_gemm_f32 (large second layers: gode_pgemm_bf16x3 from operands cut once per step) with bias / relu /
+    relu-mask fused into the epilogues:
         H = relu(x W1 + b1);  y = H W2 + b2
         dW2 = H^T dy;  db2 = colsum(dy);  dH = (dy W2^T) * [H > 0];  dW1 = x^T dH;  db1 = colsum(dH);  dx = dH W1^T"""
 
@@ -149,7 +150,15 @@ class _Mlp2Fn(torch.autograd.Function):
     def forward(ctx, x, W1, b1, W2, b2):
         x, W1, W2 = x.contiguous(), W1.contiguous(), W2.contiguous()
         H = ops.gemm(x, W1, bias=b1, relu=True)
-        y = ops.gemm(H, W2, bias=b2)
+        # large second layer (the edge encoder: 760 x 2667 x 5329): the three big products of the step run on the bf16
+        # matrix cores from exact cuts (csrc/pgemm.hip); H and W2 are cut once here and serve the backward pass too
+        ctx.cuts = None
+        if ops.pgemm_pays(H.shape[0], W2.shape[1], W2.shape[0]):
+            Hc, W2c = ops.cut3(H), ops.cut3(W2)
+            y = ops.pgemm(Hc, W2c, bias=b2)
+            ctx.cuts = (Hc, W2c)
+        else:
+            y = ops.gemm(H, W2, bias=b2)
         ctx.save_for_backward(x, H, W1, W2)
         ctx.has_bias = (b1 is not None, b2 is not None)
         return y
@@ -160,17 +169,22 @@ class _Mlp2Fn(torch.autograd.Function):
         dy = dy.contiguous()
         need = ctx.needs_input_grad
         f = dict(dtype=torch.float32, device=dy.device)
-        gW2 = ops.gemm(H, dy, trans_a=True) if need[3] else None
+        big = ctx.cuts is not None
+        dyc = ops.cut3(dy) if big and (need[3] or need[0] or need[1] or need[2]) else None
+        gW2 = None
+        if need[3]:
+            gW2 = ops.pgemm(ctx.cuts[0], dyc, trans_a=True) if big else ops.gemm(H, dy, trans_a=True)
         gb2 = ops.colsum_(torch.empty(dy.shape[1], **f), dy) if (ctx.has_bias[1] and need[4]) else None
         gx = gW1 = gb1 = None
         if need[0] or need[1] or need[2]:
-            dH = ops.gemm(dy, W2, trans_b=True, mask=H)
+            dH = ops.pgemm(dyc, ctx.cuts[1], trans_b=True, mask=H) if big else ops.gemm(dy, W2, trans_b=True, mask=H)
             if need[1]:
                 gW1 = ops.gemm(x, dH, trans_a=True)
             if ctx.has_bias[0] and need[2]:
                 gb1 = ops.colsum_(torch.empty(dH.shape[1], **f), dH)
             if need[0]:
                 gx = ops.gemm(dH, W1, trans_b=True)
+        ctx.cuts = None
         return gx, gW1, gb1, gW2, gb2
 
 

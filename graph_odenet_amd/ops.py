@@ -416,7 +416,7 @@ def rect_wgrad(x, dS):
 
 def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, mask=None, out=None):
     """C = op(A) @ op(B) (+ bias) (relu) (* [mask > 0]) on csrc/mlp.hip's fp32-MFMA GEMM (row-major matrices with unit
-    column stride; any leading dimension)."""
+    column stride; any leading dimension); large products (pgemm_pays) are cut and go to csrc/pgemm.hip."""
     lib = _lib.load()
     lda, ldb = _need_rows(A, "A"), _need_rows(B, "B")
     M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
@@ -439,8 +439,64 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, mask=None, o
     if K == 0:
         out.zero_()
         return out if bias is None else out.add_(bias)
+    if pgemm_pays(M, N, K):
+        return pgemm(cut3(A), cut3(B), trans_a, trans_b, bias, relu, mask, out)
     check(lib.gode_gemm_f32(1 if trans_a else 0, 1 if trans_b else 0, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
                             ptr(bias), 1 if relu else 0, ptr(mask), ldm, stream_ptr()), "gode_gemm_f32")
+    return out
+
+
+class Cut3:
+    """The three bf16 piece planes of an fp32 matrix (gode_cut_bf16x3_f32): x = hi + mid + lo exactly; rows and columns
+    zero-padded to multiples of 128.  Cut once, used by every product the matrix enters, in either operand role."""
+
+    __slots__ = ("planes", "rows", "cols")
+
+    def __init__(self, planes, rows, cols):
+        self.planes, self.rows, self.cols = planes, rows, cols
+
+
+def cut3(X):
+    lib = _lib.load()
+    ld = _need_rows(X, "X")
+    R, C = X.shape
+    Rp, Cp = lib.gode_cut_pad(R), lib.gode_cut_pad(C)
+    planes = torch.empty(3, Rp, Cp, dtype=torch.bfloat16, device=X.device)
+    check(lib.gode_cut_bf16x3_f32(ptr(X), ld, R, C, ptr(planes), stream_ptr()), "gode_cut_bf16x3_f32")
+    return Cut3(planes, R, C)
+
+
+PGEMM_MIN_FLOP = 2.0e9          # products below this stay on the exact-fp32 MFMA kernel (the cuts are two extra passes)
+
+
+def pgemm_pays(M, N, K):
+    """Whether C[M x N] = A B with inner dimension K goes to the bf16-piece kernel: enough work to pay for cutting both
+    operands, and no dimension so small that the 128 x 128 x 32 tiles are mostly padding."""
+    return 2.0 * M * N * K >= PGEMM_MIN_FLOP and min(M, N) >= 256 and K >= 256
+
+
+def pgemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, mask=None, out=None, products=8):
+    """C = op(A) @ op(B) from Cut3 operands on the bf16 matrix cores (csrc/pgemm.hip); arguments as gemm()."""
+    lib = _lib.load()
+    M, K = (A.cols, A.rows) if trans_a else (A.rows, A.cols)
+    K2, N = (B.cols, B.rows) if trans_b else (B.rows, B.cols)
+    if K != K2:
+        raise ValueError("pgemm: inner dimensions differ (%d vs %d)" % (K, K2))
+    _need(bias, "bias")
+    if bias is not None and bias.numel() != N:
+        raise ValueError("pgemm: bias must have %d elements" % N)
+    ldm = 0
+    if mask is not None:
+        ldm = _need_rows(mask, "mask")
+        if tuple(mask.shape) != (M, N):
+            raise ValueError("pgemm: mask must be %d x %d" % (M, N))
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.planes.device)
+    ldc = _need_rows(out, "out")
+    if tuple(out.shape) != (M, N):
+        raise ValueError("pgemm: out must be %d x %d" % (M, N))
+    check(lib.gode_pgemm_bf16x3(1 if trans_a else 0, 1 if trans_b else 0, M, N, K, ptr(A.planes), ptr(B.planes), ptr(out), ldc,
+                                ptr(bias), 1 if relu else 0, ptr(mask), ldm, int(products), stream_ptr()), "gode_pgemm_bf16x3")
     return out
 
 

@@ -10,6 +10,12 @@ torch.optim.Adam and back.  At QM9 batch sizes a step of the 14.3 M-parameter mo
 multi-tensor Adam (~30 launches with foreach); here it is two launches, and both are kernels, so the step can be
 captured into a HIP graph (qc_step.CapturedQCStep: the step counter lives on the device and is advanced by the launch).
 Parameters whose `.grad` is None are skipped, as torch does.  GPU float32 parameters only: there is no CPU path.
+
+One deviation from torch.optim.Adam: the step count (hence the bias corrections) is kept PER PARAMETER GROUP, on the
+device, not per parameter.  A parameter that receives its first gradient k steps after the others of its group (a head
+that joins late, a rank-local unused parameter) is corrected with the group's count where torch would start it at 1,
+and its exported `state['step']` is the group's count.  Every model of the reference gives all parameters a gradient
+in every step, so the two coincide there; put late joiners in their own param group to get torch's behaviour.
 """
 import ctypes
 
@@ -31,7 +37,9 @@ class Adam(torch.optim.Optimizer):
         """Launch plan of one group for the parameters that have a gradient: argument blocks of <= 64 tensors with their
         chunk lists.  Rebuilt when the set of tensors or one of their addresses changes (host-side bookkeeping only)."""
         lib = _lib.load()
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in active)
+        # the argument blocks bake in the addresses of all four arrays of a tensor: all four are part of the key
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel(), self.state[p]["exp_avg"].data_ptr(),
+                     self.state[p]["exp_avg_sq"].data_ptr()) for p in active)
         hit = self._plans.get(gi)
         dev = active[0].device
         if hit is not None and hit[0] == key:
@@ -68,6 +76,20 @@ class Adam(torch.optim.Optimizer):
         plan = (key, blocks, state_t)
         self._plans[gi] = plan
         return plan
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the moment tensors and the step counts: every launch plan (which holds their
+        addresses and the device step counter) is dropped, so that the next step re-seeds the counter from the loaded
+        `step` and points the kernel at the loaded moments."""
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            g["capturable"] = True        # a torch.optim.Adam checkpoint says False; this update always reads a device counter
+        self._plans.clear()
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_plans"):
+            self._plans.clear()
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -12,11 +12,12 @@ readouts are per graph, and rows outside the loss carry no gradient.
 import torch
 
 
-def pad_batch(x, edge_feat, Esrc, Etgt, batch, node_multiple=64, edge_multiple=128):
+def pad_batch(x, edge_feat, Esrc, Etgt, batch, node_multiple=64, edge_multiple=128, n_graphs=None):
     """Returns (x, edge_feat, Esrc, Etgt, batch, n_graphs) with x.shape[0] a multiple of `node_multiple`, Esrc.numel()
     a multiple of `edge_multiple`, and the dummy graph numbered n_graphs (use `out[:n_graphs]`).  `Etgt` is the dense
     N x E matrix of the reference's collate, or the per-edge target index vector (int64[E]) a loader has before it
-    builds that matrix - the same kind comes back."""
+    builds that matrix - the same kind comes back.  `n_graphs`: the number of graphs of the batch when the caller knows it
+    (one target row per graph); otherwise it is read from `batch` (one host synchronisation)."""
     n, e = x.shape[0], Esrc.numel()
     by_index = Etgt.dim() == 1 and not Etgt.is_floating_point()       # per-edge target index instead of the dense matrix
     if by_index:
@@ -25,7 +26,8 @@ def pad_batch(x, edge_feat, Esrc, Etgt, batch, node_multiple=64, edge_multiple=1
     elif Etgt.dim() != 2 or tuple(Etgt.shape) != (n, e) or Etgt.layout != torch.strided:
         raise ValueError("pad_batch: Etgt must be the dense N x E incidence of the reference's collate (or the per-edge "
                          "target index vector)")
-    n_graphs = int(batch.max().item()) + 1 if n else 0
+    if n_graphs is None:
+        n_graphs = int(batch.max().item()) + 1 if n else 0
     e_pad = -(-max(e, 1) // edge_multiple) * edge_multiple
     n_pad = -(-(n + 1) // node_multiple) * node_multiple            # at least one dummy atom: dummy edges live on it
     dn, de = n_pad - n, e_pad - e

@@ -1,0 +1,83 @@
+"""The body of the reference's QC training loop (QC/util.py:146-211: zero_grad, forward, criterion, backward,
+optimizer.step on a NEW mini-batch every iteration) as one object, with the mode this platform runs it fastest in as
+the default (BASELINE.json configs[3]).
+
+    step = qc_train.TrainStep(model, optimizer, criterion)            # mode="auto"
+    for batch_size, g, b, x, e_d, e_src, e_tgt, target in train_loader:
+        loss = step(x, e_d, e_src, e_tgt, b, target)                  # a device tensor; read it when you log
+
+`e_tgt` is the reference collate's dense N x E incidence or - cheaper, what a loader has before it builds that matrix -
+the per-edge target index vector (int64[E]); `b` the sorted graph index of every node (collate order).
+
+Modes:
+  "eager"     the reference's loop body as it stands: per-batch conversion of the dense matrix (one host synchronisation
+              for its validity check), ~250 launches from Python;
+  "prepared"  the edges go in as index vectors (qc_batch.prepare): no dense matrix, no host synchronisation;
+  "captured"  the batch is padded to its shape bucket (qc_batch.pad_batch: multiples of 64 atoms / 128 edges, one dummy
+              graph) and the whole step - conversion, forward, loss, backward, Adam - is ONE HIP-graph replay per
+              bucket (qc_step.CapturedQCStep); a dense `e_tgt` is reduced to index vectors first (a column arg-max, no
+              synchronisation), so that only index vectors are copied into the bucket's static buffers;
+  "auto"      "captured" when this process may rely on replayed memset nodes (hipgraph.memset_nodes_ok: start the
+              process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 or call hipgraph.prefer_safe_graphs() first) and the optimiser
+              is capturable (graph_odenet_amd.optim.Adam is), else "prepared" for index-vector batches and "eager" for
+              dense ones.
+The number of graphs of a batch is taken from `target.shape[0]` (one row per graph, as the reference's collate emits),
+never read back from the device.
+
+Multi-GPU (one rank per GPU, parallel.GradBucket): pass `exchange=lambda: bucket.allreduce_mean(assume_all=True)`; then
+forward + backward are captured and the exchange and the optimiser step run after the replay.
+
+A learning-rate change between epochs (QC/train_egcn.py:160-164) reaches a captured step only through a new capture:
+call `step.reset()` after changing `param_groups[...]["lr"]`.
+"""
+import torch
+
+from . import hipgraph
+from .qc_batch import pad_batch, prepare
+from .qc_step import CapturedQCStep
+
+
+class TrainStep:
+    def __init__(self, model, optimizer, criterion, mode="auto", exchange=None):
+        if mode not in ("auto", "eager", "prepared", "captured"):
+            raise ValueError("TrainStep: mode must be auto / eager / prepared / captured")
+        self.model, self.opt, self.criterion, self.exchange = model, optimizer, criterion, exchange
+        self.requested = mode
+        self.mode = None                 # decided at the first call (needs the device)
+        self._captured = None
+
+    def reset(self):
+        """Drop the captured graphs (after a hyper-parameter change that a captured step bakes in)."""
+        self._captured = None
+
+    def _decide(self, x, by_index):
+        m = self.requested
+        if m == "auto":
+            capturable = all(g.get("capturable", False) for g in self.opt.param_groups) or self.exchange is not None
+            m = "captured" if (x.is_cuda and capturable and hipgraph.memset_nodes_ok(x.device)) else \
+                ("prepared" if by_index else "eager")
+        if m == "prepared" and not by_index:
+            m = "eager"
+        return m
+
+    def __call__(self, x, edge_feat, Esrc, Etgt, batch, target):
+        by_index = Etgt.dim() == 1 and not Etgt.is_floating_point()
+        if self.mode is None:
+            self.mode = self._decide(x, by_index)
+        n_graphs = target.shape[0]
+        if self.mode == "captured":
+            if not by_index:
+                Etgt = (Etgt != 0).to(torch.uint8).argmax(0)         # one entry per edge column (the collate's layout)
+            x, edge_feat, Esrc, Etgt, batch, _ = pad_batch(x, edge_feat, Esrc, Etgt, batch, n_graphs=n_graphs)
+            if self._captured is None:
+                self._captured = CapturedQCStep(self.model, self.opt, self.criterion, exchange=self.exchange)
+            return self._captured(x, edge_feat, Esrc, Etgt, batch, target, n_graphs=n_graphs + 1)
+        if self.mode == "prepared":
+            Etgt, batch = prepare(Esrc, Etgt, batch, x.shape[0], n_graphs)
+        self.opt.zero_grad(set_to_none=False)
+        loss = self.criterion(self.model(x, edge_feat, Esrc, Etgt, batch), target)
+        loss.backward()
+        if self.exchange is not None:
+            self.exchange()
+        self.opt.step()
+        return loss.detach()

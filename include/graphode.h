@@ -25,6 +25,7 @@
  *   gode_lincomb_f32             torchdiffeq RK stage input / solution combine (call site GCN/models.py:192)
  *   gode_rk_errnorm_f32          torchdiffeq dopri5 mixed-tolerance error ratio (same call site)
  *   gode_gemm_f32                QC/layers.py:46-86 EdgeEncoderMLP (torch.mm + bias + relu on the edge rows) and its autograd
+ *   gode_cut_bf16x3_f32, gode_pgemm_bf16x3   the same call sites for large products (bf16 matrix cores, exact 3-way cuts)
  *   gode_adam_f32                optimizer.step() of QC/train_egcn.py, GCN/train_res.py:97 (torch.optim.Adam)
  *   gode_gat_*                   GAT/layers.py:40-55 (and :104-120)
  *   gode_edge_matvec_*           QC/mpnn.py:27-29, QC/layers.py:143-145
@@ -232,6 +233,21 @@ int gode_rect_wgrad_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, 
 int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
                   const float* mask, int64_t ldmask, void* stream);
+
+/* The same products for LARGE shapes on the bf16 matrix cores, from exact three-way cuts of the fp32 operands
+ * (csrc/pgemm.hip; replaces the three 21.6 GFLOP products of the edge encoder, QC/layers.py:46-86 and autograd:
+ * H W2, dA W2^T, H^T dA).  Step 1, once per matrix: gode_cut_bf16x3_f32 writes the three bf16 piece planes of X (R x C,
+ * leading dimension ld, any alignment): planes = 3 x R_pad x C_pad bf16, R_pad = gode_cut_pad(R), C_pad = gode_cut_pad(C)
+ * (multiples of 128), zero outside R x C; x = hi + mid + lo exactly.  16-byte aligned, caller-owned
+ * (6 * R_pad * C_pad bytes).  Step 2: gode_pgemm_bf16x3 forms C = op(A) op(B) (fp32, M x N, leading dimension ldc) from the
+ * planes of A AS STORED (M x K if trans_a = 0, K x M if 1) and of B AS STORED (K x N if trans_b = 0, N x K if 1), i.e. a cut
+ * matrix serves every product it enters in either role.  products = 8 (every piece product >= 2^-32 of a product; an fp32
+ * result) or 6 (also without mid*lo, lo*mid: 2^-24 each).  Epilogue as gode_gemm_f32: + bias[col], relu, * (mask > 0). */
+int64_t gode_cut_pad(int64_t n);
+int gode_cut_bf16x3_f32(const float* X, int64_t ld, int64_t R, int64_t C, void* planes, void* stream);
+int gode_pgemm_bf16x3(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void* A_planes,
+                      const void* B_planes, float* C, int64_t ldc, const float* bias, int relu,
+                      const float* mask, int64_t ldmask, int products, void* stream);
 
 /* torch.optim.Adam's update (no amsgrad; L2 weight decay) of up to GODE_ADAM_MAX_TENSORS tensors in ONE launch - the
  * `optimizer.step()` of QC/train_egcn.py / GCN/train_res.py:97.  args (host; copied into the kernel arguments): device

@@ -33,7 +33,7 @@ def pytest_configure(config):
 # extensions (H-head attention), the full-size property tests and the multi-rank tests.  A red extension test can
 # then no longer hide the section-8(a) evidence.  Files not listed keep their place after the listed ones.
 GPU_FILE_ORDER = ["test_gpu_kernels.py", "test_gpu_gcn.py", "test_gpu_gat_qc.py", "test_gpu_harness.py",
-                  "test_gpu_variants.py", "test_gpu_gat_heads.py", "test_gpu_fullsize.py", "test_gpu_partition.py"]
+                  "test_gpu_variants.py", "test_gpu_gat_heads.py", "test_gpu_fullsize.py", "test_gpu_partition.py", "test_gpu_bench.py"]
 
 
 def pytest_collection_modifyitems(session, config, items):

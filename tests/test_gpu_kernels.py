@@ -723,6 +723,116 @@ def test_one_launch_adam_matches_torch_adam():
     assert float(o_new.state[o_new.param_groups[0]["params"][0]]["step"]) == 8.0
 
 
+def test_adam_resumes_from_a_loaded_state_dict():
+    """step, load_state_dict (a checkpoint taken earlier), step - against torch.optim.Adam doing the same on the CPU: the
+    launch plan holds the addresses of the moment buffers and the device step counter, both replaced by the loader
+    (the round-3 plan key missed them and kept updating the freed buffers)."""
+    from graph_odenet_amd import optim
+    g = torch.Generator().manual_seed(5)
+    shapes = [(40, 7), (129,), (3, 3)]
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    got = [p.detach().clone().to(dev()).requires_grad_(True) for p in ref]
+    kw = dict(lr=1e-2, weight_decay=5e-4)
+    o_ref, o_got = torch.optim.Adam(ref, **kw), optim.Adam(got, **kw)
+
+    def both(n):
+        for _ in range(n):
+            for p, q, s in zip(ref, got, shapes):
+                gr = torch.randn(s, generator=g)
+                p.grad, q.grad = gr.clone(), gr.clone().to(dev())
+            o_ref.step(); o_got.step()
+    both(3)
+    import copy
+    ck_ref, ck_got = copy.deepcopy(o_ref.state_dict()), copy.deepcopy(o_got.state_dict())
+    w_ref, w_got = [p.detach().clone() for p in ref], [q.detach().clone() for q in got]
+    both(4)                                             # moves moments and counters away from the checkpoint
+    with torch.no_grad():
+        for p, q, a, b in zip(ref, got, w_ref, w_got):
+            p.copy_(a); q.copy_(b)
+    o_ref.load_state_dict(ck_ref); o_got.load_state_dict(ck_got)
+    both(2)
+    for p, q in zip(ref, got):
+        assert (q.detach().cpu() - p.detach()).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item())
+    assert float(o_got.state[got[0]]["step"]) == 5.0 == float(o_ref.state[ref[0]]["step"])
+    # and a torch checkpoint loads into the one-launch optimiser
+    o_two = optim.Adam(got, **kw)
+    o_two.load_state_dict(copy.deepcopy(o_ref.state_dict()))
+    both(0)
+    for p, q, s in zip(ref, got, shapes):
+        gr = torch.randn(s, generator=g)
+        p.grad, q.grad = gr.clone(), gr.clone().to(dev())
+    o_ref.step(); o_two.step()
+    for p, q in zip(ref, got):
+        assert (q.detach().cpu() - p.detach()).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item())
+
+
+def test_exact_three_way_cut_planes():
+    """gode_cut_bf16x3_f32: x = hi + mid + lo EXACTLY (three bf16 numbers, truncation), planes zero outside the matrix,
+    for a ragged matrix with an odd leading dimension (rows only 4-byte aligned, as the edge encoder's 2667 / 5329)."""
+    from graph_odenet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    wide = (torch.randn(301, 1203, generator=g) * torch.exp(4 * torch.randn(301, 1203, generator=g))).to(dev())
+    X = wide[:, 3:1202]                                             # 301 x 1199, ld = 1203, first column at an odd offset
+    c = ops.cut3(X)
+    assert tuple(c.planes.shape) == (3, 384, 1280) and (c.rows, c.cols) == (301, 1199)
+    pl = c.planes.float()
+    assert torch.equal(pl[0, :301, :1199] + pl[1, :301, :1199] + pl[2, :301, :1199], X)          # exact in fp32
+    assert float(pl[:, 301:, :].abs().max()) == 0.0 and float(pl[:, :, 1199:].abs().max()) == 0.0
+    hi = pl[0, :301, :1199]
+    assert bool((hi.abs() <= X.abs()).all()) and bool(((X - hi).abs() <= X.abs() * 2.0 ** -7).all())   # truncation, 8 bits
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 300, 150), (129, 257, 33), (1, 1, 1), (384, 256, 512)])
+def test_piece_gemm_all_operand_layouts_and_epilogues(M, N, K):
+    """csrc/pgemm.hip gode_pgemm_bf16x3 (large products of the QC edge encoder on the bf16 matrix cores from exact cuts):
+    C = op(A) op(B) for the four operand layouts - each operand read from LDS by ds_read_b128 or by the transposing
+    ds_read_b64_tr_b16 - ragged sizes, the fused epilogues, 8 and 6 piece products, against float64 at the bar of the
+    exact-fp32 kernel; the cut of a matrix serves both of its roles."""
+    from graph_odenet_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / max(K, 1) ** 0.5
+    bias, mask = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    D = dev()
+    ref = A.double() @ B.double()
+    scale = ref.abs().max().item() + 1e-30
+    tol = 3e-6 * scale
+    for ta in (False, True):
+        for tb in (False, True):
+            a = ops.cut3((A.t().contiguous() if ta else A).to(D))
+            b = ops.cut3((B.t().contiguous() if tb else B).to(D))
+            got = ops.pgemm(a, b, trans_a=ta, trans_b=tb).cpu()
+            assert (got.double() - ref).abs().max().item() <= tol, (ta, tb)
+            got6 = ops.pgemm(a, b, trans_a=ta, trans_b=tb, products=6).cpu()
+            assert (got6.double() - ref).abs().max().item() <= 2 * tol, (ta, tb, 6)
+    a, b = ops.cut3(A.to(D)), ops.cut3(B.to(D))
+    got = ops.pgemm(a, b, bias=bias.to(D), relu=True).cpu()
+    assert (got.double() - torch.relu(ref + bias.double())).abs().max().item() <= tol
+    got = ops.pgemm(a, b, mask=mask.to(D)).cpu()
+    assert (got.double() - ref * (mask > 0).double()).abs().max().item() <= tol
+    # the same cut of A as the TRANSPOSED operand of another product: A^T A (K x K), and a result inside a wider matrix
+    ata = ops.pgemm(a, a, trans_a=True).cpu()
+    ref2 = A.double().t() @ A.double()
+    assert (ata.double() - ref2).abs().max().item() <= 3e-6 * (ref2.abs().max().item() + 1e-30)
+    out = torch.full((M, N + 3), 7.0, device=D)
+    ops.pgemm(a, b, out=out[:, :N])
+    assert (out[:, :N].cpu().double() - ref).abs().max().item() <= tol and bool((out[:, N:] == 7.0).all())
+
+
+def test_piece_gemm_large_magnitude_spread():
+    """Operands whose entries span many binades (weights after training are not N(0, 1)): the cut is exact per element, so
+    the bar is the same - relative to sum |a||b| per output element, as for an fp32 fmaf chain."""
+    from graph_odenet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 260, 270, 700
+    A = torch.randn(M, K, generator=g) * torch.exp(3 * torch.randn(M, K, generator=g))
+    B = torch.randn(K, N, generator=g) * torch.exp(3 * torch.randn(K, N, generator=g))
+    D = dev()
+    got = ops.pgemm(ops.cut3(A.to(D)), ops.cut3(B.to(D))).cpu().double()
+    ref = A.double() @ B.double()
+    bound = A.double().abs() @ B.double().abs()
+    assert bool(((got - ref).abs() <= 1e-6 * bound).all())
+
+
 def test_lincomb_multi_one_launch_for_four_components():
     """gode_lincomb_multi_f32: the solution combine of an adjoint state [y, a, a_t, theta] as one launch - components of
     different lengths (one of them a single float, one not a multiple of four), in place on the first term, bit for bit the

@@ -213,3 +213,29 @@ def test_gat_multihead_layer(golden):
     for h, ps in enumerate(heads):
         for p, k in zip(ps, ("f__weight", "f__bias", "w__weight", "w__bias")):
             close(p.grad, g["h%d__grad__%s" % (h, k)], 1e-5)
+
+
+@pytest.mark.parametrize("name", ["MPNN_ENN_K_Set2Set", "EdgeGCN_K_Sum"])
+def test_qc_whole_model_restatements_vs_reference_golden(golden, name):
+    """oracle/models_ref.py (the functions the cpu_baseline legs time) against outputs and bias gradients of the
+    reference's own model classes (QC/layer_models.py:55-122) on a synthetic 4-molecule batch."""
+    from oracle import models_ref as M
+    g = golden("qc_models.npz")
+    x, ef = T(g["x"]), T(g["ef"])
+    Esrc, etgt, batch = T(g["Esrc"]).long(), T(g["etgt"]).long(), T(g["batch"]).long()
+    n, e = x.shape[0], Esrc.numel()
+    Etgt = torch.zeros(n, e)
+    Etgt[etgt, torch.arange(e)] = 1.0
+    pre = name + "__sd__"
+    p = M.leaves({k[len(pre):].replace("__", "."): T(g[k]) for k in g if k.startswith(pre)})
+    kw = dict(processing_steps=3) if name.endswith("Set2Set") else dict(dropout=0.0)
+    out = M.QC_MODELS[name](p, x, ef, Esrc, Etgt, batch, int(batch.max()) + 1, **kw)
+    close(out, T(g[name + "__out"]), 2e-6)
+    out.backward(T(g[name + "__gout"]))
+    pre = name + "__g__"
+    seen = 0
+    for k in g:
+        if k.startswith(pre):
+            close(p[k[len(pre):].replace("__", ".")].grad, T(g[k]), 1e-5)
+            seen += 1
+    assert seen >= 5

@@ -5,9 +5,11 @@ the numbers come from the same box as bench.py's line):
   C1  Cora, ODEGCN3 (GCN layers, hidden 16), rk4 16 steps = 64 f-evals             (configs[0])
   C2  Pubmed topology, GCN-dense-paper ODEGCN3 (hidden 16), dopri5 rtol=atol=1e-5    (configs[1]; synthetic features)
   C3  Citeseer edge list, GAT ODEGCN3 with 8 heads x 8 (hidden 64) and one head (hidden 16), rk4 64 f-evals (configs[2])
-  C4  QM9-like batches of 20 molecules, EdgeGCN_K_Sum / MPNN_ENN_K_Set2Set h=73 T=3, 16 distinct batches cycled (configs[3])
+  C4  QM9-like batches of 20 molecules, EdgeGCN_K_Sum / MPNN_ENN_K_Set2Set h=73 T=3, a NEW batch every step (configs[3])
 
-One step = forward + backward + Adam, as in the reference's training scripts.  `python tools/config_bench.py` prints one
+One step = forward + backward + Adam, as in the reference's training scripts.  Every entry also carries the CPU leg
+(`cpu_baseline_ms_per_step`, `cores`, `host_cpu_count`, `cpu_sample`): the oracle's restatement of the same model
+(oracle/models_ref.py) with the same weights, timed on this box's host cores in the same run.  `python tools/config_bench.py` prints one
 JSON object; bench.py calls all_configs() for its "secondary" block.  Inputs come from tests/golden (captured graph
 topologies) and graph_odenet_amd.synth."""
 import json
@@ -38,6 +40,35 @@ def _time_steps(fn, warm=3, n=10):
     return 1e3 * (time.perf_counter() - t0) / n, r
 
 
+def _cpu_fields(ms, sample):
+    """The fields every configuration adds for its CPU leg: the oracle (oracle/models_ref.py = the reference's model
+    restated from oracle/layers_ref.py + oracle/solver_ref.py, same weights) timed on this box's host cores."""
+    return {"cpu_baseline_ms_per_step": round(ms, 2), "cores": torch.get_num_threads(), "host_cpu_count": os.cpu_count(),
+            "cpu_kind": "port", "cpu_sample": sample}
+
+
+def _median_ms(fn, reps=3):
+    fn()                                            # one warm-up
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return 1e3 * sorted(ts)[len(ts) // 2]
+
+
+def _cpu_full_step(loss_fn, params, lr, wd):
+    """One reference-style training step on the host: zero_grad, forward, loss, backward, torch.optim.Adam
+    (GCN/train_res.py:63-79, QC/util.py:146-211)."""
+    opt = torch.optim.Adam(list(params.values()), lr=lr, weight_decay=wd)
+
+    def step():
+        opt.zero_grad()
+        loss_fn().backward()
+        opt.step()
+    return _median_ms(step)
+
+
 def _trainer(m, fwd, idx, y, lr=0.01, wd=5e-4):
     from graph_odenet_amd.optim import Adam
     opt = Adam(m.parameters(), lr=lr, weight_decay=wd)
@@ -51,7 +82,7 @@ def _trainer(m, fwd, idx, y, lr=0.01, wd=5e-4):
     return step
 
 
-def c1_cora(dev):
+def c1_cora(dev, cpu=True):
     from graph_odenet_amd import models
     g = dict(np.load(os.path.join(GOLD, "cora_graph.npz")))
     n = int(g["n"])
@@ -62,11 +93,19 @@ def c1_cora(dev):
     x, y, idx = x.to(dev), T(g["labels"].astype(np.int64)).to(dev), T(g["idx_train"].astype(np.int64)).to(dev)
     torch.manual_seed(0)
     m = models.ODEGCN3(nfeat=x.shape[1], nhid=16, nclass=7, dropout=0.5, method="rk4", step_size=1 / 16).to(dev)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     ms, (nf, nb) = _time_steps(_trainer(m, lambda: m(x, adj), idx, y))
-    return {"workload": "Cora 2708 nodes, ODEGCN3 hidden 16, rk4 64 f-evals", "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
+    res = {"workload": "Cora 2708 nodes, ODEGCN3 hidden 16, rk4 64 f-evals", "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
+    if cpu:
+        from oracle import models_ref as M
+        p = M.leaves(sd0)
+        xc, ac, yc, ic = x.cpu(), adj.cpu(), y.cpu(), idx.cpu()
+        t = _cpu_full_step(lambda: F.nll_loss(M.odegcn3(p, xc, ac, 0.5, True, "rk4", 1 / 16)[0][ic], yc[ic]), p, 0.01, 5e-4)
+        res.update(_cpu_fields(t, "whole training steps of the oracle's ODEGCN3 (rk4, 64 + 64 evaluations, Adam): 1 warm-up, median of 3"))
+    return res
 
 
-def c2_pubmed(dev):
+def c2_pubmed(dev, cpu=True):
     from graph_odenet_amd import dense_paper
     g = dict(np.load(os.path.join(GOLD, "pubmed_graph_sym.npz")))
     n = int(g["n"])
@@ -78,12 +117,40 @@ def c2_pubmed(dev):
     y, tr = torch.randint(0, 3, (n,), generator=gen).to(dev), torch.arange(60, device=dev)
     torch.manual_seed(0)
     m = dense_paper.ODEGCN3(nfeat=500, nhid=16, nclass=3, dropout=0.5).to(dev)                    # default method: dopri5
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     ms, (nf, nb) = _time_steps(_trainer(m, lambda: m(x, adj), tr, y))
-    return {"workload": "Pubmed 19717 nodes (real topology, synthetic features), GCN-dense-paper ODEGCN3 hidden 16, dopri5 tol 1e-5",
-            "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
+    res = {"workload": "Pubmed 19717 nodes (real topology, synthetic features), GCN-dense-paper ODEGCN3 hidden 16, dopri5 tol 1e-5",
+           "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
+    if cpu:
+        # bounded sample: one evaluation of the oracle's ODE function (dense 19717 x 19717 adjacency, as the reference
+        # holds it) and one evaluation with its VJP, scaled by the evaluation counts of the GPU step above; the two
+        # graph-convolution layers around the block timed once with their backward
+        from oracle import layers_ref as R, models_ref as M
+        p = M.leaves(sd0)
+        ac, xc = adj.cpu(), x.cpu()
+        fp = [p["gc2.odefunc.norm1.weight"], p["gc2.odefunc.norm1.bias"], p["gc2.odefunc.gc1.weight"], p["gc2.odefunc.gc1.bias"]]
+        with torch.no_grad():
+            h = torch.relu(R.graph_convolution(xc, ac, p["gc1.weight"], p["gc1.bias"]))
+            t_f = _median_ms(lambda: R.odefunc(torch.tensor(0.3), h, ac, *fp))
+
+        def fb():
+            hg = h.clone().requires_grad_(True)
+            out = R.odefunc(torch.tensor(0.3), hg, ac, *fp)
+            out.backward(torch.ones_like(out))
+        t_fb = _median_ms(fb)
+
+        def layers():
+            h1 = torch.relu(R.graph_convolution(xc, ac, p["gc1.weight"], p["gc1.bias"]))
+            R.graph_convolution(h1, ac, p["gc3.weight"], p["gc3.bias"]).sum().backward()
+        t_l = _median_ms(layers, reps=1)
+        res.update(_cpu_fields(t_l + nf * t_f + nb * t_fb,
+                               "oracle ODE function on the dense adjacency: f-eval %.1f ms, f-eval + VJP %.1f ms (1 warm-up, median of 3 each), "
+                               "first + last layer forward and backward %.1f ms; scaled to the GPU step's %d forward and %d adjoint evaluations"
+                               % (t_f, t_fb, t_l, nf, nb)))
+    return res
 
 
-def c3_citeseer_gat(dev, heads, nhid):
+def c3_citeseer_gat(dev, heads, nhid, cpu=True):
     from graph_odenet_amd import gat_heads, gat_models
     g = dict(np.load(os.path.join(GOLD, "citeseer_gat_edges.npz")))
     n = int(g["n"])
@@ -97,71 +164,103 @@ def c3_citeseer_gat(dev, heads, nhid):
     zoo = gat_models if heads == 1 else gat_heads.zoo(heads)
     torch.manual_seed(0)
     m = zoo.ODEGCN3(nfeat=3703, nhid=nhid, nclass=6, dropout=0.5, method="rk4", step_size=1 / 16).to(dev)
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     ms, (nf, nb) = _time_steps(_trainer(m, lambda: m(x, src, tgt, Mtgt), idx, y))
-    return {"workload": "Citeseer 3327 nodes / %d edges, GAT ODEGCN3 %d head(s), hidden %d, rk4 64 f-evals" % (e, heads, nhid),
-            "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
-
-
-def c4_qc(dev, model_name, captured=False):
-    from graph_odenet_amd import qc_models
-    from graph_odenet_amd.synth import qm9_like_batch
-    torch.manual_seed(0)
-    net = getattr(qc_models, model_name)(node_features=13, edge_features=5, target_features=12, hidden_features=73,
-                                         num_layers=3).to(dev)
-    batches = []
-    for b in range(16):
-        x, ef, Esrc, Etgt, batch = qm9_like_batch(20, seed=b, device=dev)
-        batches.append((x, ef, Esrc, Etgt, batch, torch.randn(20, 12, generator=torch.Generator().manual_seed(b)).to(dev)))
-    from graph_odenet_amd.optim import Adam
-    opt = Adam(net.parameters(), lr=1e-3)
-    it = [0]
-
-    def step():
-        x, ef, Esrc, Etgt, batch, tgt = batches[it[0] % len(batches)]
-        it[0] += 1
-        opt.zero_grad()
-        F.mse_loss(net(x, ef, Esrc, Etgt, batch), tgt).backward()
-        opt.step()
-    ms, _ = _time_steps(step, warm=len(batches), n=2 * len(batches))     # first pass: every batch shape seen once
-    res = {"workload": "%s h=73 T=3, 20 QM9-like molecules per step, 16 distinct batches cycled (each shape seen once before "
-                       "timing; tools/qc_bench.py times never-repeating batches)" % model_name,
-           "ms_per_step": round(ms, 3), "graphs_per_s": round(20e3 / ms, 1)}
-    if not captured:
-        return res
-    # the same batches padded to shape buckets, one HIP-graph replay per step (qc_step.CapturedQCStep); only when this
-    # process honours replayed memset nodes (graph_odenet_amd/hipgraph.py).  Stand-alone runs only: bench.py keeps
-    # graph captures of arbitrary autograd away from the process that has to print the contract line.
-    try:
-        from graph_odenet_amd import hipgraph
-        from graph_odenet_amd.qc_batch import pad_batch
-        from graph_odenet_amd.qc_step import CapturedQCStep
-        if hipgraph.memset_nodes_ok(dev):
-            padded = [pad_batch(*b[:5])[:5] + (b[5],) for b in batches]
-            opt2 = Adam(net.parameters(), lr=1e-3)
-            cstep = CapturedQCStep(net, opt2, F.mse_loss)
-            jt = [0]
-
-            def step2():
-                cstep(*padded[jt[0] % len(padded)])
-                jt[0] += 1
-            ms2, _ = _time_steps(step2, warm=4 * len(padded), n=2 * len(padded))
-            res["ms_per_step_captured"] = round(ms2, 3)
-            res["shape_buckets"] = len(cstep.buckets)
-        else:
-            res["ms_per_step_captured"] = None
-    except Exception as e:
-        res["ms_per_step_captured"] = "error: %s: %s" % (type(e).__name__, e)
+    res = {"workload": "Citeseer 3327 nodes / %d edges, GAT ODEGCN3 %d head(s), hidden %d, rk4 64 f-evals" % (e, heads, nhid),
+           "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
+    if cpu:
+        from oracle import models_ref as M
+        p = M.leaves(sd0)
+        xc, sc, tc, mc, yc, ic = x.cpu(), src.cpu(), tgt.cpu(), Mtgt.cpu(), y.cpu(), idx.cpu()
+        nh = heads if heads > 1 else None
+        t = _cpu_full_step(lambda: F.nll_loss(M.gat_odegcn3(p, xc, sc, tc, mc, nh, 0.5, True, "rk4", 1 / 16)[0][ic], yc[ic]),
+                           p, 0.01, 5e-4)
+        res.update(_cpu_fields(t, "whole training steps of the oracle's GAT ODEGCN3 (%d reference layer(s) per graph layer, rk4, 64 + 64 "
+                                  "evaluations, Adam): 1 warm-up, median of 3" % heads))
     return res
 
 
-def all_configs(dev, qc_captured=False):
+def c4_qc(dev, model_name, cpu=True, n_timed=60):
+    """C4 as the reference trains it (QC/util.py:146-211): a NEW batch every step - every step meets node / edge counts
+    it may never have seen, and the per-batch graph conversion is part of the step.  Three modes of the same loop body
+    (graph_odenet_amd/qc_train.py): eager (dense Etgt, as the reference's collate hands it over), prepared (index
+    vectors from the loader) and captured (one HIP-graph replay per shape bucket).  `ms_per_step` is the DEFAULT mode of
+    qc_train.TrainStep on dense-Etgt batches (captured when this process may replay memset nodes, else eager)."""
+    from graph_odenet_amd import hipgraph, qc_models
+    from graph_odenet_amd.optim import Adam
+    from graph_odenet_amd.qc_train import TrainStep
+    from graph_odenet_amd.synth import qm9_like_batch
+    n_warm = {"eager": 8, "prepared": 8, "captured": 150}         # captured: every shape bucket is met (and captured) first
+
+    def batches(lo, n):
+        out = []
+        for b in range(lo, lo + n):
+            x, ef, Esrc, Etgt, batch = qm9_like_batch(20, seed=b, device=dev)
+            out.append((x, ef, Esrc, Etgt, batch, torch.randn(20, 12, generator=torch.Generator().manual_seed(b)).to(dev)))
+        return out
+
+    def run(mode, seed0):
+        torch.manual_seed(0)
+        net = getattr(qc_models, model_name)(node_features=13, edge_features=5, target_features=12, hidden_features=73,
+                                             num_layers=3).to(dev)
+        step = TrainStep(net, Adam(net.parameters(), lr=1e-3), F.mse_loss, mode=mode)
+        bs = batches(seed0, n_warm[mode] + n_timed)               # resident before the timed region
+        if mode == "prepared":
+            bs = [(b[0], b[1], b[2], b[3].argmax(0), b[4], b[5]) for b in bs]      # what a loader has before the dense matrix
+        for b in bs[:n_warm[mode]]:
+            step(*b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in bs[n_warm[mode]:]:
+            step(*b)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n_timed
+        extra = {}
+        if step._captured is not None:
+            extra = {"shape_buckets_seen": len(step._captured.buckets),
+                     "shape_buckets_captured": sum(1 for b in step._captured.buckets.values() if b.graph is not None)}
+        return ms, step.mode, extra, net
+
+    res = {"workload": "%s h=73 T=3, 20 QM9-like molecules per step, a NEW batch every step (never-repeating shapes; the "
+                       "per-batch graph conversion is timed), %d timed steps per mode" % (model_name, n_timed)}
+    modes = ["eager", "prepared"] + (["captured"] if hipgraph.memset_nodes_ok(dev) else [])
+    net = None
+    for k, mode in enumerate(modes):
+        try:
+            ms, ran, extra, net = run(mode, 1000 * (k + 1))
+            res["ms_per_step_" + mode] = round(ms, 3)
+            res.update(extra)
+        except Exception as e:
+            res["ms_per_step_" + mode] = "error: %s: %s" % (type(e).__name__, e)
+    default = "captured" if "captured" in modes else "eager"
+    res["default_mode"] = default
+    v = res.get("ms_per_step_" + default)
+    if not isinstance(v, float):
+        default, v = "eager", res.get("ms_per_step_eager")
+        res["default_mode"] = "eager (captured failed)"
+    res["ms_per_step"] = v
+    if isinstance(v, float):
+        res["graphs_per_s"] = round(20e3 / v, 1)
+    if cpu and net is not None:
+        from oracle import models_ref as M
+        p = M.leaves(net.state_dict())
+        x, ef, Esrc, Etgt, batch, tgt = (t.cpu() for t in batches(7, 1)[0])
+        fn = M.QC_MODELS[model_name]
+        kw = dict(training=True) if model_name == "EdgeGCN_K_Sum" else {}
+        t = _cpu_full_step(lambda: F.mse_loss(fn(p, x, ef, Esrc, Etgt, batch, 20, **kw), tgt), p, 1e-3, 0.0)
+        res.update(_cpu_fields(t, "whole training steps of the oracle's %s on ONE batch of 20 molecules (dense Etgt, bmm messages, "
+                                  "torch Adam): 1 warm-up, median of 3" % model_name))
+    return res
+
+
+def all_configs(dev, cpu=True):
     out = {}
-    for key, fn in (("C1_cora_gcn_ode_rk4", lambda: c1_cora(dev)),
-                    ("C2_pubmed_dense_paper_ode_dopri5", lambda: c2_pubmed(dev)),
-                    ("C3_citeseer_gat_8head_ode_rk4", lambda: c3_citeseer_gat(dev, 8, 64)),
-                    ("C3_citeseer_gat_1head_ode_rk4", lambda: c3_citeseer_gat(dev, 1, 16)),
-                    ("C4_qc_edge_gcn_sum", lambda: c4_qc(dev, "EdgeGCN_K_Sum", qc_captured)),
-                    ("C4_qc_mpnn_enn_set2set", lambda: c4_qc(dev, "MPNN_ENN_K_Set2Set", qc_captured))):
+    for key, fn in (("C1_cora_gcn_ode_rk4", lambda: c1_cora(dev, cpu)),
+                    ("C2_pubmed_dense_paper_ode_dopri5", lambda: c2_pubmed(dev, cpu)),
+                    ("C3_citeseer_gat_8head_ode_rk4", lambda: c3_citeseer_gat(dev, 8, 64, cpu)),
+                    ("C3_citeseer_gat_1head_ode_rk4", lambda: c3_citeseer_gat(dev, 1, 16, cpu)),
+                    ("C4_qc_edge_gcn_sum", lambda: c4_qc(dev, "EdgeGCN_K_Sum", cpu)),
+                    ("C4_qc_mpnn_enn_set2set", lambda: c4_qc(dev, "MPNN_ENN_K_Set2Set", cpu))):
         try:
             out[key] = fn()
         except Exception as e:                     # a secondary number must never take the contract line down
@@ -171,4 +270,7 @@ def all_configs(dev, qc_captured=False):
 
 
 if __name__ == "__main__":
-    print(json.dumps(all_configs(torch.device("cuda:0"), qc_captured=True), indent=1))
+    # stand-alone, and as bench.py's child process (a fresh process: HIP-graph captures of arbitrary autograd stay away
+    # from the process that has to print the contract line): one JSON object on the LAST line of stdout
+    cpu_leg = "--no-cpu" not in sys.argv
+    print(json.dumps(all_configs(torch.device("cuda:0"), cpu=cpu_leg), indent=None if "--one-line" in sys.argv else 1))

@@ -7,9 +7,13 @@ gradients), batch of 20 synthetic QM9-like molecules per GPU (RDKit / QM9 files 
 Adam(lr 1e-3) as in QC/train_egcn.py:122.
 
   python tools/qc_bench.py                                       one GPU (+ the oracle's message step on the host)
+  python tools/qc_bench.py --gpus N                              starts N ranks itself (graph_odenet_amd/launch.py), or
   python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/qc_bench.py --gpus N
-      one rank per GPU, every rank its own batches (seed = rank), one flat RCCL all-reduce of the
-      gradients per step (parallel.GradBucket); weak scaling, value = N*20*K / max-over-ranks time.
+      one rank per GPU, every rank its own batches (seed = rank), the bucketed RCCL all-reduce of the 57 MB of
+      gradients per step (parallel.GradBucket); weak scaling, value = N*20*K / max-over-ranks time.  With fewer GPUs
+      than ranks the ranks share the GPUs and exchange over gloo (rehearsal).
+
+bench.py --gpus N calls run() for its `secondary.qc_data_parallel` entry.
 
 Prints one JSON line on rank 0.  Development / secondary measurement; the contract line is bench.py's.
 """
@@ -67,6 +71,73 @@ def cpu_oracle_step(model_name, batch_size, reps):
     return sorted(ts[1:])[len(ts[1:]) // 2]
 
 
+def run(dev, rank, world, backend, model="MPNN_ENN_K_Set2Set", steps=50, warmup=5, batch_size=20, captured=False,
+        prepared=False, bucket_pad=False):
+    """The data-parallel QC measurement; every rank calls it (collectives inside) and gets the same dict back."""
+    import torch.distributed as dist
+    from graph_odenet_amd.optim import Adam
+    from graph_odenet_amd.parallel import GradBucket, broadcast_parameters
+
+    # one distinct batch per step, as in training: the per-batch graph conversion is inside the timed region
+    bucket_pad = bucket_pad or captured
+    net, batches = build(dev, model, rank, steps + warmup, batch_size, bucket_pad, prepared)
+    broadcast_parameters(net, 0)
+    opt = Adam(net.parameters(), lr=1e-3)
+    bucket = GradBucket(net, overlap=not captured)
+    cstep = None
+    if captured:
+        from graph_odenet_amd.qc_step import CapturedQCStep
+        cstep = CapturedQCStep(net, opt, F.mse_loss, exchange=(lambda: bucket.allreduce_mean(assume_all=True)) if world > 1 else None)
+
+    def step(i):
+        x, ef, Esrc, Etgt, batch, tgt = batches[i]
+        if cstep is not None:
+            return cstep(x, ef, Esrc, Etgt, batch, tgt)            # index-vector batches are converted inside the graph
+        if prepared:
+            from graph_odenet_amd.qc_batch import prepare
+            n_graphs = tgt.shape[0] + (1 if bucket_pad else 0)
+            Etgt, batch = prepare(Esrc, Etgt, batch, x.shape[0], n_graphs)          # timed: part of every step
+        opt.zero_grad(set_to_none=False)
+        loss = F.mse_loss(net(x, ef, Esrc, Etgt, batch)[:tgt.shape[0]], tgt)
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = el.item()
+    res = {"metric": "QC edge-MPNN training throughput (graphs/s), batch %d per GPU" % batch_size,
+           "value": round(world * batch_size * steps / el, 1), "unit": "graphs/s",
+           "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * el / steps, 3), "scaling": "weak", "dtype": "f32",
+           "data": "synthetic", "loss": round(float(loss.detach()), 5), "backend": backend,
+           "config": {"workload": "%s h=73 T=3, %d QM9-like molecules per rank, a new batch every step (graph conversion timed)%s%s%s"
+                                  % (model, batch_size, ", padded to shape buckets" if bucket_pad else "",
+                                     ", edges handed over as index vectors" if prepared else "",
+                                     ", one HIP-graph replay per step and bucket" if captured else ""),
+                      "params": sum(p.numel() for p in net.parameters()),
+                      "gradient_bytes_allreduced_per_step": 4 * bucket.flat.numel() if world > 1 else 0,
+                      "exchange_buckets": len(bucket.buckets)}}
+    if cstep is not None:
+        res["config"]["shape_buckets_captured"] = sum(1 for b in cstep.buckets.values() if b.graph is not None)
+        res["config"]["shape_buckets_seen"] = len(cstep.buckets)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,77 +152,16 @@ def main():
                     help="hand the edges over as index vectors (qc_batch.prepare: no dense Etgt, no host synchronisation)")
     ap.add_argument("--bucket", action="store_true",
                     help="pad every batch to its shape bucket (multiples of 64 atoms / 128 edges, one dummy graph)")
+    ap.add_argument("--backend", choices=["auto", "nccl", "gloo"], default="auto")
     args = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run, one rank per GPU")
+    from graph_odenet_amd import launch
+    if launch.needs_self_launch(args.gpus):
+        sys.exit(launch.self_launch(__file__, sys.argv[1:], args.gpus))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    from graph_odenet_amd.parallel import GradBucket, broadcast_parameters
-
-    # one distinct batch per step, as in training: the per-batch graph conversion is inside the timed region
-    args.bucket = args.bucket or args.captured
-    net, batches = build(dev, args.model, rank, args.steps + args.warmup, args.batch_size, args.bucket, args.prepared)
-    broadcast_parameters(net, 0)
-    from graph_odenet_amd.optim import Adam
-    opt = Adam(net.parameters(), lr=1e-3)
-    bucket = GradBucket(net, overlap=not args.captured)
-    cstep = None
-    if args.captured:
-        from graph_odenet_amd.qc_step import CapturedQCStep
-        cstep = CapturedQCStep(net, opt, F.mse_loss, exchange=(lambda: bucket.allreduce_mean(assume_all=True)) if world > 1 else None)
-
-    def step(i):
-        x, ef, Esrc, Etgt, batch, tgt = batches[i]
-        if cstep is not None:
-            return cstep(x, ef, Esrc, Etgt, batch, tgt)            # index-vector batches are converted inside the graph
-        if args.prepared:
-            from graph_odenet_amd.qc_batch import prepare
-            n_graphs = tgt.shape[0] + (1 if args.bucket else 0)
-            Etgt, batch = prepare(Esrc, Etgt, batch, x.shape[0], n_graphs)          # timed: part of every step
-        opt.zero_grad(set_to_none=False)
-        loss = F.mse_loss(net(x, ef, Esrc, Etgt, batch)[:tgt.shape[0]], tgt)
-        loss.backward()
-        bucket.allreduce_mean()
-        opt.step()
-        return loss
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    barrier()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = el.item()
+    rank, _, world, dev, backend = launch.init_ranks(args.backend)
+    res = run(dev, rank, world, backend, args.model, args.steps, args.warmup, args.batch_size, args.captured, args.prepared,
+              args.bucket)
     if rank == 0:
-        res = {"metric": "QC edge-MPNN training throughput (graphs/s), batch %d per GPU" % args.batch_size,
-               "value": round(world * args.batch_size * args.steps / el, 1), "unit": "graphs/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * el / args.steps, 3), "scaling": "weak", "dtype": "f32",
-               "data": "synthetic", "loss": round(float(loss.detach()), 5),
-               "config": {"workload": "%s h=73 T=3, %d QM9-like molecules per rank, a new batch every step (graph conversion timed)%s%s"
-                                      % (args.model, args.batch_size, ", padded to shape buckets" if args.bucket else "",
-                                         ", edges handed over as index vectors" if args.prepared else ""),
-                          "params": sum(p.numel() for p in net.parameters()),
-                          "gradient_bytes_allreduced_per_step": 4 * bucket.flat.numel() if world > 1 else 0}}
-        if cstep is not None:
-            res["config"]["shape_buckets_captured"] = sum(1 for b in cstep.buckets.values() if b.graph is not None)
-            res["config"]["shape_buckets_seen"] = len(cstep.buckets)
         if world == 1 and not args.no_cpu_baseline:
             t = cpu_oracle_step(args.model, args.batch_size, 3)
             res["cpu_baseline"] = {"value": round(args.batch_size / t, 1), "unit": "graphs/s",
