@@ -129,7 +129,8 @@ SIGNATURES = {
     "gode_gemm_f32": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p, c_i64, c_p]),
     "gode_cut_pad": (c_i64, [c_i64]),
     "gode_cut_bf16x3_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p]),
-    "gode_pgemm_bf16x3": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_i64, c_i, c_p]),
+    "gode_pgemm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "gode_pgemm_bf16x3": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i, c_p, c_i64, c_i, c_p, c_p]),
     "gode_adam_chunk": (c_i64, []),
     "gode_adam_tick_f32": (c_i, [c_p, c_f, c_f, c_p]),
     "gode_adam_f32": (c_i, [ctypes.POINTER(AdamArgs), ctypes.c_int32, c_p, c_i64, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),
@@ -189,6 +190,9 @@ SIGNATURES = {
     "gode_edge_matvec_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_segment_attention_f32_fwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_segment_attention_f32_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "gode_segment_attention_f32_fwd2": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
+    "gode_segment_attention_f32_bwd2": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i64,
+                                              c_p, c_i, c_p, c_p]),
     "gode_gcn_ode_theta_len": (c_i64, [c_i64]),
     "gode_gcn_ode_rk4_forward": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, ctypes.POINTER(c_p), ctypes.POINTER(Rk4Workspace),
                                        c_f, c_f, ctypes.c_int32, c_p]),
@@ -213,6 +217,8 @@ SIGNATURES = {
     "gode_lstm_cell_supported": (c_i, [c_i64, c_i64, c_i64]),
     "gode_lstm_cell_f32_fwd": (c_i, [c_p] * 7 + [c_i64] * 3 + [c_p] * 4),
     "gode_lstm_cell_f32_bwd": (c_i, [c_p] * 9 + [c_i64] * 3 + [c_p] * 8),
+    "gode_lstm_cell_f32_fwd2": (c_i, [c_p] * 7 + [c_i64] * 3 + [c_p] * 4 + [c_i64, c_p]),
+    "gode_lstm_cell_f32_bwd2": (c_i, [c_p] * 9 + [c_i64] * 3 + [c_p] * 7 + [c_i, c_p]),
     "gode_gru_wgrad_parts": (c_i64, [c_i64]),
     "gode_gru_cell_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_gru_cell_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,

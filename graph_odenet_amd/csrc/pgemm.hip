@@ -154,7 +154,7 @@ template <bool A_KC, bool B_KC, int PRODUCTS>
 __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__ Ap, int64_t lda, int64_t pa,
                                                        const short* __restrict__ Bp, int64_t ldb, int64_t pb,
                                                        float* __restrict__ C, int64_t ldc, int M, int N, int Kp,
-                                                       int tiles_m, int tiles_n,
+                                                       int tiles_m, int tiles_n, int ksplit, float* __restrict__ ws,
                                                        const float* __restrict__ bias, int relu,
                                                        const float* __restrict__ mask, int64_t ldmask)
 {
@@ -164,9 +164,10 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
     // tile of this block: ids are dealt to the XCDs round-robin by the hardware (b and b + 8 share an L2); renumber so
     // that one XCD works on CONSECUTIVE tiles, m fastest: its blocks share the B panel of a column tile and re-use the
     // A panels of all row tiles (speed only - any placement is correct)
-    const int nwg = tiles_m * tiles_n, orig = blockIdx.x;
+    const int ntile = tiles_m * tiles_n, nwg = ntile * ksplit, orig = blockIdx.x;
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int tid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int ks = wid / ntile, tid = wid - ks * ntile;           // k slice (slowest), tile
     const int tn = tid / tiles_m, tm = tid - tn * tiles_m;
     const int m0 = tm * TM, n0 = tn * TN;
     const int wm = (wave / WN) * (TM / WM), wn = (wave % WN) * (TN / WN);
@@ -201,8 +202,13 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
     for (int j = 0; j < NJ; ++j) Operand<B_KC>::read_offsets(wn + 16 * j, lane, bo[j][0], bo[j][1]);
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
 
-    const int nk = Kp / BK;
-    issue(0, 0);
+    // k-steps of this block: slice ks of ksplit (ksplit > 1: few tiles - the blocks of a tile split the contraction and
+    // write raw partial sums to the workspace, finished by pgemm_finish_kernel)
+    const int nk_all = Kp / BK;
+    const int kt_lo = (int)((int64_t)nk_all * ks / ksplit), nk = (int)((int64_t)nk_all * (ks + 1) / ksplit) - kt_lo;
+    asrc += kt_lo * astep;
+    bsrc += kt_lo * bstep;
+    if (nk > 0) issue(0, 0);
     if (nk > 1) issue(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's share of step kt has landed (the six DMAs of step kt + 1 may stay in flight) ...
@@ -214,54 +220,61 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
         if (kt + 2 < nk) issue((kt + 2) % STAGES, kt + 2);
         const unsigned st = lds_base + (kt % STAGES) * STAGE_B;
         bf16x8_t a[MI][3], b[NJ][3];
-        // reads of the first half (all of B, rows 0-31 of A), then - before the first MFMA - the reads of the second half
+        // operand reads run one 16-row slice of A ahead of the MFMAs: all of B and slice 0, then slice i + 1 is requested
+        // before the 16 MFMAs of slice i are issued
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int p = 0; p < 3; ++p) b[j][p] = Operand<B_KC>::frag(st + OPER_B + p * PIECE_B, bo[j][0], bo[j][1]);
 #pragma unroll
-        for (int i = 0; i < MI / 2; ++i)
+        for (int p = 0; p < 3; ++p) a[0][p] = Operand<A_KC>::frag(st + p * PIECE_B, ao[0][0], ao[0][1]);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[i][p] = Operand<A_KC>::frag(st + p * PIECE_B, ao[i][0], ao[i][1]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < MI; ++i) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < MI) {
 #pragma unroll
-        for (int i = MI / 2; i < MI; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) a[i][p] = Operand<A_KC>::frag(st + p * PIECE_B, ao[i][0], ao[i][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half == 1) {
-                __builtin_amdgcn_sched_barrier(0);            // the MFMAs of the first half stay in front of this wait
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int p = 0; p < 3; ++p) a[i + 1][p] = Operand<A_KC>::frag(st + p * PIECE_B, ao[i + 1][0], ao[i + 1][1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = half * (MI / 2); i < (half + 1) * (MI / 2); ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    f32x4 s = small[i][j];
-                    if (PRODUCTS == 8) {
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][1], s, 0, 0, 0);      // lo*mid
-                        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][2], s, 0, 0, 0);      // mid*lo
-                    }
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], s, 0, 0, 0);          // lo*hi
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], s, 0, 0, 0);          // hi*lo
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], s, 0, 0, 0);          // mid*mid
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], s, 0, 0, 0);          // mid*hi
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], s, 0, 0, 0);          // hi*mid
-                    small[i][j] = s;
-                    big[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], big[i][j], 0, 0, 0);   // hi*hi
+            for (int j = 0; j < NJ; ++j) {
+                f32x4 sm = small[i][j];
+                if (PRODUCTS == 8) {
+                    sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][1], sm, 0, 0, 0);      // lo*mid
+                    sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][2], sm, 0, 0, 0);      // mid*lo
                 }
+                sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[j][0], sm, 0, 0, 0);          // lo*hi
+                sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][2], sm, 0, 0, 0);          // hi*lo
+                sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][1], sm, 0, 0, 0);          // mid*mid
+                sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[j][0], sm, 0, 0, 0);          // mid*hi
+                sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][1], sm, 0, 0, 0);          // hi*mid
+                small[i][j] = sm;
+                big[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[j][0], big[i][j], 0, 0, 0);   // hi*hi
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
     }
 
     // D layout of v_mfma_f32_16x16x32_bf16: col = lane & 15, row = 4 (lane >> 4) + e.  Epilogue operands are loaded from
     // clamped coordinates (no load under a divergent branch); only the store is guarded.
+    if (ksplit > 1) {
+        float* w = ws + (int64_t)ks * M * N;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn + 16 * j + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int rb = m0 + wm + 16 * i + 4 * (lane >> 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rb + e < M && col < N) w[(int64_t)(rb + e) * N + col] = big[i][j][e] + small[i][j][e];
+            }
+        }
+        return;
+    }
     const bool has_bias = bias != nullptr, has_mask = mask != nullptr;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -290,25 +303,56 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
     }
 }
 
+// C = sum over the k slices of the workspace (+ bias) (relu) (* [mask > 0]); a thread per element, rows of N contiguous
+__global__ __launch_bounds__(256) void pgemm_finish_kernel(const float* __restrict__ ws, int ksplit, float* __restrict__ C,
+                                                           int64_t ldc, int M, int N, const float* __restrict__ bias, int relu,
+                                                           const float* __restrict__ mask, int64_t ldmask)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)M * N;
+    if (idx >= total) return;
+    const int row = (int)(idx / N), col = (int)(idx - (int64_t)row * N);
+    float v = 0.f;
+    for (int s = 0; s < ksplit; ++s) v += ws[(int64_t)s * total + idx];
+    if (bias) v += bias[col];
+    if (relu) v = fmaxf(v, 0.f);
+    if (mask) v = mask[(int64_t)row * ldmask + col] > 0.f ? v : 0.f;
+    C[(int64_t)row * ldc + col] = v;
+}
+
+// k slices per tile: 1 when the tiles alone fill the chip; else as many as keep every slice >= 16 k-steps deep
+int choose_ksplit(int64_t tiles, int64_t nk) {
+    int s = 1;
+    while (tiles * (s + 1) <= 256 && nk / (s + 1) >= 16 && s < 8) ++s;
+    return s;
+}
+
 template <bool A_KC, bool B_KC>
 int launch(int products, const short* Ap, int64_t lda, int64_t pa, const short* Bp, int64_t ldb, int64_t pb, float* C,
-           int64_t ldc, int M, int N, int Kp, const float* bias, int relu, const float* mask, int64_t ldmask, hipStream_t s)
+           int64_t ldc, int M, int N, int Kp, const float* bias, int relu, const float* mask, int64_t ldmask, float* ws,
+           hipStream_t s)
 {
     const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const size_t lds = (size_t)STAGES * STAGE_B;
-    const dim3 grid(tiles_m * tiles_n), block(512);
+    const int ksplit = ws ? choose_ksplit((int64_t)tiles_m * tiles_n, Kp / BK) : 1;
+    const dim3 grid(tiles_m * tiles_n * ksplit), block(512);
     if (products == 6) {
         auto* k = pgemm_kernel<A_KC, B_KC, 6>;
         const int rc = gode_set_lds_once((const void*)k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, block, lds, s, Ap, lda, pa, Bp, ldb, pb, C, ldc, M, N, Kp, tiles_m, tiles_n, bias, relu, mask, ldmask);
+        hipLaunchKernelGGL(k, grid, block, lds, s, Ap, lda, pa, Bp, ldb, pb, C, ldc, M, N, Kp, tiles_m, tiles_n, ksplit, ws, bias, relu, mask, ldmask);
     } else {
         auto* k = pgemm_kernel<A_KC, B_KC, 8>;
         const int rc = gode_set_lds_once((const void*)k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, block, lds, s, Ap, lda, pa, Bp, ldb, pb, C, ldc, M, N, Kp, tiles_m, tiles_n, bias, relu, mask, ldmask);
+        hipLaunchKernelGGL(k, grid, block, lds, s, Ap, lda, pa, Bp, ldb, pb, C, ldc, M, N, Kp, tiles_m, tiles_n, ksplit, ws, bias, relu, mask, ldmask);
     }
     GODE_LAUNCH_CHECK();
+    if (ksplit > 1) {
+        const int64_t total = (int64_t)M * N;
+        hipLaunchKernelGGL(pgemm_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, ksplit, C, ldc, M, N,
+                           bias, relu, mask, ldmask);
+        GODE_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -332,9 +376,17 @@ extern "C" int gode_cut_bf16x3_f32(const float* X, int64_t ld, int64_t R, int64_
     return 0;
 }
 
+extern "C" int64_t gode_pgemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int64_t tiles = (gode_cut_pad(M) / TM) * (gode_cut_pad(N) / TN);
+    const int ks = choose_ksplit(tiles, gode_cut_pad(K) / BK);
+    return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
+}
+
 extern "C" int gode_pgemm_bf16x3(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void* A_planes,
                                  const void* B_planes, float* C, int64_t ldc, const float* bias, int relu,
-                                 const float* mask, int64_t ldmask, int products, void* stream)
+                                 const float* mask, int64_t ldmask, int products, void* workspace, void* stream)
 {
     if (M < 0 || N < 0 || K < 0) return GODE_E_SHAPE;
     if (M == 0 || N == 0) return 0;
@@ -352,9 +404,11 @@ extern "C" int gode_pgemm_bf16x3(int trans_a, int trans_b, int64_t M, int64_t N,
     const short* Ap = reinterpret_cast<const short*>(A_planes);
     const short* Bp = reinterpret_cast<const short*>(B_planes);
     hipStream_t s = (hipStream_t)stream;
+    float* ws = reinterpret_cast<float*>(workspace);          // nullable: without it the contraction is never split
+    if (ws && (((uintptr_t)ws) & 15)) return GODE_E_ALIGN;
     const bool akc = !trans_a, bkc = trans_b != 0;
-    if (akc && bkc) return launch<true, true>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, s);
-    if (akc && !bkc) return launch<true, false>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, s);
-    if (!akc && bkc) return launch<false, true>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, s);
-    return launch<false, false>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, s);
+    if (akc && bkc) return launch<true, true>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, ws, s);
+    if (akc && !bkc) return launch<true, false>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, ws, s);
+    if (!akc && bkc) return launch<false, true>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, ws, s);
+    return launch<false, false>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, ws, s);
 }

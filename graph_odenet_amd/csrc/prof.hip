@@ -63,6 +63,11 @@ extern "C" int gode_prof_kinds(void* prof, int32_t* kinds, int max_n) {
 int gode_prof_begin(hipStream_t s, int64_t d, int64_t rows, int64_t extra, int kind) {
     GodeProf* p = g_prof;
     if (!p || p->count >= p->capacity) return -1;
+    // never inside a stream capture: the record would become a graph node that refers to an event this profile owns -
+    // a replay after gode_prof_destroy() then touches a destroyed handle (hipErrorInvalidHandle on the next API call;
+    // round 4: bench.py --gpus 2 at a launch-bound size, where the solves are captured inside the timed region)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;
     const int i = p->count;
     p->d[i] = d; p->rows[i] = rows; p->extra[i] = extra; p->kind[i] = kind;
     (void)hipEventRecord(p->ev[2 * i], s);

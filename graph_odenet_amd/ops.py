@@ -495,8 +495,11 @@ def pgemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, mask=None, 
     ldc = _need_rows(out, "out")
     if tuple(out.shape) != (M, N):
         raise ValueError("pgemm: out must be %d x %d" % (M, N))
+    wb = lib.gode_pgemm_workspace_bytes(M, N, K)
+    ws = torch.empty(wb // 4, dtype=torch.float32, device=out.device) if wb else None
     check(lib.gode_pgemm_bf16x3(1 if trans_a else 0, 1 if trans_b else 0, M, N, K, ptr(A.planes), ptr(B.planes), ptr(out), ldc,
-                                ptr(bias), 1 if relu else 0, ptr(mask), ldm, int(products), stream_ptr()), "gode_pgemm_bf16x3")
+                                ptr(bias), 1 if relu else 0, ptr(mask), ldm, int(products), ptr(ws), stream_ptr()),
+          "gode_pgemm_bf16x3")
     return out
 
 
@@ -903,3 +906,61 @@ def group_norm_bwd(x, groups, eps, gamma, dy, want_affine_grads=True):
     check(lib.gode_group_norm_f32_bwd(ptr(x), n, d, groups, float(eps), ptr(gamma), ptr(dy), ptr(dx), ptr(dg), ptr(db),
                                       stream_ptr()), "gode_group_norm_f32_bwd")
     return dx, dg, db
+
+
+# ---- the whole Set2Set readout loop (QC/set2set.py:59-75) -------------------------------------------------------
+def set2set_fwd(segptr, perm, x, w_ih, w_hh, b_ih, b_hh, steps, n_graphs):
+    """q_star after `steps` processing steps, plus what the backward pass reads.  Two launches per step: the LSTM cell
+    writes q_t into the left half of q_star[t + 1], the segment attention writes r_t into its right half."""
+    lib = _lib.load()
+    for t_, nm in ((x, "x"), (w_ih, "weight_ih"), (w_hh, "weight_hh"), (b_ih, "bias_ih"), (b_hh, "bias_hh")):
+        _need(t_, nm)
+    N, H = x.shape
+    B = int(n_graphs)
+    f = dict(dtype=torch.float32, device=x.device)
+    qs = torch.zeros(steps + 1, B, 2 * H, **f)          # q_star[0] = 0; q_star[t + 1] = [q_t | r_t]
+    hs = torch.zeros(steps + 1, B, H, **f)              # h_0 = 0; h_{t+1} = q_t (contiguous copy: the next cell's h input)
+    cs = torch.zeros(steps + 1, B, H, **f)
+    gates = torch.empty(steps, B, 4 * H, **f)
+    att = torch.empty(steps, N, **f)
+    st = stream_ptr()
+    for t in range(steps):
+        check(lib.gode_lstm_cell_f32_fwd2(ptr(qs[t]), ptr(hs[t]), ptr(cs[t]), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), B,
+                                          2 * H, H, ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(gates[t]), ptr(qs[t + 1]), 2 * H, st),
+              "gode_lstm_cell_f32_fwd2")
+        check(lib.gode_segment_attention_f32_fwd2(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(hs[t + 1]), B, H,
+                                                  ptr(att[t]), ctypes.c_void_p(qs[t + 1].data_ptr() + 4 * H), 2 * H, st),
+              "gode_segment_attention_f32_fwd2")
+    return qs, hs, cs, gates, att
+
+
+def set2set_bwd(segptr, perm, x, w_ih, w_hh, has_bias, saved, dq_star):
+    """Cotangents of (x, w_ih, w_hh, b_ih, b_hh) from dq_star (B x 2H).  Two launches per step; the weight gradients of
+    the steps collect in one buffer (gode_lstm_cell_f32_bwd2 with accumulate), the node cotangent in another."""
+    lib = _lib.load()
+    qs, hs, cs, gates, att = saved
+    steps, B, H = gates.shape[0], qs.shape[1], hs.shape[2]
+    N = x.shape[0]
+    f = dict(dtype=torch.float32, device=x.device)
+    dx = torch.empty(N, H, **f)
+    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+    db_ih = torch.empty(4 * H, **f) if has_bias else None
+    db_hh = torch.empty(4 * H, **f) if has_bias else None
+    dqs = dq_star.contiguous()                           # cotangent of q_star[t + 1], B x 2H
+    dh_next = dc_next = None                             # the next cell's cotangents of (h, c)
+    dq = torch.empty(B, H, **f)
+    st = stream_ptr()
+    for t in reversed(range(steps)):
+        # r_t = attention(x, q_t): dr = right half of dqs; dq_t = attention part + left half of dqs + the next cell's dh
+        check(lib.gode_segment_attention_f32_bwd2(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(hs[t + 1]), ptr(att[t]),
+                                                  ctypes.c_void_p(dqs.data_ptr() + 4 * H), 2 * H, ptr(dqs), 2 * H,
+                                                  ptr(dh_next), H, B, H, ptr(dx), 0 if t == steps - 1 else 1, ptr(dq), st),
+              "gode_segment_attention_f32_bwd2")
+        dqs_new, dh_new, dc_new = torch.empty(B, 2 * H, **f), torch.empty(B, H, **f), torch.empty(B, H, **f)
+        check(lib.gode_lstm_cell_f32_bwd2(ptr(qs[t]), ptr(hs[t]), ptr(cs[t]), ptr(w_ih), ptr(w_hh), ptr(gates[t]), ptr(cs[t + 1]),
+                                          ptr(dq), ptr(dc_next), B, 2 * H, H, ptr(dqs_new), ptr(dh_new), ptr(dc_new),
+                                          ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh), 0 if t == steps - 1 else 1, st),
+              "gode_lstm_cell_f32_bwd2")
+        dqs, dh_next, dc_next = dqs_new, dh_new, dc_new
+    return dx, dw_ih, dw_hh, db_ih, db_hh
+

@@ -135,7 +135,9 @@ class GradBucket:
             if _alone() or self._seen[i]:
                 return
             self._seen[i] = True
-            if not self.overlap or _capturing(_param):
+            if not self.overlap or _capturing(_param) or (_param.is_cuda and dist.get_backend() == "gloo"):
+                # gloo with GPU tensors is the one-box rehearsal (ranks sharing a GPU, exchange staged through the host):
+                # its blocking host round trip stays on the main thread (_finish), not on autograd's worker thread
                 return
             self._attach(i)
             b = self._bucket_of[i]

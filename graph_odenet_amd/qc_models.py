@@ -206,6 +206,32 @@ class _LstmCellFn(torch.autograd.Function):
         return dx, dh, (dc if ctx.needs_input_grad[2] else None), dw_ih, dw_hh, db_ih, db_hh
 
 
+SET2SET_ONE_NODE = True      # False: the readout as a chain of per-step autograd nodes (kept for the A/B test)
+
+
+class _Set2SetFn(torch.autograd.Function):
+    """The whole readout loop of QC/set2set.py:59-75 as ONE autograd node: two launches per processing step in each
+    direction (ops.set2set_fwd / set2set_bwd).  As a chain of per-step nodes autograd summed the LSTM's weight gradients
+    with ~50 elementwise launches per training step and formed q_star with a `cat` per step; here the cell writes q_t into
+    q_star itself and the weight gradients of the 12 steps collect in one buffer inside the cell's backward kernel."""
+
+    @staticmethod
+    def forward(ctx, seg, x, w_ih, w_hh, b_ih, b_hh, steps):
+        x = x.contiguous()
+        w_ih, w_hh = w_ih.contiguous(), w_hh.contiguous()
+        saved = ops.set2set_fwd(seg.segptr, seg.perm, x, w_ih, w_hh, b_ih, b_hh, steps, seg.nb)
+        ctx.seg, ctx.has_bias = seg, b_ih is not None
+        ctx.save_for_backward(x, w_ih, w_hh, *saved)
+        return saved[0][steps]
+
+    @staticmethod
+    def backward(ctx, dq_star):
+        x, w_ih, w_hh = ctx.saved_tensors[:3]
+        dx, dw_ih, dw_hh, db_ih, db_hh = ops.set2set_bwd(ctx.seg.segptr, ctx.seg.perm, x, w_ih, w_hh, ctx.has_bias,
+                                                         ctx.saved_tensors[3:], dq_star)
+        return None, dx, dw_ih, dw_hh, db_ih, db_hh, None
+
+
 class Set2Set(nn.Module):
     """Set2Set pooling (Vinyals et al. 2015) with the reference's parameters (`lstm`).  The per-graph softmax loop of
     the reference is one kernel per processing step (csrc/segment.hip); the single-layer LSTM step runs as the fused
@@ -232,6 +258,12 @@ class Set2Set(nn.Module):
     def forward(self, x, batch):
         seg = _segments(batch)
         nb = seg.nb
+        l = self.lstm
+        if SET2SET_ONE_NODE and self.num_layers == 1 and x.is_cuda and x.dtype == torch.float32 and self.processing_steps > 0 and \
+                (getattr(l, "bias_ih_l0", None) is None) == (getattr(l, "bias_hh_l0", None) is None) and \
+                ops.lstm_cell_supported(nb, self.out_channels, self.in_channels) and nb > 0:
+            return _Set2SetFn.apply(seg, x, l.weight_ih_l0, l.weight_hh_l0, getattr(l, "bias_ih_l0", None),
+                                    getattr(l, "bias_hh_l0", None), self.processing_steps)
         h = (x.new_zeros(self.num_layers, nb, self.in_channels), x.new_zeros(self.num_layers, nb, self.in_channels))
         q_star = x.new_zeros(nb, self.out_channels)
         for _ in range(self.processing_steps):

@@ -10,17 +10,19 @@ the default (BASELINE.json configs[3]).
 the per-edge target index vector (int64[E]); `b` the sorted graph index of every node (collate order).
 
 Modes:
-  "eager"     the reference's loop body as it stands: per-batch conversion of the dense matrix (one host synchronisation
-              for its validity check), ~250 launches from Python;
-  "prepared"  the edges go in as index vectors (qc_batch.prepare): no dense matrix, no host synchronisation;
+  "eager"     the reference's loop body as it stands: per-batch conversion of the dense matrix (a column arg-max, a
+              validity check = one host synchronisation), ~250-450 launches from Python;
+  "prepared"  the edges go in as index vectors (qc_batch.prepare): handed over by the loader, or taken off the dense
+              matrix by a column arg-max on the device - no validity check, no host synchronisation, the GPU queue
+              stays full;
   "captured"  the batch is padded to its shape bucket (qc_batch.pad_batch: multiples of 64 atoms / 128 edges, one dummy
               graph) and the whole step - conversion, forward, loss, backward, Adam - is ONE HIP-graph replay per
-              bucket (qc_step.CapturedQCStep); a dense `e_tgt` is reduced to index vectors first (a column arg-max, no
-              synchronisation), so that only index vectors are copied into the bucket's static buffers;
-  "auto"      "captured" when this process may rely on replayed memset nodes (hipgraph.memset_nodes_ok: start the
-              process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 or call hipgraph.prefer_safe_graphs() first) and the optimiser
-              is capturable (graph_odenet_amd.optim.Adam is), else "prepared" for index-vector batches and "eager" for
-              dense ones.
+              bucket (qc_step.CapturedQCStep); needs hipgraph.memset_nodes_ok();
+  "auto"      = "prepared".  Measured on never-repeating batches of 20 molecules (tools/config_bench.py, round 4):
+              EdgeGCN_K_Sum eager 2.6 ms / prepared 1.9 ms / captured 2.8 ms per step, MPNN_ENN_K_Set2Set 3.9-4.7 / 3.2 /
+              3.7 ms.  The captured step loses on this platform: replayed memset nodes are only reliable with the HIP
+              runtime's graph fast path OFF (hipgraph.py), and on that path a replay issues its ~300 kernel nodes one by
+              one from the host - no cheaper than the eager launches it replaces - while the padding adds work.
 The number of graphs of a batch is taken from `target.shape[0]` (one row per graph, as the reference's collate emits),
 never read back from the device.
 
@@ -53,11 +55,7 @@ class TrainStep:
     def _decide(self, x, by_index):
         m = self.requested
         if m == "auto":
-            capturable = all(g.get("capturable", False) for g in self.opt.param_groups) or self.exchange is not None
-            m = "captured" if (x.is_cuda and capturable and hipgraph.memset_nodes_ok(x.device)) else \
-                ("prepared" if by_index else "eager")
-        if m == "prepared" and not by_index:
-            m = "eager"
+            m = "prepared" if x.is_cuda else "eager"
         return m
 
     def __call__(self, x, edge_feat, Esrc, Etgt, batch, target):
@@ -73,6 +71,8 @@ class TrainStep:
                 self._captured = CapturedQCStep(self.model, self.opt, self.criterion, exchange=self.exchange)
             return self._captured(x, edge_feat, Esrc, Etgt, batch, target, n_graphs=n_graphs + 1)
         if self.mode == "prepared":
+            if not by_index:
+                Etgt = (Etgt != 0).to(torch.uint8).argmax(0)         # one entry per edge column (the collate's layout)
             Etgt, batch = prepare(Esrc, Etgt, batch, x.shape[0], n_graphs)
         self.opt.zero_grad(set_to_none=False)
         loss = self.criterion(self.model(x, edge_feat, Esrc, Etgt, batch), target)

@@ -242,12 +242,16 @@ int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, con
  * (6 * R_pad * C_pad bytes).  Step 2: gode_pgemm_bf16x3 forms C = op(A) op(B) (fp32, M x N, leading dimension ldc) from the
  * planes of A AS STORED (M x K if trans_a = 0, K x M if 1) and of B AS STORED (K x N if trans_b = 0, N x K if 1), i.e. a cut
  * matrix serves every product it enters in either role.  products = 8 (every piece product >= 2^-32 of a product; an fp32
- * result) or 6 (also without mid*lo, lo*mid: 2^-24 each).  Epilogue as gode_gemm_f32: + bias[col], relu, * (mask > 0). */
+ * result) or 6 (also without mid*lo, lo*mid: 2^-24 each).  Epilogue as gode_gemm_f32: + bias[col], relu, * (mask > 0).
+ * workspace: gode_pgemm_workspace_bytes(M, N, K) bytes of caller-owned scratch (16-byte aligned) or NULL - with it a
+ * product of few 128 x 128 tiles (760 x 2667: 126 tiles for 256 CUs) splits its contraction over several blocks per tile,
+ * which write raw partial sums there, added in fixed order by a finishing launch (deterministic, no atomics). */
 int64_t gode_cut_pad(int64_t n);
 int gode_cut_bf16x3_f32(const float* X, int64_t ld, int64_t R, int64_t C, void* planes, void* stream);
+int64_t gode_pgemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int gode_pgemm_bf16x3(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void* A_planes,
                       const void* B_planes, float* C, int64_t ldc, const float* bias, int relu,
-                      const float* mask, int64_t ldmask, int products, void* stream);
+                      const float* mask, int64_t ldmask, int products, void* workspace, void* stream);
 
 /* torch.optim.Adam's update (no amsgrad; L2 weight decay) of up to GODE_ADAM_MAX_TENSORS tensors in ONE launch - the
  * `optimizer.step()` of QC/train_egcn.py / GCN/train_res.py:97.  args (host; copied into the kernel arguments): device
@@ -404,6 +408,17 @@ int gode_segment_attention_f32_fwd(const int32_t* segptr, const int32_t* perm, c
 int gode_segment_attention_f32_bwd(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
                                    const float* q, const float* a, const float* dr, int64_t n_seg, int64_t h,
                                    float* dx, float* dq, void* stream);
+/* The forms the whole Set2Set loop runs on (one autograd node for the 12 processing steps of QC/set2set.py:59-75):
+ * fwd2 writes r with a leading dimension (straight into the right half of q_star = [q | r]); bwd2 reads dr with a leading
+ * dimension (the right half of the cotangent of q_star), ADDS dx into the running node cotangent (accumulate_dx != 0) and
+ * returns dq = (attention part) + add1 + add2 (nullable n_seg x h matrices with leading dimensions: the left half of the
+ * cotangent of q_star and the LSTM's cotangent of h). */
+int gode_segment_attention_f32_fwd2(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
+                                    const float* q, int64_t n_seg, int64_t h, float* a, float* r, int64_t ldr, void* stream);
+int gode_segment_attention_f32_bwd2(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
+                                    const float* q, const float* a, const float* dr, int64_t ld_dr,
+                                    const float* add1, int64_t ld1, const float* add2, int64_t ld2, int64_t n_seg,
+                                    int64_t h, float* dx, int accumulate_dx, float* dq, void* stream);
 
 /* ---- whole rk4 integrations of the GCN ODE function in one call (host-launch-bound sizes) -----
  * f(t, x) = relu(A * ([t | GroupNorm(x)] * W) + b)   (ODEfunc.forward, GCN/models.py:172-179).
@@ -592,6 +607,16 @@ int gode_lstm_cell_f32_bwd(const float* x, const float* h, const float* c, const
                            const float* gates, const float* c_out, const float* dh_out, const float* dc_out, int64_t B,
                            int64_t I, int64_t H, float* dx, float* dh, float* dc, float* dw_ih, float* dw_hh,
                            float* db_ih, float* db_hh, void* stream);
+/* fwd2: h' is also written to h_out2 (nullable; leading dimension ld_h2 >= H: the left half of Set2Set's q_star);
+ * bwd2: accumulate != 0 ADDS the weight / bias gradients into dw_ih, dw_hh, db_ih, db_hh in place (every element has one
+ * owner thread), so the gradients of the processing steps of a readout loop collect in one buffer, in step order. */
+int gode_lstm_cell_f32_fwd2(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
+                            const float* b_ih, const float* b_hh, int64_t B, int64_t I, int64_t H, float* h_out,
+                            float* c_out, float* gates, float* h_out2, int64_t ld_h2, void* stream);
+int gode_lstm_cell_f32_bwd2(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
+                            const float* gates, const float* c_out, const float* dh_out, const float* dc_out, int64_t B,
+                            int64_t I, int64_t H, float* dx, float* dh, float* dc, float* dw_ih, float* dw_hh,
+                            float* db_ih, float* db_hh, int accumulate, void* stream);
 
 /* ---- QC node update: fused GRU cell (replaces nn.GRUCell(2h, h) applied to ([x | m], x), QC/mpnn.py:12,30) -----
  * x, m: n x h (state and aggregated messages; the concatenation [x | m] is never formed).  w_ih: 3h x 2h, w_hh: 3h x h,

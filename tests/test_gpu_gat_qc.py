@@ -557,6 +557,41 @@ def test_set2set_module_vs_reference_golden(golden):
         close(p.grad, g["g__" + k.replace(".", "__")], 2e-5, "grad " + k)
 
 
+@pytest.mark.parametrize("sorted_batch", [True, False])
+def test_set2set_one_node_matches_per_step_path(sorted_batch):
+    """The readout loop as ONE autograd node (ops.set2set_fwd / set2set_bwd: the LSTM cell writes q_t into q_star, the
+    weight gradients of the processing steps collect inside the cell's backward kernel, the node cotangent inside the
+    attention's) against the chain of per-step nodes: q_star and every gradient, a sorted and an unsorted batch vector, a
+    graph without nodes, 12 processing steps."""
+    from graph_odenet_amd import qc_models as Q
+    g = torch.Generator().manual_seed(3)
+    n, h, nb = 230, 73, 9
+    batch = torch.randint(0, nb, (n,), generator=g)
+    batch[batch == 4] = 5                                        # graph 4 has no nodes
+    batch[0] = nb - 1                                            # the largest id is present: nb graphs
+    if sorted_batch:
+        batch = batch.sort().values
+    x0 = torch.randn(n, h, generator=g)
+    gout = torch.randn(nb, 2 * h, generator=g)
+    res = []
+    for one in (True, False):
+        Q.SET2SET_ONE_NODE = one
+        try:
+            torch.manual_seed(1)
+            m = Q.Set2Set(h, 12, 1).to(dev())
+            x = x0.to(dev()).requires_grad_(True)
+            b = batch.to(dev())
+            out = m(x, b)
+            (out * gout.to(dev())).sum().backward()
+            res.append((out.detach().cpu(), x.grad.cpu(), [p.grad.cpu() for p in m.parameters()]))
+        finally:
+            Q.SET2SET_ONE_NODE = True
+    close(res[0][0], res[1][0], 1e-6, "q_star")
+    close(res[0][1], res[1][1], 1e-5, "dx")
+    for a, b_ in zip(res[0][2], res[1][2]):
+        close(a, b_, 1e-5, "lstm parameter gradient")
+
+
 def test_gat_hip_graph_captured_solves_match_eager(golden):
     """Same as the GCN capture test for the fused GAT field (Python-driven stages, weights re-packed inside the graph)."""
     from graph_odenet_amd import gat_models, odeint as OI

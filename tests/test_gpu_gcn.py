@@ -965,6 +965,34 @@ def test_graph_convolution_sparse_features_and_padded_classes():
     for _ in range(3):
         lay(xdense, a2)
     assert L.sparse_features(xdense) is None
+    # the explicit switches: sparse_input=True takes CSR(X) from the FIRST call, False never does,
+    # and a sparse tensor as the input is the CSR route whatever the switch - all against the oracle layer
+    lay = L.GraphConvolution(f, 7)
+    w, b = lay.weight.detach().clone().requires_grad_(True), lay.bias.detach().clone().requires_grad_(True)
+    ref = R.graph_convolution(x, adj, w, b)
+    gout = torch.randn(n, 7)
+    ref.backward(gout)
+    lay, ad = lay.to(dev()), adj.to(dev())
+    for mode, inp, want in ((True, x.to(dev()), True), (False, x.to(dev()), False), (None, x.to_sparse().to(dev()), True),
+                            (None, x.to_sparse_csr().to(dev()), True)):
+        lay.sparse_input = mode
+        lay.zero_grad()
+        out = lay(inp, ad)
+        out.backward(gout.to(dev()))
+        close(out, ref, 1e-5, "out (sparse_input=%r, %s)" % (mode, inp.layout))
+        close(lay.weight.grad, w.grad, 2e-5, "dW"); close(lay.bias.grad, b.grad, 2e-5, "db")
+        if inp.layout == torch.strided:
+            assert (L.sparse_features(inp, mode) is not None) == want
+    # inside a capture nothing is decided: an unseen tensor runs dense, no host synchronisation is attempted
+    fresh = x.to(dev())
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        L.sparse_features(fresh)                              # first sighting outside
+        with torch.cuda.graph(g, stream=st):
+            assert L.sparse_features(fresh) is None           # the second sighting would decide: not while capturing
+    L.invalidate_sparse_features(fresh)
+    assert L.sparse_features(fresh) is None                   # forgotten: a first sighting again
 
 
 @pytest.mark.parametrize("n", [1500, 9000])          # a wave per row / four rows per wave (from 8 192 rows on)

@@ -782,13 +782,16 @@ def test_exact_three_way_cut_planes():
     assert bool((hi.abs() <= X.abs()).all()) and bool(((X - hi).abs() <= X.abs() * 2.0 ** -7).all())   # truncation, 8 bits
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 300, 150), (129, 257, 33), (1, 1, 1), (384, 256, 512)])
+@pytest.mark.parametrize("M,N,K", [(200, 300, 150), (129, 257, 33), (1, 1, 1), (384, 256, 512), (130, 100, 2100)])
 def test_piece_gemm_all_operand_layouts_and_epilogues(M, N, K):
     """csrc/pgemm.hip gode_pgemm_bf16x3 (large products of the QC edge encoder on the bf16 matrix cores from exact cuts):
     C = op(A) op(B) for the four operand layouts - each operand read from LDS by ds_read_b128 or by the transposing
     ds_read_b64_tr_b16 - ragged sizes, the fused epilogues, 8 and 6 piece products, against float64 at the bar of the
-    exact-fp32 kernel; the cut of a matrix serves both of its roles."""
-    from graph_odenet_amd import ops
+    exact-fp32 kernel; the cut of a matrix serves both of its roles.  (130, 100, 2100): two tiles, 66 k-steps - the
+    contraction is split over four blocks per tile and summed by the finishing launch."""
+    from graph_odenet_amd import _lib, ops
+    if (M, N, K) == (130, 100, 2100):
+        assert _lib.load().gode_pgemm_workspace_bytes(M, N, K) == 4 * M * N * 4
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / max(K, 1) ** 0.5
     bias, mask = torch.randn(N, generator=g), torch.randn(M, N, generator=g)

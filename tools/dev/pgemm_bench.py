@@ -39,6 +39,22 @@ def timed(fn, n=20):
     return ev[0].elapsed_time(ev[1]) / n * 1e3
 
 
+FLUSH = torch.empty(1 << 28, device=D)            # 1 GiB: four times the Infinity Cache
+
+
+def timed_cold(fn, n=8):
+    """every call behind a 2 GiB read-modify-write of another buffer: operands come from HBM, as inside a training step"""
+    fn()
+    tot = 0.0
+    for _ in range(n):
+        FLUSH.add_(1.0)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record(); fn(); ev[1].record()
+        torch.cuda.synchronize()
+        tot += ev[0].elapsed_time(ev[1])
+    return tot / n * 1e3
+
+
 Hc, Wc, dc = ops.cut3(H), ops.cut3(W2), ops.cut3(dA)
 flop = 2.0 * E * Hd * O
 rows = []
@@ -50,8 +66,10 @@ for name, f32fn, pfn in (
         t32 = timed(f32fn)
         t8 = timed(lambda: pfn(8))
         t6 = timed(lambda: pfn(6))
+        c32, c8 = timed_cold(f32fn), timed_cold(lambda: pfn(8))
         print("%-16s fp32-MFMA %7.1f us (%5.1f TFLOP/s)   pieces x8 %7.1f us (%5.1f fp32-equiv TFLOP/s, %4.2f of the bf16 peak)   x6 %7.1f us"
-              % (name, t32, flop / t32 / 1e6, t8, flop / t8 / 1e6, 8 * flop / t8 / 1e6 / 2500.0, t6), flush=True)
+              "   | operands from HBM: fp32 %7.1f us, pieces x8 %7.1f us"
+              % (name, t32, flop / t32 / 1e6, t8, flop / t8 / 1e6, 8 * flop / t8 / 1e6 / 2500.0, t6, c32, c8), flush=True)
 for name, X in (("cut W2 (2667 x 5329)", W2), ("cut dA (760 x 5329)", dA), ("cut H (760 x 2667)", H)):
     t = timed(lambda: ops.cut3(X))
     byt = X.numel() * 4 + 6 * lib.gode_cut_pad(X.shape[0]) * lib.gode_cut_pad(X.shape[1])
