@@ -190,9 +190,12 @@ SIGNATURES = {
     "gode_edge_matvec_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_segment_attention_f32_fwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_segment_attention_f32_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
-    "gode_segment_attention_f32_fwd2": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
-    "gode_segment_attention_f32_bwd2": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i64,
-                                              c_p, c_i, c_p, c_p]),
+    "gode_assign_csr_supported": (c_i, [c_i64, c_i64]),
+    "gode_assign_csr_i32": (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "gode_set2set_supported": (c_i, [c_i64]),
+    "gode_set2set_f32_fwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "gode_set2set_f32_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p,
+                                   c_p, c_p]),
     "gode_gcn_ode_theta_len": (c_i64, [c_i64]),
     "gode_gcn_ode_rk4_forward": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, ctypes.POINTER(c_p), ctypes.POINTER(Rk4Workspace),
                                        c_f, c_f, ctypes.c_int32, c_p]),
@@ -217,8 +220,6 @@ SIGNATURES = {
     "gode_lstm_cell_supported": (c_i, [c_i64, c_i64, c_i64]),
     "gode_lstm_cell_f32_fwd": (c_i, [c_p] * 7 + [c_i64] * 3 + [c_p] * 4),
     "gode_lstm_cell_f32_bwd": (c_i, [c_p] * 9 + [c_i64] * 3 + [c_p] * 8),
-    "gode_lstm_cell_f32_fwd2": (c_i, [c_p] * 7 + [c_i64] * 3 + [c_p] * 4 + [c_i64, c_p]),
-    "gode_lstm_cell_f32_bwd2": (c_i, [c_p] * 9 + [c_i64] * 3 + [c_p] * 7 + [c_i, c_p]),
     "gode_gru_wgrad_parts": (c_i64, [c_i64]),
     "gode_gru_cell_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_gru_cell_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,

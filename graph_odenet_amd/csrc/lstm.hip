@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restr
                                                             const float* __restrict__ w_hh, const float* __restrict__ b_ih,
                                                             const float* __restrict__ b_hh, int B, int I, int H, int CB,
                                                             float* __restrict__ h_out, float* __restrict__ c_out,
-                                                            float* __restrict__ gates, float* __restrict__ h_out2, int64_t ld_h2)
+                                                            float* __restrict__ gates)
 {
     extern __shared__ float smem[];
     const int u = blockIdx.x, g = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -65,9 +65,7 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restr
             const float ig = sigmoidf_(pre[l]), fg = sigmoidf_(pre[64 + l]), gg = tanhf(pre[128 + l]), og = sigmoidf_(pre[192 + l]);
             const float cn = fg * c[(int64_t)b * H + u] + ig * gg;
             c_out[(int64_t)b * H + u] = cn;
-            const float hv = og * tanhf(cn);
-            h_out[(int64_t)b * H + u] = hv;
-            if (h_out2) h_out2[(int64_t)b * ld_h2 + u] = hv;         // a second copy inside a wider matrix (Set2Set's q_star)
+            h_out[(int64_t)b * H + u] = og * tanhf(cn);
             if (gates) {
                 float* gp = gates + (int64_t)b * 4 * H + u;
                 gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dc_out, int B, int I, int H,
                                                             float* __restrict__ dx, float* __restrict__ dh, float* __restrict__ dc,
                                                             float* __restrict__ dw_ih, float* __restrict__ dw_hh,
-                                                            float* __restrict__ db_ih, float* __restrict__ db_hh, int accumulate)
+                                                            float* __restrict__ db_ih, float* __restrict__ db_hh)
 {
     extern __shared__ float smem[];
     const int G4 = 4 * H, K = I + H, GP = G4 | 1;               // odd row stride of dG: lane b reads dG[b][j] conflict-free
@@ -150,15 +148,10 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = k0 + q;
-            // every element of a weight gradient belongs to exactly one thread: accumulating over the processing steps of a
-            // Set2Set readout is a read-modify-write in place, in step order
-            if (k < I) { float* d = dw_ih + (int64_t)j * I + k; *d = accumulate ? *d + av[q] : av[q]; }
-            else if (k < K) { float* d = dw_hh + (int64_t)j * H + (k - I); *d = accumulate ? *d + av[q] : av[q]; }
+            if (k < I) dw_ih[(int64_t)j * I + k] = av[q];
+            else if (k < K) dw_hh[(int64_t)j * H + (k - I)] = av[q];
         }
-        if (blockIdx.x == 0) {
-            if (db_ih) db_ih[j] = accumulate ? db_ih[j] + s : s;
-            if (db_hh) db_hh[j] = accumulate ? db_hh[j] + s : s;
-        }
+        if (blockIdx.x == 0) { if (db_ih) db_ih[j] = s; if (db_hh) db_hh[j] = s; }
     }
     // input cotangents: wave w owns column k0 + w, LANE b the batch row (broadcast reads of the column, no reduction)
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, k = k0 + w;
@@ -181,21 +174,10 @@ extern "C" int gode_lstm_cell_supported(int64_t B, int64_t I, int64_t H) {
     return B > 0 && I > 0 && H > 0 && B * (4 * H + 1) + 4 * B + 16 * H <= kLstmMaxLds && 6 * (I + H) + 256 <= kLstmMaxLds;
 }
 
-extern "C" int gode_lstm_cell_f32_fwd2(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
-                                       const float* b_ih, const float* b_hh, int64_t B, int64_t I, int64_t H, float* h_out,
-                                       float* c_out, float* gates, float* h_out2, int64_t ld_h2, void* stream);
 extern "C" int gode_lstm_cell_f32_fwd(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
                                       const float* b_ih, const float* b_hh, int64_t B, int64_t I, int64_t H, float* h_out,
                                       float* c_out, float* gates, void* stream)
 {
-    return gode_lstm_cell_f32_fwd2(x, h, c, w_ih, w_hh, b_ih, b_hh, B, I, H, h_out, c_out, gates, nullptr, 0, stream);
-}
-
-extern "C" int gode_lstm_cell_f32_fwd2(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
-                                       const float* b_ih, const float* b_hh, int64_t B, int64_t I, int64_t H, float* h_out,
-                                       float* c_out, float* gates, float* h_out2, int64_t ld_h2, void* stream)
-{
-    if (h_out2 && ld_h2 < H) return GODE_E_SHAPE;
     if (B < 0 || I <= 0 || H <= 0) return GODE_E_SHAPE;
     if (B == 0) return 0;
     if (!x || !h || !c || !w_ih || !w_hh || !h_out || !c_out) return GODE_E_NULLPTR;
@@ -207,28 +189,15 @@ extern "C" int gode_lstm_cell_f32_fwd2(const float* x, const float* h, const flo
     const size_t lds = (size_t)(cb * KP + 4 * K + 256) * sizeof(float);
     int rc = gode_set_lds_once(reinterpret_cast<const void*>(lstm_cell_fwd_kernel), lds); if (rc) return rc;
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((unsigned)H), dim3(256), lds, (hipStream_t)stream, x, h, c, w_ih, w_hh, b_ih, b_hh,
-                       (int)B, (int)I, (int)H, (int)cb, h_out, c_out, gates, h_out2, ld_h2);
+                       (int)B, (int)I, (int)H, (int)cb, h_out, c_out, gates);
     GODE_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gode_lstm_cell_f32_bwd2(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
-                                       const float* gates, const float* c_out, const float* dh_out, const float* dc_out,
-                                       int64_t B, int64_t I, int64_t H, float* dx, float* dh, float* dc, float* dw_ih,
-                                       float* dw_hh, float* db_ih, float* db_hh, int accumulate, void* stream);
 extern "C" int gode_lstm_cell_f32_bwd(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
                                       const float* gates, const float* c_out, const float* dh_out, const float* dc_out,
                                       int64_t B, int64_t I, int64_t H, float* dx, float* dh, float* dc, float* dw_ih,
                                       float* dw_hh, float* db_ih, float* db_hh, void* stream)
-{
-    return gode_lstm_cell_f32_bwd2(x, h, c, w_ih, w_hh, gates, c_out, dh_out, dc_out, B, I, H, dx, dh, dc, dw_ih, dw_hh, db_ih,
-                                   db_hh, 0, stream);
-}
-
-extern "C" int gode_lstm_cell_f32_bwd2(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
-                                       const float* gates, const float* c_out, const float* dh_out, const float* dc_out,
-                                       int64_t B, int64_t I, int64_t H, float* dx, float* dh, float* dc, float* dw_ih,
-                                       float* dw_hh, float* db_ih, float* db_hh, int accumulate, void* stream)
 {
     if (B < 0 || I <= 0 || H <= 0) return GODE_E_SHAPE;
     if (B == 0) return 0;
@@ -238,7 +207,7 @@ extern "C" int gode_lstm_cell_f32_bwd2(const float* x, const float* h, const flo
     int rc = gode_set_lds_once(reinterpret_cast<const void*>(lstm_cell_bwd_kernel), lds); if (rc) return rc;
     const int64_t blocks = (I + H + 3) / 4;
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, x, h, c, w_ih, w_hh, gates,
-                       c_out, dh_out, dc_out, (int)B, (int)I, (int)H, dx, dh, dc, dw_ih, dw_hh, db_ih, db_hh, accumulate);
+                       c_out, dh_out, dc_out, (int)B, (int)I, (int)H, dx, dh, dc, dw_ih, dw_hh, db_ih, db_hh);
     GODE_LAUNCH_CHECK();
     return 0;
 }

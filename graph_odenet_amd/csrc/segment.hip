@@ -41,14 +41,14 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const int32_t* __rest
                                                            const int32_t* __restrict__ perm,
                                                            const float* __restrict__ x, int64_t ldx,
                                                            const float* __restrict__ q, int h,
-                                                           float* __restrict__ a, float* __restrict__ r, int64_t ldr) {
+                                                           float* __restrict__ a, float* __restrict__ r) {
     __shared__ float red[kWaves];
     __shared__ float racc[kWaves][MC * 64];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int beg = segptr[b], end = segptr[b + 1];
     if (end <= beg) {                                       // graph without nodes: r = 0
-        for (int f = threadIdx.x; f < h; f += 256) r[(int64_t)b * ldr + f] = 0.f;
+        for (int f = threadIdx.x; f < h; f += 256) r[(int64_t)b * h + f] = 0.f;
         return;
     }
     float qv[MC];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void seg_attn_fwd_kernel(const int32_t* __rest
         float t = 0.f;
 #pragma unroll
         for (int j = 0; j < kWaves; ++j) t += racc[j][f];
-        r[(int64_t)b * ldr + f] = t * inv;
+        r[(int64_t)b * h + f] = t * inv;
     }
     for (int k = beg + threadIdx.x; k < end; k += 256) {
         const int node = perm ? perm[k] : k;
@@ -107,18 +107,15 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const int32_t* __rest
                                                            const int32_t* __restrict__ perm,
                                                            const float* __restrict__ x, int64_t ldx,
                                                            const float* __restrict__ q, const float* __restrict__ a,
-                                                           const float* __restrict__ dr, int64_t ld_dr,
-                                                           const float* __restrict__ add1, int64_t ld1,
-                                                           const float* __restrict__ add2, int64_t ld2, int h,
-                                                           float* __restrict__ dx, int accumulate_dx, float* __restrict__ dq) {
+                                                           const float* __restrict__ dr, int h,
+                                                           float* __restrict__ dx, float* __restrict__ dq) {
     __shared__ float red[kWaves];
     __shared__ float qacc[kWaves][MC * 64];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int beg = segptr[b], end = segptr[b + 1];
     if (end <= beg) {
-        for (int f = threadIdx.x; f < h; f += 256)
-            dq[(int64_t)b * h + f] = (add1 ? add1[(int64_t)b * ld1 + f] : 0.f) + (add2 ? add2[(int64_t)b * ld2 + f] : 0.f);
+        for (int f = threadIdx.x; f < h; f += 256) dq[(int64_t)b * h + f] = 0.f;
         return;
     }
     float qv[MC], gv[MC];
@@ -126,7 +123,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const int32_t* __rest
     for (int c = 0; c < MC; ++c) {
         const int f = lane + 64 * c;
         qv[c] = f < h ? q[(int64_t)b * h + f] : 0.f;
-        gv[c] = f < h ? dr[(int64_t)b * ld_dr + f] : 0.f;
+        gv[c] = f < h ? dr[(int64_t)b * h + f] : 0.f;
     }
     float t = 0.f;
     for (int k = beg + w; k < end; k += kWaves) {
@@ -154,7 +151,7 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const int32_t* __rest
 #pragma unroll
         for (int c = 0; c < MC; ++c) {
             const int f = lane + 64 * c;
-            if (f < h) { const float v = fmaf(ai, gv[c], de * qv[c]); dxr[f] = accumulate_dx ? dxr[f] + v : v; }
+            if (f < h) dxr[f] = fmaf(ai, gv[c], de * qv[c]);
             acc[c] = fmaf(de, xv[c], acc[c]);
         }
     }
@@ -165,8 +162,6 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const int32_t* __rest
         float v = 0.f;
 #pragma unroll
         for (int j = 0; j < kWaves; ++j) v += qacc[j][f];
-        if (add1) v += add1[(int64_t)b * ld1 + f];
-        if (add2) v += add2[(int64_t)b * ld2 + f];
         dq[(int64_t)b * h + f] = v;
     }
 }
@@ -183,50 +178,30 @@ __global__ __launch_bounds__(256) void seg_attn_bwd_kernel(const int32_t* __rest
         else hipLaunchKernelGGL(KERNEL<16>, dim3((unsigned)n_seg), dim3(256), 0, s, __VA_ARGS__);        \
     } while (0)
 
-extern "C" int gode_segment_attention_f32_fwd2(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
-                                               const float* q, int64_t n_seg, int64_t h, float* a, float* r, int64_t ldr,
-                                               void* stream);
 extern "C" int gode_segment_attention_f32_fwd(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
                                               const float* q, int64_t n_seg, int64_t h, float* a, float* r,
                                               void* stream) {
-    return gode_segment_attention_f32_fwd2(segptr, perm, x, ldx, q, n_seg, h, a, r, h, stream);
-}
-
-extern "C" int gode_segment_attention_f32_fwd2(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
-                                               const float* q, int64_t n_seg, int64_t h, float* a, float* r, int64_t ldr,
-                                               void* stream) {
-    if (n_seg < 0 || h <= 0 || ldx < h || ldr < h) return GODE_E_SHAPE;
+    if (n_seg < 0 || h <= 0 || ldx < h) return GODE_E_SHAPE;
     if (n_seg == 0) return 0;
     if (!segptr || !x || !q || !a || !r) return GODE_E_NULLPTR;
     if (h > 1024) return GODE_E_UNSUPPORTED;
     if (n_seg > INT32_MAX) return GODE_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
-    GODE_SEG_DISPATCH(seg_attn_fwd_kernel, segptr, perm, x, ldx, q, (int)h, a, r, ldr);
+    GODE_SEG_DISPATCH(seg_attn_fwd_kernel, segptr, perm, x, ldx, q, (int)h, a, r);
     GODE_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int gode_segment_attention_f32_bwd2(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
-                                               const float* q, const float* a, const float* dr, int64_t ld_dr,
-                                               const float* add1, int64_t ld1, const float* add2, int64_t ld2, int64_t n_seg,
-                                               int64_t h, float* dx, int accumulate_dx, float* dq, void* stream);
 extern "C" int gode_segment_attention_f32_bwd(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
                                               const float* q, const float* a, const float* dr, int64_t n_seg,
                                               int64_t h, float* dx, float* dq, void* stream) {
-    return gode_segment_attention_f32_bwd2(segptr, perm, x, ldx, q, a, dr, h, nullptr, 0, nullptr, 0, n_seg, h, dx, 0, dq, stream);
-}
-
-extern "C" int gode_segment_attention_f32_bwd2(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
-                                               const float* q, const float* a, const float* dr, int64_t ld_dr,
-                                               const float* add1, int64_t ld1, const float* add2, int64_t ld2, int64_t n_seg,
-                                               int64_t h, float* dx, int accumulate_dx, float* dq, void* stream) {
-    if (n_seg < 0 || h <= 0 || ldx < h || ld_dr < h || (add1 && ld1 < h) || (add2 && ld2 < h)) return GODE_E_SHAPE;
+    if (n_seg < 0 || h <= 0 || ldx < h) return GODE_E_SHAPE;
     if (n_seg == 0) return 0;
     if (!segptr || !x || !q || !a || !dr || !dx || !dq) return GODE_E_NULLPTR;
     if (h > 1024) return GODE_E_UNSUPPORTED;
     if (n_seg > INT32_MAX) return GODE_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
-    GODE_SEG_DISPATCH(seg_attn_bwd_kernel, segptr, perm, x, ldx, q, a, dr, ld_dr, add1, ld1, add2, ld2, (int)h, dx, accumulate_dx, dq);
+    GODE_SEG_DISPATCH(seg_attn_bwd_kernel, segptr, perm, x, ldx, q, a, dr, (int)h, dx, dq);
     GODE_LAUNCH_CHECK();
     return 0;
 }

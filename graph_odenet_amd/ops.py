@@ -908,59 +908,44 @@ def group_norm_bwd(x, groups, eps, gamma, dy, want_affine_grads=True):
     return dx, dg, db
 
 
-# ---- the whole Set2Set readout loop (QC/set2set.py:59-75) -------------------------------------------------------
+# ---- the whole Set2Set readout loop (QC/set2set.py:50-75): one launch per direction (csrc/set2set.hip) -------------
+def set2set_supported(H):
+    return bool(_lib.load().gode_set2set_supported(int(H)))
+
+
 def set2set_fwd(segptr, perm, x, w_ih, w_hh, b_ih, b_hh, steps, n_graphs):
-    """q_star after `steps` processing steps, plus what the backward pass reads.  Two launches per step: the LSTM cell
-    writes q_t into the left half of q_star[t + 1], the segment attention writes r_t into its right half."""
+    """Returns (qs, cs, gates, att): qs[steps] is q_star; the rest is what set2set_bwd reads."""
     lib = _lib.load()
     for t_, nm in ((x, "x"), (w_ih, "weight_ih"), (w_hh, "weight_hh"), (b_ih, "bias_ih"), (b_hh, "bias_hh")):
         _need(t_, nm)
     N, H = x.shape
     B = int(n_graphs)
+    if tuple(w_ih.shape) != (4 * H, 2 * H) or tuple(w_hh.shape) != (4 * H, H):
+        raise ValueError("set2set: weight_ih 4H x 2H, weight_hh 4H x H for H = %d (got %s, %s)" % (H, tuple(w_ih.shape), tuple(w_hh.shape)))
     f = dict(dtype=torch.float32, device=x.device)
-    qs = torch.zeros(steps + 1, B, 2 * H, **f)          # q_star[0] = 0; q_star[t + 1] = [q_t | r_t]
-    hs = torch.zeros(steps + 1, B, H, **f)              # h_0 = 0; h_{t+1} = q_t (contiguous copy: the next cell's h input)
-    cs = torch.zeros(steps + 1, B, H, **f)
-    gates = torch.empty(steps, B, 4 * H, **f)
-    att = torch.empty(steps, N, **f)
-    st = stream_ptr()
-    for t in range(steps):
-        check(lib.gode_lstm_cell_f32_fwd2(ptr(qs[t]), ptr(hs[t]), ptr(cs[t]), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), B,
-                                          2 * H, H, ptr(hs[t + 1]), ptr(cs[t + 1]), ptr(gates[t]), ptr(qs[t + 1]), 2 * H, st),
-              "gode_lstm_cell_f32_fwd2")
-        check(lib.gode_segment_attention_f32_fwd2(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(hs[t + 1]), B, H,
-                                                  ptr(att[t]), ctypes.c_void_p(qs[t + 1].data_ptr() + 4 * H), 2 * H, st),
-              "gode_segment_attention_f32_fwd2")
-    return qs, hs, cs, gates, att
+    Wt = torch.cat([w_ih, w_hh], 1).t().contiguous()        # (3H) x (4H): gate rows contiguous for the cell's threads
+    qs, cs = torch.empty(steps + 1, B, 2 * H, **f), torch.empty(steps + 1, B, H, **f)
+    gates, att = torch.empty(steps, B, 4 * H, **f), torch.empty(steps, N, **f)
+    check(lib.gode_set2set_f32_fwd(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(Wt), ptr(b_ih), ptr(b_hh), B, H, steps, N,
+                                   ptr(qs), ptr(cs), ptr(gates), ptr(att), stream_ptr()), "gode_set2set_f32_fwd")
+    return qs, cs, gates, att
 
 
 def set2set_bwd(segptr, perm, x, w_ih, w_hh, has_bias, saved, dq_star):
-    """Cotangents of (x, w_ih, w_hh, b_ih, b_hh) from dq_star (B x 2H).  Two launches per step; the weight gradients of
-    the steps collect in one buffer (gode_lstm_cell_f32_bwd2 with accumulate), the node cotangent in another."""
+    """(dx, dw_ih, dw_hh, db_ih, db_hh) from dq_star (B x 2H): the loop kernel, one small product for the weight gradient
+    (dW_ih = DG^T QS; dW_hh is its first H columns), one column sum for the biases."""
     lib = _lib.load()
-    qs, hs, cs, gates, att = saved
-    steps, B, H = gates.shape[0], qs.shape[1], hs.shape[2]
+    qs, cs, gates, att = saved
+    steps, B, H = gates.shape[0], qs.shape[1], cs.shape[2]
     N = x.shape[0]
     f = dict(dtype=torch.float32, device=x.device)
-    dx = torch.empty(N, H, **f)
-    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
-    db_ih = torch.empty(4 * H, **f) if has_bias else None
-    db_hh = torch.empty(4 * H, **f) if has_bias else None
-    dqs = dq_star.contiguous()                           # cotangent of q_star[t + 1], B x 2H
-    dh_next = dc_next = None                             # the next cell's cotangents of (h, c)
-    dq = torch.empty(B, H, **f)
-    st = stream_ptr()
-    for t in reversed(range(steps)):
-        # r_t = attention(x, q_t): dr = right half of dqs; dq_t = attention part + left half of dqs + the next cell's dh
-        check(lib.gode_segment_attention_f32_bwd2(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(hs[t + 1]), ptr(att[t]),
-                                                  ctypes.c_void_p(dqs.data_ptr() + 4 * H), 2 * H, ptr(dqs), 2 * H,
-                                                  ptr(dh_next), H, B, H, ptr(dx), 0 if t == steps - 1 else 1, ptr(dq), st),
-              "gode_segment_attention_f32_bwd2")
-        dqs_new, dh_new, dc_new = torch.empty(B, 2 * H, **f), torch.empty(B, H, **f), torch.empty(B, H, **f)
-        check(lib.gode_lstm_cell_f32_bwd2(ptr(qs[t]), ptr(hs[t]), ptr(cs[t]), ptr(w_ih), ptr(w_hh), ptr(gates[t]), ptr(cs[t + 1]),
-                                          ptr(dq), ptr(dc_next), B, 2 * H, H, ptr(dqs_new), ptr(dh_new), ptr(dc_new),
-                                          ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh), 0 if t == steps - 1 else 1, st),
-              "gode_lstm_cell_f32_bwd2")
-        dqs, dh_next, dc_next = dqs_new, dh_new, dc_new
-    return dx, dw_ih, dw_hh, db_ih, db_hh
-
+    dx = torch.zeros(N, H, **f) if B == 0 else torch.empty(N, H, **f)
+    DG = torch.empty(steps, B, 4 * H, **f)
+    check(lib.gode_set2set_f32_bwd(ptr(segptr), ptr(perm), ptr(x), x.stride(0), ptr(w_ih), ptr(w_hh), B, H, steps, N, ptr(qs),
+                                   ptr(cs), ptr(gates), ptr(att), ptr(dq_star.contiguous()), ptr(dx), ptr(DG), stream_ptr()),
+          "gode_set2set_f32_bwd")
+    dg2 = DG.view(steps * B, 4 * H)
+    dw_ih = gemm(dg2, qs[:steps].reshape(steps * B, 2 * H), trans_a=True)
+    dw_hh = dw_ih[:, :H].contiguous()
+    db = colsum_(torch.empty(4 * H, **f), dg2) if has_bias else None
+    return dx, dw_ih, dw_hh, db, db

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from . import ops
 from .functional import GroupNorm
 from .functional import Linear as GodeLinear
-from .graph import RECORDS_MIN_NNZ, CSRGraph, incidence_from_index
+from .graph import RECORDS_MIN_NNZ, CSRGraph, csr_from_assignment, incidence_from_index
 from .qc_layers import EdgeGraphConvolution, MPNN_enn_edge
 
 
@@ -111,14 +111,14 @@ class _Segments:
             self.nb = int(mx) + 1
         else:
             self.nb, uns = 0, 0
-        counts = torch.zeros(self.nb, dtype=torch.int64, device=batch.device).index_add_(
-            0, b64, torch.ones(n, dtype=torch.int64, device=batch.device))
-        segptr = torch.zeros(self.nb + 1, dtype=torch.int64, device=batch.device)
-        segptr[1:] = torch.cumsum(counts, 0)
-        self.segptr = segptr.to(torch.int32)
-        self.perm = torch.argsort(b64, stable=True).to(torch.int32) if uns else None
+        # nodes grouped by graph, ascending inside a graph: one launch for a mini-batch (graph.csr_from_assignment ->
+        # csrc/convert.hip), the sort-based path for large inputs
+        g = csr_from_assignment(b64, self.nb, None, records=False) if self.nb > 0 else None
+        self.segptr = g.rowptr if g is not None else torch.zeros(1, dtype=torch.int32, device=batch.device)
+        self.perm = g.col if (uns and g is not None) else None
         self.index = b64
-        self.incidence = None
+        # sorted batch vector: the rows of the membership matrix are the segments themselves and g IS that matrix
+        self.incidence = g if (g is not None and not uns and n < RECORDS_MIN_NNZ) else None
 
     def sum_matrix(self):
         """nb x N membership matrix (pattern-only CSR) for the per-graph sum."""
@@ -210,10 +210,11 @@ SET2SET_ONE_NODE = True      # False: the readout as a chain of per-step autogra
 
 
 class _Set2SetFn(torch.autograd.Function):
-    """The whole readout loop of QC/set2set.py:59-75 as ONE autograd node: two launches per processing step in each
-    direction (ops.set2set_fwd / set2set_bwd).  As a chain of per-step nodes autograd summed the LSTM's weight gradients
-    with ~50 elementwise launches per training step and formed q_star with a `cat` per step; here the cell writes q_t into
-    q_star itself and the weight gradients of the 12 steps collect in one buffer inside the cell's backward kernel."""
+    """The whole readout loop of QC/set2set.py:50-75 as ONE autograd node and ONE launch per direction (csrc/set2set.hip:
+    a workgroup per graph walks its row of the LSTM state and its nodes through every processing step - nothing couples two
+    graphs of a batch).  As a chain of per-step nodes the readout was ~50 launches forward, ~50 backward and ~50 elementwise
+    launches of autograd summing the LSTM's per-step weight gradients; here those gradients are one small product over the
+    saved gate cotangents (ops.set2set_bwd)."""
 
     @staticmethod
     def forward(ctx, seg, x, w_ih, w_hh, b_ih, b_hh, steps):
@@ -261,7 +262,7 @@ class Set2Set(nn.Module):
         l = self.lstm
         if SET2SET_ONE_NODE and self.num_layers == 1 and x.is_cuda and x.dtype == torch.float32 and self.processing_steps > 0 and \
                 (getattr(l, "bias_ih_l0", None) is None) == (getattr(l, "bias_hh_l0", None) is None) and \
-                ops.lstm_cell_supported(nb, self.out_channels, self.in_channels) and nb > 0:
+                ops.set2set_supported(self.in_channels) and nb > 0:
             return _Set2SetFn.apply(seg, x, l.weight_ih_l0, l.weight_hh_l0, getattr(l, "bias_ih_l0", None),
                                     getattr(l, "bias_hh_l0", None), self.processing_steps)
         h = (x.new_zeros(self.num_layers, nb, self.in_channels), x.new_zeros(self.num_layers, nb, self.in_channels))

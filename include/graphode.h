@@ -408,17 +408,34 @@ int gode_segment_attention_f32_fwd(const int32_t* segptr, const int32_t* perm, c
 int gode_segment_attention_f32_bwd(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
                                    const float* q, const float* a, const float* dr, int64_t n_seg, int64_t h,
                                    float* dx, float* dq, void* stream);
-/* The forms the whole Set2Set loop runs on (one autograd node for the 12 processing steps of QC/set2set.py:59-75):
- * fwd2 writes r with a leading dimension (straight into the right half of q_star = [q | r]); bwd2 reads dr with a leading
- * dimension (the right half of the cotangent of q_star), ADDS dx into the running node cotangent (accumulate_dx != 0) and
- * returns dq = (attention part) + add1 + add2 (nullable n_seg x h matrices with leading dimensions: the left half of the
- * cotangent of q_star and the LSTM's cotangent of h). */
-int gode_segment_attention_f32_fwd2(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
-                                    const float* q, int64_t n_seg, int64_t h, float* a, float* r, int64_t ldr, void* stream);
-int gode_segment_attention_f32_bwd2(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx,
-                                    const float* q, const float* a, const float* dr, int64_t ld_dr,
-                                    const float* add1, int64_t ld1, const float* add2, int64_t ld2, int64_t n_seg,
-                                    int64_t h, float* dx, int accumulate_dx, float* dq, void* stream);
+/* ---- CSR of a small assignment matrix in one launch (csrc/convert.hip) -----------------------------------------
+ * The (n_rows x n_entries) matrix with one entry per column e at row index[e] - edge -> target atom, edge -> source atom,
+ * atom -> graph of a QC mini-batch (QC/datasets/utils.py:194-214) - as int32 CSR: rowptr[n_rows + 1], order[n_entries] =
+ * the column ids grouped by row, ascending inside a row (stable), vals_out[k] = vals[order[k]] (both nullable; vals null,
+ * vals_out not: ones).  Entries with an index outside [0, n_rows) are dropped (rowptr[n_rows] counts what is left).
+ * One workgroup; n_entries <= 2048, n_rows <= 4096 (gode_assign_csr_supported), else GODE_E_UNSUPPORTED. */
+int gode_assign_csr_supported(int64_t n_entries, int64_t n_rows);
+int gode_assign_csr_i32(const int64_t* index, int64_t n_entries, int64_t n_rows, int32_t* rowptr, int32_t* order,
+                        const float* vals, float* vals_out, void* stream);
+
+/* ---- the whole Set2Set readout loop (QC/set2set.py:50-75) as ONE launch per direction (csrc/set2set.hip) ----------
+ * processing_steps rounds of { q_t = LSTMCell(q*_{t-1}); r_t = segment attention of x with query q_t; q*_t = [q_t | r_t] }.
+ * Row b of every quantity depends on the nodes of graph b only, so one workgroup walks graph b through all rounds.
+ * Wt: the transposed weights [W_ih | W_hh]^T, (3H) x (4H) row-major (gate order i, f, g, o as torch.nn.LSTM); b_ih, b_hh
+ * nullable.  fwd writes (caller-owned, any previous content): qs (steps+1) x n_graphs x 2H with qs[t+1] = q*_t (qs[steps]
+ * is the module's output), cs (steps+1) x n_graphs x H, gates steps x n_graphs x 4H (activations), att steps x n_nodes.
+ * bwd takes dq_final (n_graphs x 2H) and those arrays; writes dx (n_nodes x H, contiguous) and DG (steps x n_graphs x 4H,
+ * the gate cotangents).  The weight gradients follow without another pass over the nodes:
+ * dW_ih = DG^T QS (rows t, b: DG[t][b] and qs[t][b]), dW_hh = dW_ih[:, :H] (h_{t-1} is the left half of q*_{t-1}),
+ * db_ih = db_hh = column sums of DG.  H <= 512. */
+int gode_set2set_supported(int64_t H);
+int gode_set2set_f32_fwd(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx, const float* Wt,
+                         const float* b_ih, const float* b_hh, int64_t n_graphs, int64_t H, int64_t steps, int64_t n_nodes,
+                         float* qs, float* cs, float* gates, float* att, void* stream);
+int gode_set2set_f32_bwd(const int32_t* segptr, const int32_t* perm, const float* x, int64_t ldx, const float* w_ih,
+                         const float* w_hh, int64_t n_graphs, int64_t H, int64_t steps, int64_t n_nodes, const float* qs,
+                         const float* cs, const float* gates, const float* att, const float* dq_final, float* dx,
+                         float* DG, void* stream);
 
 /* ---- whole rk4 integrations of the GCN ODE function in one call (host-launch-bound sizes) -----
  * f(t, x) = relu(A * ([t | GroupNorm(x)] * W) + b)   (ODEfunc.forward, GCN/models.py:172-179).
@@ -607,17 +624,6 @@ int gode_lstm_cell_f32_bwd(const float* x, const float* h, const float* c, const
                            const float* gates, const float* c_out, const float* dh_out, const float* dc_out, int64_t B,
                            int64_t I, int64_t H, float* dx, float* dh, float* dc, float* dw_ih, float* dw_hh,
                            float* db_ih, float* db_hh, void* stream);
-/* fwd2: h' is also written to h_out2 (nullable; leading dimension ld_h2 >= H: the left half of Set2Set's q_star);
- * bwd2: accumulate != 0 ADDS the weight / bias gradients into dw_ih, dw_hh, db_ih, db_hh in place (every element has one
- * owner thread), so the gradients of the processing steps of a readout loop collect in one buffer, in step order. */
-int gode_lstm_cell_f32_fwd2(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
-                            const float* b_ih, const float* b_hh, int64_t B, int64_t I, int64_t H, float* h_out,
-                            float* c_out, float* gates, float* h_out2, int64_t ld_h2, void* stream);
-int gode_lstm_cell_f32_bwd2(const float* x, const float* h, const float* c, const float* w_ih, const float* w_hh,
-                            const float* gates, const float* c_out, const float* dh_out, const float* dc_out, int64_t B,
-                            int64_t I, int64_t H, float* dx, float* dh, float* dc, float* dw_ih, float* dw_hh,
-                            float* db_ih, float* db_hh, int accumulate, void* stream);
-
 /* ---- QC node update: fused GRU cell (replaces nn.GRUCell(2h, h) applied to ([x | m], x), QC/mpnn.py:12,30) -----
  * x, m: n x h (state and aggregated messages; the concatenation [x | m] is never formed).  w_ih: 3h x 2h, w_hh: 3h x h,
  * b_ih, b_hh: 3h (nullable), gate order r, z, n as torch.nn.GRUCell.  out: n x h.  gates (nullable; n x 4h) receives

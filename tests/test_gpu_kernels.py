@@ -836,6 +836,34 @@ def test_piece_gemm_large_magnitude_spread():
     assert bool(((got - ref).abs() <= 1e-6 * bound).all())
 
 
+def test_one_launch_assignment_csr_matches_the_sort_based_path():
+    """csrc/convert.hip gode_assign_csr_i32 (a QC mini-batch's edge -> atom and atom -> graph vectors as CSR in one launch)
+    against graph.csr_from_assignment's sort-based path: row pointers, the STABLE order inside every row, gathered values;
+    empty rows, a single row, the size limits, and sizes past them (which take the sort-based path)."""
+    from graph_odenet_amd import _lib, graph as G
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(17)
+    for e, n in ((760, 360), (2048, 4096), (1, 1), (5, 3000), (300, 7), (0, 4)):
+        idx = torch.randint(0, n, (e,), generator=g)
+        if e > 10:
+            idx[idx == 2] = 3                                          # row 2 stays empty
+        vals = torch.randn(e, generator=g)
+        assert lib.gode_assign_csr_supported(e, n)
+        got = G.csr_from_assignment(idx.to(dev()), n, vals.to(dev()))
+        order = torch.argsort(idx, stable=True)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(torch.bincount(idx, minlength=n), 0)
+        assert got.items is None and got.rowptr.dtype == torch.int32
+        assert torch.equal(got.rowptr.cpu().long(), rowptr) and torch.equal(got.col.cpu().long(), order)
+        assert torch.equal(got.val.cpu(), vals[order])
+        pat = G.csr_from_assignment(idx.to(dev()), n)                  # pattern-only
+        assert pat.val is None and torch.equal(pat.col.cpu().long(), order)
+    assert not lib.gode_assign_csr_supported(2049, 10) and not lib.gode_assign_csr_supported(10, 4097)
+    idx = torch.randint(0, 5000, (3000,), generator=g)
+    big = G.csr_from_assignment(idx.to(dev()), 5000)                   # the sort-based path
+    assert torch.equal(big.col.cpu().long(), torch.argsort(idx, stable=True))
+
+
 def test_lincomb_multi_one_launch_for_four_components():
     """gode_lincomb_multi_f32: the solution combine of an adjoint state [y, a, a_t, theta] as one launch - components of
     different lengths (one of them a single float, one not a multiple of four), in place on the first term, bit for bit the
