@@ -140,7 +140,7 @@ def secondary(args, model, x, g, step, barrier):
     # against the default (bf16-piece kernels for the weight gradient and the <= 2-term forward launches)
     from graph_odenet_amd import _lib
     lib = _lib.load()
-    names = (b"gemm_split", b"wgrad_split", b"fwd_pc", b"bwd_pc")
+    names = (b"gemm_split", b"wgrad_split", b"fwd_pc", b"bwd_pc", b"bwd_wgrad")
     was = [lib.gode_get_option(k) for k in names]
 
     def timed(settings, reps=2):
@@ -162,19 +162,23 @@ def secondary(args, model, x, g, step, barrier):
     # kernels, <= 2-term forward on gn_gemm_fwd_split_kernel), every dense product on the fp32-MFMA kernels, and the
     # default again (the first and last figure bracket the drift of the box)
     out["steps_per_s_default_kernels"] = timed(was)
-    out["steps_per_s_with_round2_dense_kernels"] = timed((2, was[1], 0, 0))
-    out["steps_per_s_with_fp32_mfma_dense_kernels_only"] = timed((0, 0, 0, 0))
+    out["steps_per_s_with_separate_vjp_and_weight_gradient_launches"] = timed((was[0], was[1], was[2], was[3], 0))   # round 3
+    out["steps_per_s_with_round2_dense_kernels"] = timed((2, was[1], 0, 0, 0))
+    out["steps_per_s_with_fp32_mfma_dense_kernels_only"] = timed((0, 0, 0, 0, 0))
     out["steps_per_s_default_kernels_again"] = timed(was)
     return out
 
 
 BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense")
-FAMILY = {1: ("forward S = [t|GN(x)]W", 2), 2: ("VJP dx = GN'(x)^T dS W1^T", 3), 3: ("weight gradient dW = [1|GN(x)]^T dS", 2)}
+FAMILY = {1: ("forward S = [t|GN(x)]W", 2), 2: ("VJP dx = GN'(x)^T dS W1^T", 3), 3: ("weight gradient dW = [1|GN(x)]^T dS", 2),
+          4: ("VJP + weight gradient in one pass (2 products)", 3)}
+FAMILY_PRODUCTS = {1: 1, 2: 1, 3: 1, 4: 2}            # N x d x d products a launch of the family forms
 KERNEL = {(1, 0): "gn_gemm_fwd_kernel<8,4> (fp32 MFMA)", (1, 1): "gn_gemm_fwd_split_kernel (bf16 pieces)",
           (1, 2): "gn_gemm_fwd_pc_kernel (bf16 pieces, producer/consumer)",
           (2, 0): "gn_gemm_bwd_kernel<8,4> (fp32 MFMA)",
           (2, 2): "gn_gemm_bwd_pc_kernel (bf16 pieces, producer/consumer)",
-          (3, 0): "wgrad_kernel<8,4> (fp32 MFMA)", (3, 2): "wgrad_split_kernel (bf16 pieces, producer/consumer)"}
+          (3, 0): "wgrad_kernel<8,4> (fp32 MFMA)", (3, 2): "wgrad_split_kernel (bf16 pieces, producer/consumer)",
+          (4, 2): "gn_gemm_bwd_wgrad_pc_kernel (bf16 pieces, one producer group, transposed LDS reads)"}
 
 
 def dense_table(lib, cnt, ms, dd, rr, xx, kk, n, hidden, flop, nd4):
@@ -196,7 +200,7 @@ def dense_table(lib, cnt, ms, dd, rr, xx, kk, n, hidden, flop, nd4):
     for (fam, form, extra), v in sorted(groups.items()):
         avg = sum(v) / len(v)
         byts = (FAMILY[fam][1] + extra) * nd4
-        eq = flop / (avg * 1e-3) / 1e12
+        eq = FAMILY_PRODUCTS[fam] * flop / (avg * 1e-3) / 1e12
         unit = eq / MFMA_F32_PEAK_TFLOPS if form == 0 else 8 * eq / BF16_PEAK_TFLOPS
         out["kernels"]["%s, +%d arrays" % (KERNEL.get((fam, form), "family %d form %d" % (fam, form)), extra)] = {
             "launches_timed": len(v), "avg_launch_ms": round(avg, 4), "achieved": round(eq, 1),
@@ -207,7 +211,7 @@ def dense_table(lib, cnt, ms, dd, rr, xx, kk, n, hidden, flop, nd4):
     for fam, (tot, c) in fam_tot.items():
         avg = tot / c
         out["families"][FAMILY[fam][0]] = {"launches_timed": c, "avg_launch_ms": round(avg, 4),
-                                           "frac_fp32_equiv": round(flop / (avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+                                           "frac_fp32_equiv": round(FAMILY_PRODUCTS[fam] * flop / (avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
     return out
 
 

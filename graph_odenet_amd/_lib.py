@@ -119,6 +119,10 @@ SIGNATURES = {
     "gode_gemm_bwd_parts": (c_i64, [c_i64]),
     "gode_gn_time_gemm_bwd_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p,
                                         c_p, c_i64, c_i, c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p]),
+    "gode_bwd_wgrad_supported": (c_i, [c_i64, c_i64, c_i64, ctypes.c_int32]),
+    "gode_bwd_wgrad_parts": (c_i64, [c_i64]),
+    "gode_gn_time_gemm_bwd_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_i64, c_i,
+                                              c_p, c_f, ctypes.POINTER(LinComb), c_p, c_p, c_p, c_p, c_p]),
     "gode_group_norm_parts": (c_i64, [c_i64]),
     "gode_group_norm_f32_fwd": (c_i, [c_p, c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p]),
     "gode_group_norm_f32_bwd": (c_i, [c_p, c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),

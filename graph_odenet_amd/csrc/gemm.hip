@@ -1587,6 +1587,36 @@ extern "C" int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin, int64_t n_ro
     return 0;
 }
 
+// VJP w.r.t. x AND the weight gradient from one read of x and dS (gemm_pc.hip: gn_gemm_bwd_wgrad_pc_kernel); the same
+// outputs as gode_gn_time_gemm_bwd_f32 + gode_wgrad_f32, except that dW_part holds gode_bwd_wgrad_parts(n_rows) partials.
+extern "C" int gode_bwd_wgrad_supported(int64_t n_rows, int64_t d_in, int64_t d_out, int32_t groups) {
+    const int cg = fast_cg(d_in, d_out, groups);
+    return (cg == 0 || cg == 4) && d_in == 128 && gode_opt_bwd_wgrad() && gode_opt_bwd_pc() && gode_opt_wgrad_split() == 8 &&
+           (n_rows >= kWgradSplitMinRows || gode_opt_wgrad_split_small());
+}
+extern "C" int64_t gode_bwd_wgrad_parts(int64_t n_rows) { return gode_pc_bwd_wgrad_parts(n_rows); }
+
+extern "C" int gode_gn_time_gemm_bwd_wgrad_f32(const gode_lincomb_t* xin, int64_t n_rows, int64_t d_in, int32_t groups,
+                                               float eps, const float* gamma, const float* beta, const float* W,
+                                               int64_t d_out, int has_time, const float* dS, float out_scale,
+                                               const gode_lincomb_t* pre, float* dx, float* dgamma_part,
+                                               float* dbeta_part, float* dW_part, void* stream)
+{
+    int rc = check_common(xin, n_rows, d_in, groups, d_out); if (rc) return rc;
+    if (n_rows == 0) return 0;
+    if (!W || !dS || !dx || !dW_part) return GODE_E_NULLPTR;
+    if ((dgamma_part == nullptr) != (dbeta_part == nullptr)) return GODE_E_NULLPTR;
+    if (pre && pre->n > 0) { rc = check_lincomb(pre, true); if (rc) return rc; } else pre = nullptr;
+    if (!gode_bwd_wgrad_supported(n_rows, d_in, d_out, groups)) return GODE_E_UNSUPPORTED;
+    const bool al = lincomb_aligned16(xin) && lincomb_aligned16(pre) && !(((uintptr_t)dS) & 15) && !(((uintptr_t)dx) & 15) &&
+                    (!gamma || !(((uintptr_t)gamma) & 15)) && (!beta || !(((uintptr_t)beta) & 15)) &&
+                    (!dgamma_part || (!(((uintptr_t)dgamma_part) & 15) && !(((uintptr_t)dbeta_part) & 15)));
+    if (!al) return GODE_E_ALIGN;
+    return gode_pc_bwd_wgrad_launch(make_lincomb(xin), n_rows, eps, gamma, beta, W, has_time ? 1 : 0, dS, out_scale,
+                                    make_lincomb(pre), dx, dgamma_part, dbeta_part, gode_gemm_bwd_parts(n_rows), dW_part,
+                                    fast_cg(d_in, d_out, groups), (hipStream_t)stream);
+}
+
 extern "C" int64_t gode_wgrad_parts(int64_t n_rows) {
     return wgrad_blocks(n_rows);
 }

@@ -388,6 +388,245 @@ __global__ __launch_bounds__(1024, 1) void gn_gemm_bwd_pc_kernel(LinComb xin, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// VJP and weight gradient in ONE pass (round 4):  dx = GN'(x)^T (dS W1^T)  AND  dW = [1 | GN(x)]^T dS  from one read of x
+// and dS per adjoint stage (the two launches read both arrays twice: -1 GB per stage at 2^20 x 128).
+//
+// 768 threads: waves 0-7 consume, waves 8-11 produce (ONE producer group with two register sets, so that two tiles are in
+// flight while a third is staged; 12 waves = 3 per SIMD leave 168 registers per wave - the 16-wave layout of the two
+// separate kernels leaves 128, and a consumer here holds 48 (its W1 slab) + 32 (its dW tiles) + 8 (its dx tiles)
+// resident beside ~36 of operand fragments).
+// Producers stage, per 32-row tile: the pieces of dS and of xn = GN(x) as ROW-MAJOR images (272-byte rows) and the fp32 x
+// tile the GroupNorm backward reads.  Consumers: (1) dxn = dS W1^T as in gn_gemm_bwd_pc_kernel - weight slab in
+// registers, dS rows by ds_read_b128; (2) the wave's 4 x 2 tiles of xn^T dS - both operands are wanted TRANSPOSED (8
+// consecutive rows of one column): ds_read_b64_tr_b16 delivers exactly that from the same row-major images, so nothing
+// is staged twice.  128 MFMAs per tile and wave.  Outputs as the two kernels': dx (+ pre-terms), one dgamma / dbeta
+// partial row per block, one dW partial ((D + has_time) x D, row 0 = column sums of dS) per block.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+#define GODE_LDS_AS __attribute__((address_space(3)))
+
+// this lane's fragment of a transposed operand: rows 8 g .. 8 g + 7 of the image, column c16 + (lane & 15)
+__device__ __forceinline__ bf16x8 tr_frag(const char* img_lane /* image + lane's offset */, int col_bytes) {
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GODE_LDS_AS s16x4_t*)(img_lane + col_bytes));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GODE_LDS_AS s16x4_t*)(img_lane + col_bytes + 4 * LDK * 2));
+    const bf16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return v;
+}
+
+template <int CG, int NX>   // CG: 0 or 4 channels per group; NX: terms of x held raw (1, 2), 0 = any count, combined at load
+__global__ __launch_bounds__(768) void gn_gemm_bwd_wgrad_pc_kernel(LinComb xin, int n_rows, float eps,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 const float* __restrict__ W, int has_time,
+                                                                 const float* __restrict__ dS, float out_scale,
+                                                                 LinComb pre, float* __restrict__ dx,
+                                                                 float* __restrict__ dgamma_part,
+                                                                 float* __restrict__ dbeta_part, int n_part,
+                                                                 float* __restrict__ dW_part)
+{
+    constexpr int R = 32, PIECE_B = Img<R>::PIECE_B, IMG_B = 3 * PIECE_B;
+    constexpr int XT_B = CG != 0 ? R * LDX * 4 : 0;
+    constexpr int BUF_B = 2 * IMG_B + XT_B;                         // dS pieces | xn pieces | fp32 x tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    const TileWalk tw(n_rows, R);
+    float* out = dW_part + (int64_t)blockIdx.x * (D + has_time) * D;
+    if (threadIdx.x >= 512) {
+        // ---- producers: thread (trow, tc4) stages rows 4 trow + p, columns 4 tc4 .. + 3 (one GroupNorm group)
+        const int pt = threadIdx.x - 512;
+        const int trow = pt >> 5, tcol = 4 * (pt & 31);
+        const float4 gmv = gamma ? ld4(gamma + tcol) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 btv = beta ? ld4(beta + tcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int NXR = NX > 0 ? NX : 1;
+        struct Regs { float4 g[4]; float4 x[NXR][4]; };
+        Regs qa, qb;
+        auto prefetch = [&](Regs& q, int k) {     // unconditional loads from clamped rows
+            const int tile = tw.clamped(k);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = tile * R + 4 * trow + p;
+                const int64_t off = (int64_t)(row < n_rows ? row : n_rows - 1) * D + tcol;
+                q.g[p] = ld4(dS + off);
+                if (NX > 0) {
+#pragma unroll
+                    for (int j = 0; j < NXR; ++j) q.x[j][p] = ld4(xin.ptr[j] + off);
+                } else {
+                    q.x[0][p] = lc_load4(xin, off);
+                }
+            }
+        };
+        // NO branch around loads or around the code that consumes them: hipcc waits vmcnt(0) at the join of a branch that
+        // holds a load, which would drain the OTHER register set's prefetch (issued a moment ago) in front of every stage -
+        // the first version did, and ran at 4.7 us per tile instead of ~2.  Tiles past the block's last one are staged
+        // from clamped rows into the buffer nobody reads any more, and count as invalid (live = false).
+        auto stage = [&](Regs& q, int k) {        // tile k of this block -> buffer k & 1
+            char* buf = lds + (k & 1) * BUF_B;
+            const bool live = k < tw.mine;
+            const int tile = tw.clamped(k);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int rr = 4 * trow + p;
+                const bool valid = live && tile * R + rr < n_rows;
+                float4 x = q.x[0][p];
+                if (NX > 0) {                     // the term order and arithmetic of lc_load4_n
+                    x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < NXR; ++j) {
+                        const float c = xin.coef[j];
+                        x.x = fmaf(c, q.x[j][p].x, x.x); x.y = fmaf(c, q.x[j][p].y, x.y);
+                        x.z = fmaf(c, q.x[j][p].z, x.z); x.w = fmaf(c, q.x[j][p].w, x.w);
+                    }
+                }
+                float4 xn = gn_forward_v<CG>(x, eps, gmv, btv);
+                float4 gv = q.g[p];
+                if (!valid) { xn = make_float4(0.f, 0.f, 0.f, 0.f); gv = make_float4(0.f, 0.f, 0.f, 0.f); }
+                csum.x += gv.x; csum.y += gv.y; csum.z += gv.z; csum.w += gv.w;
+                stage_row4<PIECE_B>(buf + rr * LDK * 2 + tcol * 2, gv);
+                stage_row4<PIECE_B>(buf + IMG_B + rr * LDK * 2 + tcol * 2, xn);
+                if (CG != 0) *reinterpret_cast<float4*>(buf + 2 * IMG_B + (rr * LDX + tcol) * 4) = x;
+            }
+        };
+        prefetch(qa, 0);
+        prefetch(qb, 1);
+        stage(qa, 0);
+        prefetch(qa, 2);
+        lds_barrier();                                                     // tile 0 staged
+        for (int k = 0; k < tw.mine;) {                                    // while the consumers work on tile k
+            stage(qb, k + 1);
+            prefetch(qb, k + 3);
+            lds_barrier();
+            if (++k >= tw.mine) break;
+            stage(qa, k + 1);
+            prefetch(qa, k + 3);
+            lds_barrier();
+            ++k;
+        }
+        // every consumer is past its last operand read: column sums of dS (the time row of dW), and the partial rows of
+        // the GroupNorm affine gradients that no block owns
+        if (has_time) {
+            float* red = smem;                                             // [8][D]
+            *reinterpret_cast<float4*>(red + trow * D + tcol) = csum;
+        }
+        __syncthreads();                                                   // pairs with the consumers' barrier below
+        if (has_time && pt < D) {
+            float sacc = 0.f;
+            for (int p = 0; p < 8; ++p) sacc += smem[p * D + pt];
+            out[pt] = sacc;
+        }
+        if (CG != 0 && dgamma_part)
+            for (int p = gridDim.x + blockIdx.x; p < n_part; p += gridDim.x)
+                for (int c = pt; c < D; c += 256) { dgamma_part[(int64_t)p * D + c] = 0.f; dbeta_part[(int64_t)p * D + c] = 0.f; }
+        return;
+    }
+    // ---- consumers
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    const int i0 = 16 * wave, c0 = i0 + 4 * g;                            // VJP: this lane's four input channels
+    bf16x8 A[4][3];
+    load_weight_pieces(A, [&](int m, int k) { return W[(int64_t)(i0 + m + has_time) * D + k]; });     // W1 slab: rows i, k = n
+    const float4 gm = (CG != 0 && gamma) ? ld4(gamma + c0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 dgs = make_float4(0.f, 0.f, 0.f, 0.f), dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int rd_off = r * LDK * 2 + g * 16;
+    const int xt_off = 2 * IMG_B + (r * LDX + c0) * 4;
+    const int a0 = 4 * (wave >> 2), b0 = 2 * (wave & 3);                  // weight gradient: tiles (a0 .. a0 + 3) x (b0, b0 + 1)
+    const int tr_off = (8 * g + (r >> 2)) * LDK * 2 + 4 * (r & 3) * 2;    // lane 4 q + p of a group: row q, columns 4 p ..
+    f32x4 wacc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) wacc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    lds_barrier();                                                         // tile 0 staged
+    for (int k = 0; k < tw.mine; ++k) {
+        const char* buf = lds + (k & 1) * BUF_B;
+        const int row0 = tw.tile(k) * R + r;
+        // (1) dxn = dS W1^T and the GroupNorm backward
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        tile_product<R>(buf + rd_off, A, acc);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int row = row0 + 16 * rt;
+            const bool valid = row < n_rows;
+            const float4 dy = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+            float4 o4 = dy;
+            if (CG != 0) {
+                const float4 x = *reinterpret_cast<const float4*>(buf + xt_off + rt * 16 * LDX * 4);
+                float4 mean, rstd;
+                gn_stats<CG>(x, eps, mean, rstd);
+                const float4 xh = make_float4((x.x - mean.x) * rstd.x, (x.y - mean.y) * rstd.y,
+                                              (x.z - mean.z) * rstd.z, (x.w - mean.w) * rstd.w);
+                const float4 dh = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+                if (valid) {
+                    dgs.x += dy.x * xh.x; dgs.y += dy.y * xh.y; dgs.z += dy.z * xh.z; dgs.w += dy.w * xh.w;
+                    dbs.x += dy.x; dbs.y += dy.y; dbs.z += dy.z; dbs.w += dy.w;
+                }
+                const float m1 = ((dh.x + dh.y) + (dh.z + dh.w)) * 0.25f;
+                const float m2 = ((dh.x * xh.x + dh.y * xh.y) + (dh.z * xh.z + dh.w * xh.w)) * 0.25f;
+                const float rs = rstd.x;
+                o4 = make_float4(rs * (dh.x - m1 - xh.x * m2), rs * (dh.y - m1 - xh.y * m2),
+                                 rs * (dh.z - m1 - xh.z * m2), rs * (dh.w - m1 - xh.w * m2));
+            }
+            if (valid) {
+                float4 o = make_float4(out_scale * o4.x, out_scale * o4.y, out_scale * o4.z, out_scale * o4.w);
+                if (pre.n > 0) {                // fused RK solution combine of the adjoint component (last stage only)
+                    const float4 pv = lc_load4(pre, (int64_t)row * D + c0);
+                    o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+                }
+                *reinterpret_cast<float4*>(dx + (int64_t)row * D + c0) = o;
+            }
+        }
+        // (2) the wave's tiles of xn^T dS: transposed fragments straight from the row-major images
+        const char* Gp = buf + tr_off;
+        const char* Xp = buf + IMG_B + tr_off;
+        bf16x8 Bf[2][3];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) Bf[b][pc] = tr_frag(Gp + pc * PIECE_B, 16 * (b0 + b) * 2);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bf16x8 Af[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) Af[pc] = tr_frag(Xp + pc * PIECE_B, 16 * (a0 + a) * 2);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x4 c = wacc[a][b];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[2], Bf[b][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[1], Bf[b][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[2], Bf[b][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[0], Bf[b][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[1], Bf[b][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[1], Bf[b][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[0], Bf[b][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[0], Bf[b][0], c, 0, 0, 0);
+                wacc[a][b] = c;
+            }
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * (a0 + a) + 4 * g + q;
+                out[(int64_t)(i + has_time) * D + 16 * (b0 + b) + r] = wacc[a][b][q];
+            }
+    if (CG != 0 && dgamma_part) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            dgs.x += __shfl_xor(dgs.x, o, 64); dgs.y += __shfl_xor(dgs.y, o, 64); dgs.z += __shfl_xor(dgs.z, o, 64); dgs.w += __shfl_xor(dgs.w, o, 64);
+            dbs.x += __shfl_xor(dbs.x, o, 64); dbs.y += __shfl_xor(dbs.y, o, 64); dbs.z += __shfl_xor(dbs.z, o, 64); dbs.w += __shfl_xor(dbs.w, o, 64);
+        }
+        if (r == 0) {
+            *reinterpret_cast<float4*>(dgamma_part + (int64_t)blockIdx.x * D + c0) = dgs;
+            *reinterpret_cast<float4*>(dbeta_part + (int64_t)blockIdx.x * D + c0) = dbs;
+        }
+    }
+    __syncthreads();                                                       // pairs with the producers' barrier before the time row
+}
+
 int64_t pc_blocks(int64_t n_rows, int R) {
     int64_t b = (n_rows + R - 1) / R;
     if (b < 1) b = 1;
@@ -445,5 +684,29 @@ int gode_pc_bwd_launch(const LinComb& lc, int64_t n_rows, float eps, const float
     if (cg == 0) GODE_BPC3(0, 1, false) else if (cg == 4) GODE_BPC(4)
 #undef GODE_BPC
 #undef GODE_BPC3
+    return GODE_E_UNSUPPORTED;
+}
+
+int64_t gode_pc_bwd_wgrad_parts(int64_t n_rows) { return pc_blocks(n_rows, 32); }
+
+int gode_pc_bwd_wgrad_launch(const LinComb& lc, int64_t n_rows, float eps, const float* gamma, const float* beta, const float* W,
+                             int has_time, const float* dS, float out_scale, const LinComb& pre, float* dx,
+                             float* dgamma_part, float* dbeta_part, int64_t n_part, float* dW_part, int cg, hipStream_t s)
+{
+    const int64_t blocks = pc_blocks(n_rows, 32);
+    int rc = 0;
+#define GODE_BW(CGV, NXV)                                                                                          \
+    { const size_t lds = 2 * ((size_t)2 * 3 * Img<32>::PIECE_B + (CGV != 0 ? 32 * LDX * 4 : 0));                     \
+      rc = set_lds_pc(gn_gemm_bwd_wgrad_pc_kernel<CGV, NXV>, lds); if (rc) return rc;                               \
+      const int slot = gode_prof_begin(s, D, n_rows, (int64_t)lc.n - 1 + pre.n, GODE_PROF_BWD_WGRAD | GODE_PROF_FORM_PC); \
+      hipLaunchKernelGGL((gn_gemm_bwd_wgrad_pc_kernel<CGV, NXV>), dim3((unsigned)blocks), dim3(768), lds, s,         \
+                         lc, (int)n_rows, eps, gamma, beta, W, has_time, dS, out_scale, pre, dx, dgamma_part,       \
+                         dbeta_part, (int)n_part, dW_part);                                                        \
+      gode_prof_end(s, slot);                                                                                       \
+      GODE_LAUNCH_CHECK(); return 0; }
+#define GODE_BWN(CGV) { if (lc.n == 1) GODE_BW(CGV, 1) else if (lc.n == 2) GODE_BW(CGV, 2) else GODE_BW(CGV, 0) }
+    if (cg == 0) GODE_BWN(0) else if (cg == 4) GODE_BWN(4)
+#undef GODE_BWN
+#undef GODE_BW
     return GODE_E_UNSUPPORTED;
 }

@@ -191,6 +191,8 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
     float* ka[4] = {ws->ka[0], ws->ka[1], ws->ka[2], ws->ka[3]};
     const int64_t wparts = gode_wgrad_parts(n), gparts = gode_gemm_bwd_parts(n);
     const int total = 4 * n_steps;
+    // d = 128 on large graphs: Gb(s) and Wg(s) as ONE pass over x and dS (gemm_pc.hip: gn_gemm_bwd_wgrad_pc_kernel)
+    const bool bw = !small && gode_bwd_wgrad_supported(n, d, d, f->groups) && gode_bwd_wgrad_parts(n) <= wparts;
 
     // Stage inputs with 3 or 4 terms (stages 2 and 3 of the 3/8 rule) are written out by their Gf launch so that
     // Gb and Wg read ONE n x d array instead of the term list (measured at C5: Gb 0.78 -> 0.42 ms, Wg 0.56 -> 0.43 ms
@@ -250,8 +252,42 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
             GODE_HIP(hipEventRecord(ov->spt, hs));
             GODE_HIP(hipStreamWaitEvent(ov->side, ov->spt, 0));
         }
-        // side stream, beside Gb(g) on the main stream: Wg(g), then the dense part of the NEXT stage
         float* kt = ws->ktheta[s];
+        if (bw) {
+            // Gb(g) + Wg(g) in one launch on the caller's stream, then Gf(g+1) behind it (a 138 KB-LDS block and a
+            // forward block do not share a CU anyway); the small reductions of the stage run on the side stream beside
+            // them: colsum(dZ) as soon as SpT(g) is done, the partial sums once the dense launch is
+            if (two) GODE_HIP(hipStreamWaitEvent(ov->side, ov->spt, 0));
+            GODE_TRY(gode_colsum_f32(kt + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, side));
+            GODE_TRY(gode_gn_time_gemm_bwd_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1, ws->dS,
+                                                     s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &apre : nullptr, ka[s],
+                                                     f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr,
+                                                     ws->wpart, stream));
+            if (two) {
+                GODE_HIP(hipEventRecord(ov->sp, hs));
+                GODE_HIP(hipStreamWaitEvent(ov->side, ov->sp, 0));
+            }
+            GODE_TRY(gode_reduce_parts_f32(kt, ws->wpart, gode_bwd_wgrad_parts(n), nW, 1.f, 0, side));
+            hipLaunchKernelGGL(theta_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)side, kt, f->W, ts, (int)d, P - 1);
+            GODE_LAUNCH_CHECK();
+            if (f->groups > 0) {
+                GODE_TRY(gode_reduce_parts2_f32(kt + nW + d, ws->gpart, kt + nW + 2 * d, ws->bpart, gparts, d, 1.f, 0, side));
+            } else {
+                GODE_TRY(gode_zero_f32(kt + nW + d, 2 * d, side));
+            }
+            if (two) { GODE_HIP(hipEventRecord(ov->wg, ov->side)); wg_pending = true; }
+            if (g + 1 < total) {                                                    // Gf(g+1), same stream as Sp(g+1)
+                const int i2 = (g + 1) / 4, s2 = (g + 1) % 4;
+                gode_lincomb_t yin2 = stage_terms(ycur_n, ky_n, s2, h);
+                GODE_TRY(gode_gn_time_gemm_xout_f32(&yin2, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1,
+                                                    (float)((double)t0 + i2 * h + C38[s2] * h), Sbuf[(g + 1) & 1],
+                                                    x_out_of(g + 1), stream));
+                if (two) GODE_HIP(hipEventRecord(ov->gf, hs));      // the wait at the top of the next stage finds it done
+            }
+            // the side chain still reads dZ and the partial buffers, which Sp(g+1) and the next dense launch overwrite
+            if (two) { GODE_HIP(hipStreamWaitEvent(hs, ov->wg, 0)); wg_pending = false; }
+        } else {
+        // side stream, beside Gb(g) on the main stream: Wg(g), then the dense part of the NEXT stage
         const bool merged = small;                                    // launch-bound: one finishing launch per stage
         GODE_TRY(gode_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, ws->dS, d, 1, ws->wpart, side));   // Wg(g)
         if (!merged) {
@@ -280,6 +316,7 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
             } else {
                 GODE_TRY(gode_zero_f32(kt + nW + d, 2 * d, stream));
             }
+        }
         }
         if (s == 3) {
             // theta <- theta + h * sum b_s ktheta_s   (packed small components, one launch)

@@ -39,7 +39,8 @@ def _repack(spec, heads):
     if spec.d < 32 or not spec.Wsrc.is_cuda:
         return
     lib = _lib.load()
-    if not lib.gode_gat_small_supported(spec.eg.n if hasattr(spec.eg, "n") else spec.n, spec.d, int(spec.groups), heads):
+    # spec.n is the BASE node count (what _HeadsWork and the fields' small() test): with heads spec.eg is the H-fold graph
+    if not lib.gode_gat_small_supported(spec.n, spec.d, int(spec.groups), heads):
         return
     spec.Wpacked = ops.gat_small_pack(spec.Wsrc, spec.Wtgt, spec.Wlog, heads, out=spec.Wpacked)
 
@@ -58,6 +59,7 @@ class GatOdeSpec:
         self.Wtgt = torch.empty(self.i, self.d, dtype=torch.float32, device=dev)
         self.Wlog = torch.empty(self.i, 2, dtype=torch.float32, device=dev)
         self.Wpacked = None                           # LDS images of the three blocks for the one-launch kernels (d >= 32)
+        self.n = eg.n
         self.refresh()
         self.bf, self.bw = layer.f.bias.detach(), layer.w.bias.detach()
         self.gamma, self.beta = norm.weight.detach(), norm.bias.detach()

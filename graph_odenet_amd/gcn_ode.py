@@ -69,7 +69,7 @@ class _Shared:
                                        device=self.device))
         return self._ky, self._ka, self._kt, self._parts
 
-    def workspace_struct(self, adjoint):
+    def workspace_struct(self, adjoint, groups=0):
         ky, ka, kt, parts = self.stage_buffers(adjoint)
         ws = _lib.Rk4Workspace()
         ws.S = self.S.data_ptr()
@@ -88,14 +88,16 @@ class _Shared:
             if getattr(self, "X2", None) is None:
                 self.X2 = [torch.empty_like(self.S), torch.empty_like(self.S)]
             ws.X[0], ws.X[1] = self.X2[0].data_ptr(), self.X2[1].data_ptr()
-            sp = self.small_part()
+            sp = self.small_part(groups)
             ws.small_part = sp.data_ptr() if sp is not None else None
         return ws
 
-    def small_part(self):
+    def small_part(self, groups):
         """Block partials of the fused launch-bound VJP (csrc/small.hip); None when the shape is outside that path."""
+        lib = _lib.load()
+        if not lib.gode_gcn_small_supported(self.n, self.d, int(groups)):
+            return None                       # e.g. 2^20 x 128: 277 MB that nothing would ever read
         if getattr(self, "_small_part", None) is None:
-            lib = _lib.load()
             self._small_part = torch.empty(4 * lib.gode_gcn_small_parts(self.n) * lib.gode_gcn_small_part_len(self.d),
                                            dtype=torch.float32, device=self.device)
         return self._small_part
@@ -244,7 +246,7 @@ class GcnOdeField(Field):
         lib = _lib.load()
         s, w = self.s, self.w
         ky = w.stage_buffers(False)[0]
-        fs, ws = _func_struct(s), w.workspace_struct(False)
+        fs, ws = _func_struct(s), w.workspace_struct(False, s.groups)
         res = ctypes.c_void_p()
         _lib.check(lib.gode_gcn_ode_rk4_forward(ctypes.byref(fs), _lib.ptr(comps[0]), ctypes.byref(res), ctypes.byref(ws),
                                                 float(t0), float(t1), int(n_steps), _lib.stream_ptr()),
@@ -269,7 +271,7 @@ class GcnOdeField(Field):
         """One adaptive step in one C call (csrc/ode_driver.hip); returns the error sums as an fp64 device tensor."""
         lib = _lib.load()
         s, w = self.s, self.w
-        fs, ws = _func_struct(s), w.workspace_struct(False)
+        fs, ws = _func_struct(s), w.workspace_struct(False, s.groups)
         kptr = (ctypes.c_void_p * 7)(*[kk[i][0].data_ptr() for i in range(7)])
         sums = torch.empty(1, dtype=torch.float64, device=y[0].device)
         sc = ops._scratch(y[0].device, lib.gode_rk_errnorm_scratch_bytes())
@@ -350,7 +352,7 @@ class GcnOdeAdjointField(Field):
         lib = _lib.load()
         s, w = self.s, self.w
         ky, ka, _, _ = w.stage_buffers(True)
-        fs, ws = _func_struct(s), w.workspace_struct(True)
+        fs, ws = _func_struct(s), w.workspace_struct(True, s.groups)
         yr, ar = ctypes.c_void_p(), ctypes.c_void_p()
         _lib.check(lib.gode_gcn_ode_rk4_adjoint(ctypes.byref(fs), _lib.ptr(comps[0]), _lib.ptr(comps[1]), _lib.ptr(self.theta),
                                                 ctypes.byref(yr), ctypes.byref(ar), ctypes.byref(ws),
@@ -391,7 +393,7 @@ class GcnOdeAdjointField(Field):
     def dopri5_step_native(self, y, kk, y1, t, h, rtol, atol):
         lib = _lib.load()
         s, w = self.s, self.w
-        fs, ws = _func_struct(s), w.workspace_struct(True)
+        fs, ws = _func_struct(s), w.workspace_struct(True, s.groups)
         arr = lambda idx: (ctypes.c_void_p * 7)(*[kk[i][idx].data_ptr() for i in range(7)])      # noqa: E731
         kth = (ctypes.c_void_p * 7)(*[self._theta_of(kk[i]).data_ptr() for i in range(7)])
         sums = torch.empty(4, dtype=torch.float64, device=y[0].device)
@@ -427,7 +429,7 @@ class GcnOdeAdjointField(Field):
             fs = _func_struct(s)
             lx = _lib.lincomb(y_terms)
             lp = _lib.lincomb(pre[1]) if last else None
-            part = w.small_part()
+            part = w.small_part(s.groups)
             _lib.check(lib.gode_gcn_vjp_small_f32(ctypes.byref(fs), ctypes.byref(lx), _lib.ptr(dZ), float(coef if last else 1.0),
                                                   ctypes.byref(lp) if lp is not None else None, _lib.ptr(out[1]), _lib.ptr(part),
                                                   _lib.stream_ptr()), "gode_gcn_vjp_small_f32")
@@ -440,10 +442,16 @@ class GcnOdeAdjointField(Field):
                  cot_terms=[(-c, x) for (c, x) in terms[1]], out2=dZ,
                  pre_terms=pre[0] if pre is not None else None, alpha=coef if pre is not None else 1.0)
         ops.spmm(s.graph.transpose(), dZ, out=dS)                       # dS = A^T dZ
-        _, dgp, dbp = ops.gn_time_gemm_bwd(y_terms, n, d, s.groups, s.eps, s.gamma, s.W, True, dS,
-                                           out_scale=coef if pre is not None else 1.0, out=out[1],
-                                           pre_terms=pre[1] if pre is not None else None)   # k_a = -a^T df/dy
-        part = ops.wgrad(y_terms, n, d, s.groups, s.eps, s.gamma, s.beta, dS, True)
+        if ops.bwd_wgrad_supported(n, d, s.groups):
+            # large graphs at d = 128: k_a and the weight-gradient partials from ONE read of y and dS (csrc/gemm_pc.hip)
+            _, dgp, dbp, part = ops.gn_time_gemm_bwd_wgrad(y_terms, n, d, s.groups, s.eps, s.gamma, s.beta, s.W, True, dS,
+                                                           out_scale=coef if pre is not None else 1.0, out=out[1],
+                                                           pre_terms=pre[1] if pre is not None else None)
+        else:
+            _, dgp, dbp = ops.gn_time_gemm_bwd(y_terms, n, d, s.groups, s.eps, s.gamma, s.W, True, dS,
+                                               out_scale=coef if pre is not None else 1.0, out=out[1],
+                                               pre_terms=pre[1] if pre is not None else None)   # k_a = -a^T df/dy
+            part = ops.wgrad(y_terms, n, d, s.groups, s.eps, s.gamma, s.beta, dS, True)
         ops.reduce_parts_(out[3].view(-1), part)                        # row 0 = colsum(dS)
         out[2].copy_((out[3][0] * s.W[0]).sum().reshape(1))             # a_t' = -a^T df/dt
         out[3][0].mul_(t)                                               # dW[0,:] = t * colsum(dS)

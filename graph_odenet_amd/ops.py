@@ -329,6 +329,44 @@ def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS,
     return out, dg, db
 
 
+def bwd_wgrad_supported(n_rows, d, groups):
+    return bool(_lib.load().gode_bwd_wgrad_supported(n_rows, d, d, groups))
+
+
+def gn_time_gemm_bwd_wgrad(x_terms, n_rows, d, groups, eps, gamma, beta, W, has_time, dS, out_scale=1.0, out=None,
+                           pre_terms=None, parts=None, wpart=None):
+    """The VJP w.r.t. x and the weight gradient in one pass (csrc/gemm_pc.hip): returns (dx, dgamma_part, dbeta_part,
+    dW_part); dW_part is [gode_bwd_wgrad_parts(n_rows), (d + has_time) * d].  Raises where bwd_wgrad_supported is false."""
+    lib = _lib.load()
+    _need(W, "W"); _need(gamma, "gamma"); _need(beta, "beta"); _need(dS, "dS")
+    if _need_terms(x_terms, "x") != n_rows * d:
+        raise ValueError("gn_time_gemm_bwd_wgrad: x terms have wrong size")
+    if out is None:
+        out = torch.empty(n_rows, d, dtype=torch.float32, device=W.device)
+    _need(out, "out")
+    dg = db = None
+    if groups > 0:
+        n_part = lib.gode_gemm_bwd_parts(n_rows)
+        if parts is not None:
+            dg, db = parts
+        else:
+            dg = torch.empty(n_part, d, dtype=torch.float32, device=W.device)
+            db = torch.empty(n_part, d, dtype=torch.float32, device=W.device)
+    K = d + (1 if has_time else 0)
+    npw = lib.gode_bwd_wgrad_parts(n_rows)
+    if wpart is None:
+        wpart = torch.empty(npw, K * d, dtype=torch.float32, device=W.device)
+    elif wpart.numel() < npw * K * d:
+        raise ValueError("gn_time_gemm_bwd_wgrad: weight-gradient partial buffer too small")
+    lc = lincomb(x_terms)
+    pre = lincomb(pre_terms) if pre_terms is not None else None
+    check(lib.gode_gn_time_gemm_bwd_wgrad_f32(ctypes.byref(lc), n_rows, d, groups, float(eps), ptr(gamma), ptr(beta), ptr(W), d,
+                                              1 if has_time else 0, ptr(dS), float(out_scale),
+                                              ctypes.byref(pre) if pre is not None else None, ptr(out), ptr(dg), ptr(db),
+                                              ptr(wpart), stream_ptr()), "gode_gn_time_gemm_bwd_wgrad_f32")
+    return out, dg, db, wpart.view(-1)[:npw * K * d].view(npw, K * d)
+
+
 def wgrad(x_terms, n_rows, d_in, groups, eps, gamma, beta, dS, has_time, part=None):
     """Block partials [n_part, (d_in+has_time)*d_out] of dW = [1 | GN(x)]^T dS (row 0 = colsum(dS))."""
     lib = _lib.load()

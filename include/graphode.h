@@ -174,6 +174,18 @@ int gode_gn_time_gemm_bwd_f32(const gode_lincomb_t* xin /* host */, int64_t n_ro
                               const gode_lincomb_t* pre /* host, nullable */, float* dx,
                               float* dgamma_part, float* dbeta_part, void* stream);
 
+/* The VJP above AND the weight gradient (gode_wgrad_f32) from ONE read of x and dS (csrc/gemm_pc.hip; round 4): per adjoint
+ * stage the two launches read both N x d arrays twice.  Outputs as theirs: dx (+ pre), dgamma_part / dbeta_part
+ * [gode_gemm_bwd_parts(n_rows)][d] (both nullable together), dW_part [gode_bwd_wgrad_parts(n_rows)][(d + has_time) * d]
+ * (row 0 of a partial with has_time: column sums of dS).  Only where gode_bwd_wgrad_supported says so (d = 128, 0 or 4
+ * channels per group, >= 65 536 rows, 16-byte aligned operands); else GODE_E_UNSUPPORTED and the caller issues the pair. */
+int gode_bwd_wgrad_supported(int64_t n_rows, int64_t d_in, int64_t d_out, int32_t groups);
+int64_t gode_bwd_wgrad_parts(int64_t n_rows);
+int gode_gn_time_gemm_bwd_wgrad_f32(const gode_lincomb_t* xin /* host */, int64_t n_rows, int64_t d_in, int32_t groups,
+                                    float eps, const float* gamma, const float* beta, const float* W, int64_t d_out,
+                                    int has_time, const float* dS, float out_scale, const gode_lincomb_t* pre /* host, nullable */,
+                                    float* dx, float* dgamma_part, float* dbeta_part, float* dW_part, void* stream);
+
 /* Several block-partial reductions in ONE launch (what closes an adjoint stage on launch-bound graphs: weight-gradient
  * partials, bias column sums, GroupNorm affine partials, time-row bookkeeping).  Segment s:
  *   out[j] = sum_p part[p*ld + col0 + j*col_stride]   for j < len  (fixed summation order: deterministic);
@@ -651,6 +663,7 @@ int gode_gru_cell_f32_bwd(const float* x, const float* m, const float* w_ih, con
 #define GODE_PROF_GEMM_FWD 1
 #define GODE_PROF_GEMM_BWD 2
 #define GODE_PROF_WGRAD    3
+#define GODE_PROF_BWD_WGRAD 4      /* VJP + weight gradient in one pass (gode_gn_time_gemm_bwd_wgrad_f32): 2 x 2 N d^2 flop */
 /* which kernel of the family ran, OR-ed into the kind of a dense launch (kind & 0xff = family, kind >> 8 = form):
  * exact-fp32 MFMA kernel; bf16-piece kernel, every wave loading + cutting + multiplying; bf16-piece kernel in
  * producer / consumer form (wgrad_split_kernel, gemm_pc.hip) */

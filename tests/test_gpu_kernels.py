@@ -555,6 +555,66 @@ def test_vjp_from_exact_bf16_pieces(n, groups):
         lib.gode_set_option(b"wgrad_split_small", 0)
 
 
+@pytest.mark.parametrize("n", [1, 31, 33, 64, 1000, 4097, 70001])
+@pytest.mark.parametrize("groups", [32, 0])
+def test_vjp_and_weight_gradient_in_one_pass(n, groups):
+    """csrc/gemm_pc.hip gn_gemm_bwd_wgrad_pc_kernel (round 4): dx = GN'(x)^T (dS W1^T) and dW = [1 | GN(x)]^T dS from ONE
+    read of x and dS - one producer group with two register sets, transposed operand fragments by ds_read_b64_tr_b16 from
+    the row-major piece images - against float64 autograd and against the two separate kernels: dx (pre-term and output
+    scale), dgamma, dbeta, dW with and without the time row, 1 / 2 raw terms and 3 combined at load, ragged row counts
+    (odd tile counts per block, a partly empty last tile, fewer tiles than register sets)."""
+    from graph_odenet_amd import _lib, ops
+    import torch.nn.functional as F
+    lib = _lib.load()
+    d = 128
+    g = torch.Generator().manual_seed(n * 11 + groups)
+    ys = [torch.randn(n, d, generator=g) * 1.5 + 0.3, torch.randn(n, d, generator=g), torch.randn(n, d, generator=g)]
+    cf = [1.0, 0.25, -0.5]
+    dS, pre = torch.randn(n, d, generator=g) * torch.rand(n, 1, generator=g), torch.randn(n, d, generator=g)
+    gam, bet = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    W = torch.randn(d + 1, d, generator=g) / d ** 0.5
+    D = dev()
+    gm = gam.to(D) if groups else torch.ones(d, device=D)
+    bt = bet.to(D) if groups else torch.zeros(d, device=D)
+    try:
+        assert lib.gode_set_option(b"wgrad_split_small", 1) == 0
+        assert ops.bwd_wgrad_supported(n, d, groups)
+        for nt in (1, 2, 3):
+            x = sum(c * t.double() for c, t in zip(cf[:nt], ys[:nt])).requires_grad_(True)
+            g64 = gam.double().requires_grad_(True)
+            b64 = bet.double().requires_grad_(True)
+            xn = F.group_norm(x, groups, g64, b64, 1e-5) if groups else x
+            Wd = W.double().requires_grad_(True)
+            S = torch.cat([torch.ones(n, 1, dtype=torch.float64), xn], 1) @ Wd
+            S.backward(dS.double())
+            terms = [(c, t.to(D)) for c, t in zip(cf[:nt], ys[:nt])]
+            for with_pre, has_time in ((True, True), (False, True), (False, False)):
+                want_dx = (pre.double() if with_pre else 0.0) + 0.5 * x.grad
+                want_dW = Wd.grad if has_time else Wd.grad[1:]
+                Wg = W.to(D) if has_time else W[1:].contiguous().to(D)
+                pt = [(1.0, pre.to(D))] if with_pre else None
+                dx, dg, db, wp = ops.gn_time_gemm_bwd_wgrad(terms, n, d, groups, 1e-5, gm, bt, Wg, has_time, dS.to(D), out_scale=0.5,
+                                                            pre_terms=pt)
+                dx2, dg2, db2 = ops.gn_time_gemm_bwd(terms, n, d, groups, 1e-5, gm, Wg, has_time, dS.to(D), out_scale=0.5, pre_terms=pt)
+                wp2 = ops.wgrad(terms, n, d, groups, 1e-5, gm, bt, dS.to(D), has_time)
+                sx = want_dx.abs().max().item()
+                assert (dx.double().cpu() - want_dx).abs().max().item() <= 2e-5 * sx, (n, groups, nt, with_pre)
+                assert torch.equal(dx, dx2)                     # the same arithmetic as the stand-alone VJP kernel, bit for bit
+                dW = wp.double().sum(0).view(d + (1 if has_time else 0), d).cpu()
+                sw = want_dW.abs().max().item() + 1e-30
+                assert (dW - want_dW).abs().max().item() <= 2e-6 * sw, (n, groups, nt, has_time)
+                dW2 = wp2.double().sum(0).view_as(dW).cpu()
+                assert (dW - dW2).abs().max().item() <= 2e-6 * sw
+                if groups:
+                    for got_p, ref_p, want in ((dg, dg2, g64.grad), (db, db2, b64.grad)):
+                        got = got_p.double().sum(0).cpu()
+                        assert (got - want).abs().max().item() <= 3e-6 * max(1.0, want.abs().max().item()) * max(1, n ** 0.5)
+                        assert torch.equal(got_p.sum(0), ref_p.sum(0)) or (got - ref_p.double().sum(0).cpu()).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    finally:
+        lib.gode_set_option(b"wgrad_split_small", 0)
+    assert not ops.bwd_wgrad_supported(1000, d, groups)         # below 65 536 rows the drivers keep the two launches
+
+
 @pytest.mark.parametrize("n", [1, 17, 1000, 70001])
 @pytest.mark.parametrize("K,M", [(16, 7), (128, 16), (1433, 16), (500, 16), (3, 3), (100, 40), (64, 200), (130, 129), (3703, 64), (3703, 2)])
 def test_rectangular_products_vs_float64(n, K, M):
