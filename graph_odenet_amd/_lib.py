@@ -150,6 +150,7 @@ SIGNATURES = {
     "gode_gat_maxpath_heads_part_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_gat_heads_block_cap": (c_i64, []),
     "gode_gat_small_finish_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
+    "gode_gat_small_finish_step_f32": (c_i, [c_p, c_i64, c_i64, c_i64, ctypes.c_int32, c_p, c_p, c_p, c_p, c_p]),
     "gode_gcn_small_supported": (c_i, [c_i64, c_i64, ctypes.c_int32]),
     "gode_gcn_small_parts": (c_i64, [c_i64]),
     "gode_gcn_small_part_len": (c_i64, [c_i64]),

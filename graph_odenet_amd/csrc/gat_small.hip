@@ -408,6 +408,10 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
 struct GatFinish {
     const float* part; int n_part, plen, d, nl, nlp, heads, out_len;
     float t; float* ktheta; float* kat;
+    // n_slots > 0: the partials of n_slots stages (slot s at part + s * n_part * plen, evaluated at ts[s]) are closed in ONE
+    // launch that ADDS sum_s w[s] * (stage derivative) to ktheta / kat - the solution combine of the small components of a
+    // fixed-grid Runge-Kutta step (the adjoint ODE is linear in them and a fixed grid never looks at them in between)
+    int n_slots; float ts[4]; float w[4];
 };
 __global__ __launch_bounds__(1024) void gat_small_finish_kernel(GatFinish g)
 {
@@ -418,35 +422,52 @@ __global__ __launch_bounds__(1024) void gat_small_finish_kernel(GatFinish g)
     const int oBf = 2 * nW + nL, oBw = oBf + d, oGm = oBw + g.heads;     // theta offsets; gamma, beta are contiguous in both
     // partial rows are in the VJP kernel's LDS layout: two (d+1) x (d+1) blocks, one (d+1) x (NLP+1) block, dgamma, dbeta, a_t
     const int RS = d + 1, RSL = g.nlp + 1, rT = (d + 1) * RS, rL = 2 * rT, rG = rL + (d + 1) * RSL;
-    int src = -1; float scale = 1.f;
+    int src = -1; float scale = 1.f; bool is_time_row = false;
     if (j < g.out_len) {
-        if (j < 2 * nW) { const int b = j >= nW, jj = j - b * nW, r = jj / d; src = b * rT + r * RS + (jj - r * d); if (r == 0) scale = g.t; }
-        else if (j < oBf) { const int jj = j - 2 * nW, r = jj / g.nl; src = rL + r * RSL + (jj - r * g.nl); if (r == 0) scale = g.t; }
+        if (j < 2 * nW) { const int b = j >= nW, jj = j - b * nW, r = jj / d; src = b * rT + r * RS + (jj - r * d); if (r == 0) { scale = g.t; is_time_row = true; } }
+        else if (j < oBf) { const int jj = j - 2 * nW, r = jj / g.nl; src = rL + r * RSL + (jj - r * g.nl); if (r == 0) { scale = g.t; is_time_row = true; } }
         else if (j < oBw) src = rT + (j - oBf);                          // bf = colsum(dPt): the time row of the Wtgt block
         else if (j < oGm) src = rL + 2 * (j - oBw) + 1;                  // bw_h = colsum(dA2)[2h + 1]
         else src = rG + (j - oGm);                                       // dgamma | dbeta
     } else if (j == g.out_len) src = g.plen - 1;                         // a_t'
-    float v = 0.f;
-    if (src >= 0) {
-        for (int p0 = qq; p0 < g.n_part; p0 += 32 * 16) {       // 16 independent loads in flight per thread
-            float x[16];
+    const int n_rounds = g.n_slots > 0 ? g.n_slots : 1;
+    float total = 0.f;
+    for (int sl = 0; sl < n_rounds; ++sl) {
+        const float* part = g.part + (int64_t)sl * g.n_part * g.plen;
+        float v = 0.f;
+        if (src >= 0) {
+            for (int p0 = qq; p0 < g.n_part; p0 += 32 * 16) {       // 16 independent loads in flight per thread
+                float x[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int p = p0 + 32 * u;
-                x[u] = p < g.n_part ? g.part[(int64_t)p * g.plen + src] : 0.f;
+                for (int u = 0; u < 16; ++u) {
+                    const int p = p0 + 32 * u;
+                    x[u] = p < g.n_part ? part[(int64_t)p * g.plen + src] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v += x[u];
             }
+        }
+        __syncthreads();                                             // the previous round's sums have been read
+        sm[qq][jj] = v;
+        __syncthreads();
+        if (qq == 0 && src >= 0) {
+            float tsum = sm[0][jj];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v += x[u];
+            for (int k = 1; k < 32; ++k) tsum += sm[k][jj];
+            if (g.n_slots > 0) {
+                const float sc = (j < g.out_len && is_time_row) ? g.ts[sl] : 1.f;
+                total = fmaf(g.w[sl], sc * tsum, total);
+            } else {
+                total = (j < g.out_len ? scale : 1.f) * tsum;
+            }
         }
     }
-    sm[qq][jj] = v;
-    __syncthreads();
     if (qq == 0 && src >= 0) {
-        float tsum = sm[0][jj];
-#pragma unroll
-        for (int k = 1; k < 32; ++k) tsum += sm[k][jj];
-        if (j < g.out_len) g.ktheta[j] = scale * tsum;
-        else *g.kat = tsum;
+        if (g.n_slots > 0) {
+            if (j < g.out_len) g.ktheta[j] += total; else *g.kat += total;
+        } else {
+            if (j < g.out_len) g.ktheta[j] = total; else *g.kat = total;
+        }
     }
 }
 
@@ -578,7 +599,29 @@ extern "C" int gode_gat_small_finish_f32(const float* part, int64_t n_rows, int6
     g.part = part; g.n_part = (int)gode_gat_small_parts(n_rows, d); g.plen = (int)gode_gat_small_part_len(d, heads);
     g.d = (int)d; g.nl = (int)(2 * heads); g.nlp = g.nl <= 4 ? 4 : 16; g.heads = (int)heads;
     g.out_len = (int)(2 * (d + 1) * d + (d + 1) * 2 * heads + d + heads + 2 * d);
-    g.t = t; g.ktheta = ktheta; g.kat = kat;
+    g.t = t; g.ktheta = ktheta; g.kat = kat; g.n_slots = 0;
+    for (int q = 0; q < 4; ++q) { g.ts[q] = 0.f; g.w[q] = 0.f; }
+    const int blocks = (g.out_len + 1 + 31) / 32;
+    hipLaunchKernelGGL(gat_small_finish_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, g);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same for the stages of one fixed-grid Runge-Kutta step at once: theta += sum_s w[s] k_theta(stage s), a_t likewise,
+// from n_slots <= 4 partial buffers laid out one after the other (each gode_gat_small_parts x gode_gat_small_part_len floats).
+extern "C" int gode_gat_small_finish_step_f32(const float* part, int64_t n_rows, int64_t d, int64_t heads, int32_t n_slots,
+                                              const float* ts /* host */, const float* w /* host */, float* theta, float* at,
+                                              void* stream)
+{
+    if (heads < 1) heads = 1;
+    if (!part || !theta || !at || !ts || !w) return GODE_E_NULLPTR;
+    if (n_rows <= 0 || n_rows > 65536 || d <= 0 || heads > 8 || n_slots < 1 || n_slots > 4) return GODE_E_SHAPE;
+    GatFinish g;
+    g.part = part; g.n_part = (int)gode_gat_small_parts(n_rows, d); g.plen = (int)gode_gat_small_part_len(d, heads);
+    g.d = (int)d; g.nl = (int)(2 * heads); g.nlp = g.nl <= 4 ? 4 : 16; g.heads = (int)heads;
+    g.out_len = (int)(2 * (d + 1) * d + (d + 1) * 2 * heads + d + heads + 2 * d);
+    g.t = 0.f; g.ktheta = theta; g.kat = at; g.n_slots = n_slots;
+    for (int q = 0; q < 4; ++q) { g.ts[q] = q < n_slots ? ts[q] : 0.f; g.w[q] = q < n_slots ? w[q] : 0.f; }
     const int blocks = (g.out_len + 1 + 31) / 32;
     hipLaunchKernelGGL(gat_small_finish_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, g);
     GODE_LAUNCH_CHECK();

@@ -230,6 +230,7 @@ class _HeadsWork:
         self.colsum_scratch2 = torch.empty(max(lib.gode_colsum_scratch_bytes(n, 2 * H), 16), **u8)
         self.err_scratch = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), **u8)
         self.small_part = None
+        self.step_parts = None
         if not spec.pad_logits and lib.gode_gat_small_supported(n, d, spec.groups, H):
             self.small_part = ops.gat_small_part(n, d, H, device)
         if spec.pad_logits:
@@ -334,6 +335,12 @@ class GatHeadsAdjointField(GatHeadsField):
         self.ratio_groups = [[0], [1], [2], [3]]
 
     new_state = GatOdeAdjointField.new_state
+    # fixed-grid steps: the small components advance once per RK step (gat_ode.GatOdeAdjointField)
+    deferred_components = GatOdeAdjointField.deferred_components
+    DEFER_SMALL = True
+    begin_rk4_step = GatOdeAdjointField.begin_rk4_step
+    finish_rk4_step = GatOdeAdjointField.finish_rk4_step
+    _stage_part = GatOdeAdjointField._stage_part
 
     def _dopri5_step(self, y, kk, y1, t, h, rtol, atol):
         return GatOdeAdjointField.dopri5_step_native(self, y, kk, y1, t, h, rtol, atol)
@@ -361,11 +368,13 @@ class GatHeadsAdjointField(GatHeadsField):
                     raw_scratch=w.heads_scratch if self.raw_logits() else None, defer_maxpath=self.raw_logits())
         if self.small():
             # (on the raw-logit route the per-head max-path sums are taken off dA2 inside this launch)
+            part, deferred = self._stage_part(t)
             ops.gat_dense_vjp_small(xt, n, d, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, H, w.dPs, w.dPt, w.dA2,
-                                    out[1], w.small_part,
+                                    out[1], part,
                                     maxfix=(w.heads_scratch, eg.src, eg.tgt) if self.raw_logits() and eg.E > 0 else None,
                                     packed=s.Wpacked)
-            ops.gat_small_finish(w.small_part, n, d, H, t, out[3], out[2])
+            if not deferred:
+                ops.gat_small_finish(part, n, d, H, t, out[3], out[2])
             return
         from .gat_ode import MERGED_FINISH_MAX_ROWS
         merged = n <= MERGED_FINISH_MAX_ROWS and s.groups > 0 and not s.pad_logits      # one reduction launch per stage

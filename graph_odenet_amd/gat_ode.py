@@ -119,6 +119,7 @@ class _Work:
         self.err_scratch = torch.empty(lib.gode_rk_errnorm_scratch_bytes(), **u8)
         # launch-bound graphs: block partials of the one-launch dense VJP (csrc/gat_small.hip)
         self.small_part = ops.gat_small_part(n, o, 1, device) if lib.gode_gat_small_supported(n, o, spec.groups, 1) else None
+        self.step_parts = None                 # four such buffers, one per stage of a fixed-grid step (allocated on first use)
 
 
 class GatOdeField(Field):
@@ -243,6 +244,36 @@ class GatOdeAdjointField(GatOdeField):
             "gode_gat_ode_dopri5_step_adjoint")
         return sums
 
+    # ---- fixed-grid steps on launch-bound graphs: the small components (a_t, theta) are advanced once per RK step ----
+    deferred_components = (2, 3)
+    DEFER_SMALL = True            # False: every stage closes its own partials (round 3)
+
+    def begin_rk4_step(self):
+        if not (self.DEFER_SMALL and self.small()):
+            self._slots = None
+            return False
+        w = self.w
+        if w.step_parts is None:
+            w.step_parts = torch.empty(4 * w.small_part.numel(), dtype=torch.float32, device=w.small_part.device)
+        self._slots = []              # evaluation times of the stages seen so far in this step
+        return True
+
+    def finish_rk4_step(self, weights, y):
+        s, ts = self.s, self._slots
+        self._slots = None
+        ops.gat_small_finish_step(self.w.step_parts, s.n, s.d, self.heads, ts, weights[:len(ts)], y[3], y[2])
+        return self.deferred_components
+
+    def _stage_part(self, t):
+        """Partial buffer of the stage being evaluated, and whether its closing launch is deferred to the end of the step."""
+        slots = getattr(self, "_slots", None)
+        if slots is None:
+            return self.w.small_part, False
+        k = len(slots)
+        slots.append(t)
+        n = self.w.small_part.numel()
+        return self.w.step_parts[k * n:(k + 1) * n], True
+
     def eval(self, t, terms, out):
         s, w = self.s, self.w
         eg, n, o = s.eg, s.n, s.d
@@ -253,9 +284,11 @@ class GatOdeAdjointField(GatOdeField):
                     cot_terms=terms[1], cot_scale=-1.0)
         if self.small():
             # launch-bound graphs: k_a and the partials of every parameter gradient in one launch, one more to close
+            part, deferred = self._stage_part(t)
             ops.gat_dense_vjp_small(xt, n, o, s.groups, s.eps_gn, s.gamma, s.beta, s.Wsrc, s.Wtgt, s.Wlog, 1, w.dPs, w.dPt, w.dA2,
-                                    out[1], w.small_part, packed=s.Wpacked)
-            ops.gat_small_finish(w.small_part, n, o, 1, t, out[3], out[2])
+                                    out[1], part, packed=s.Wpacked)
+            if not deferred:
+                ops.gat_small_finish(part, n, o, 1, t, out[3], out[2])
             return
         # bias gradients: sum over edges of dz / da = sum over nodes of the per-target sums just formed (every edge has
         # exactly one target) - N rows instead of E

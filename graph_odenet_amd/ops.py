@@ -293,6 +293,20 @@ def gat_small_finish(part, n_rows, d, heads, t, ktheta, kat):
           "gode_gat_small_finish_f32")
 
 
+def gat_small_finish_step(parts, n_rows, d, heads, ts, ws, theta, at):
+    """theta += sum_s ws[s] * k_theta(stage s), at likewise, from the partial buffers of the len(ts) <= 4 stages of one
+    fixed-grid RK step laid out one after the other in `parts` (csrc/gat_small.hip: one closing launch per STEP)."""
+    lib = _lib.load()
+    _need(parts, "parts"); _need(theta, "theta"); _need(at, "a_t")
+    k = len(ts)
+    if parts.numel() < k * lib.gode_gat_small_parts(n_rows, d) * lib.gode_gat_small_part_len(d, heads) or \
+            theta.numel() != lib.gode_gat_ode_theta_len_heads(d, heads) or at.numel() != 1:
+        raise ValueError("gat_small_finish_step: buffers have wrong size")
+    tsa, wsa = (ctypes.c_float * 4)(*([float(v) for v in ts] + [0.0] * (4 - k))), (ctypes.c_float * 4)(*([float(v) for v in ws] + [0.0] * (4 - k)))
+    check(lib.gode_gat_small_finish_step_f32(ptr(parts), n_rows, d, heads, k, tsa, wsa, ptr(theta), ptr(at), stream_ptr()),
+          "gode_gat_small_finish_step_f32")
+
+
 def gn_time_gemm_bwd(x_terms, n_rows, d_in, groups, eps, gamma, W, has_time, dS, out_scale=1.0, out=None,
                      want_affine_grads=True, pre_terms=None, parts=None):
     """Returns (dx, dgamma_part, dbeta_part); parts are [n_part, d_in] block partials (or None).

@@ -102,8 +102,14 @@ def integrate_rk4(field, y, t0, t1, n_steps, work=None):
     nfe = 0
     nc = len(y)
     fused = getattr(field, "eval_combine", None)
+    # a field may keep the stage derivatives of its SMALL components (a_t, parameter gradients: the adjoint ODE is linear
+    # in them and no stage input reads them) as block partials and close the four stages of a step with ONE launch that
+    # adds h * sum_s b_s k_s to the solution (gat_ode / gat_heads on launch-bound graphs): begin_rk4_step() before the
+    # stages, finish_rk4_step(weights, y) after them returns the components it has advanced
+    begin, finish = getattr(field, "begin_rk4_step", None), getattr(field, "finish_rk4_step", None)
     for i in range(n_steps):
         t = t0 + i * h
+        deferred = begin is not None and begin()
         for s in range(3):
             field.eval(t + RK38_C[s] * h, _stage_terms(y, ks, RK38_A[s], h), ks[s])
         done = ()
@@ -113,9 +119,13 @@ def integrate_rk4(field, y, t0, t1, n_steps, work=None):
         else:
             field.eval(t + RK38_C[3] * h, _stage_terms(y, ks, RK38_A[3], h), ks[3])
         nfe += 4
+        if deferred:
+            done = tuple(done) + tuple(finish([h * b for b in RK38_B], y))
         todo = []
         for c in range(nc):
             if c in done:
+                if deferred and c in field.deferred_components:
+                    continue                           # advanced in place by finish_rk4_step
                 y[c], ks[3][c] = ks[3][c], y[c]        # ks[3][c] already holds the new solution
             else:
                 todo.append(c)

@@ -602,6 +602,12 @@ int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n_rows, int6
                                  const float* packed /* nullable: gode_gat_small_pack_f32 */, void* stream);
 int gode_gat_small_finish_f32(const float* part, int64_t n_rows, int64_t d, int64_t heads, float t, float* ktheta,
                               float* kat, void* stream);
+/* The closing launches of the n_slots <= 4 stages of ONE fixed-grid Runge-Kutta step as one: theta += sum_s w[s] k_theta(s),
+ * a_t += sum_s w[s] k_at(s), stage s evaluated at ts[s], its partials at part + s * parts * part_len (round 4: the small
+ * components of the adjoint state are linear in the ODE and never read inside a fixed-grid step). */
+int gode_gat_small_finish_step_f32(const float* part, int64_t n_rows, int64_t d, int64_t heads, int32_t n_slots,
+                                   const float* ts /* host */, const float* w /* host */, float* theta, float* at,
+                                   void* stream);
 /* The LDS images of [Wsrc | Wtgt | Wlog] both kernels stage (row-major with padded logit columns for project, transposed
  * without the time row for dense_vjp), formed once per solve - the weights do not change inside one - so that staging is
  * a straight 16-byte copy: packed holds gode_gat_small_pack_len(d, heads) floats.  Passing NULL for `packed` makes the
