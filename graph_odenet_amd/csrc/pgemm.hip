@@ -201,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
 #pragma unroll
     for (int j = 0; j < NJ; ++j) Operand<B_KC>::read_offsets(wn + 16 * j, lane, bo[j][0], bo[j][1]);
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= (WM * WN) / 2;       // wave-uniform by construction
 
     // k-steps of this block: slice ks of ksplit (ksplit > 1: few tiles - the blocks of a tile split the contraction and
     // write raw partial sums to the workspace, finished by pgemm_finish_kernel)
@@ -217,7 +218,10 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
         // ... and after the barrier everybody's has, and everybody has finished reading step kt - 1, whose buffer the
         // DMAs of step kt + 2 may now overwrite
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue((kt + 2) % STAGES, kt + 2);
+        // The two waves of a SIMD (w and w + 4) leave the barrier together and would spend the same ~600 cycles issuing
+        // their six DMAs while the matrix pipe idles (counters, profiles/r04_pgemm_pmc.txt: pipe busy 51 % of the launch).
+        // Waves 0-3 issue theirs now, waves 4-7 after the MFMAs of their second slice: the partner multiplies meanwhile.
+        if (!late && kt + 2 < nk) issue((kt + 2) % STAGES, kt + 2);
         const unsigned st = lds_base + (kt % STAGES) * STAGE_B;
         bf16x8_t a[MI][3], b[NJ][3];
         // operand reads run one 16-row slice of A ahead of the MFMAs: all of B and slice 0, then slice i + 1 is requested
@@ -255,6 +259,10 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            if (late && i == MI / 2 - 1 && kt + 2 < nk) {
+                issue((kt + 2) % STAGES, kt + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 

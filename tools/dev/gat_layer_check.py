@@ -1,3 +1,4 @@
+"""One GAT layer (o = 16 / 64 / 128) against the fp64 oracle on an edge list with a hub (cited by tests/test_gpu_gat_qc.py)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

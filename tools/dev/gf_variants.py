@@ -1,3 +1,4 @@
+"""C5 decomposition of the dense product: bare product, + time row, + GroupNorm, forward and VJP (HISTORY.md, dense kernels)."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

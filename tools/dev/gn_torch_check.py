@@ -1,3 +1,4 @@
+"""torch 2.10.0+rocm7.0 F.group_norm backward on 2-D input: CPU vs GPU dgamma / dbeta (cited by functional.py; HISTORY.md)."""
 import torch, torch.nn.functional as F
 torch.manual_seed(0)
 for n, c, g in ((3327, 128, 32), (120, 64, 32), (257, 16, 16), (3327, 129, 1)):

@@ -1,3 +1,4 @@
+"""Row-partitioned solve: two node orders on ONE GPU differ by the same rounding amounts as two ranks (cited by tests/test_gpu_partition.py)."""
 import os, sys
 import torch, torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,4 @@
+"""Row-partitioned solve: gradient differences rank-count 1 vs 2 at tol 1e-4 vs 1e-6 (HISTORY.md, partition section)."""
 import os, sys
 import torch, torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
