@@ -24,7 +24,7 @@ class LinComb(ctypes.Structure):
 class SpmmEpilogue(ctypes.Structure):
     """Mirror of gode_spmm_epilogue_t."""
     _fields_ = [("bias", ctypes.c_void_p), ("relu", ctypes.c_int32), ("alpha", ctypes.c_float),
-                ("pre", LinComb), ("cot", LinComb), ("Y2", ctypes.c_void_p)]
+                ("pre", LinComb), ("cot", LinComb), ("Y2", ctypes.c_void_p), ("Y2_colsum", ctypes.c_void_p)]
 
 
 class Graph(ctypes.Structure):
@@ -53,7 +53,8 @@ class Rk4Workspace(ctypes.Structure):
     _fields_ = [("S", ctypes.c_void_p), ("dZ", ctypes.c_void_p), ("dS", ctypes.c_void_p), ("S2", ctypes.c_void_p),
                 ("ky", ctypes.c_void_p * 4), ("ka", ctypes.c_void_p * 4), ("ktheta", ctypes.c_void_p * 4),
                 ("wpart", ctypes.c_void_p), ("gpart", ctypes.c_void_p), ("bpart", ctypes.c_void_p),
-                ("colsum_scratch", ctypes.c_void_p), ("X", ctypes.c_void_p * 2), ("small_part", ctypes.c_void_p)]
+                ("colsum_scratch", ctypes.c_void_p), ("X", ctypes.c_void_p * 2), ("small_part", ctypes.c_void_p),
+                ("y2_colsum", ctypes.c_void_p)]
 
 
 class ReduceSeg(ctypes.Structure):
@@ -168,6 +169,7 @@ SIGNATURES = {
     "gode_reduce_segments_f32": (c_i, [ctypes.POINTER(ReduceSeg), ctypes.c_int32, c_f, c_p, c_p]),
     "gode_colsum_parts_f32": (c_i, [c_p, c_i64, c_i64, c_p, ctypes.POINTER(c_i64), c_p]),
     "gode_colsum_scratch_bytes": (c_i64, [c_i64, c_i64]),
+    "gode_spmm_y2_colsum_rows": (c_i64, [c_i64, c_i64, c_i64]),
     "gode_colsum_f32": (c_i, [c_p, c_p, c_i64, c_i64, c_f, c_i, c_p, c_p]),
     "gode_gat_logits_scratch_bytes": (c_i64, [c_i64]),
     "gode_gat_logits_f32": (c_i, [ctypes.POINTER(GatProj), c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),

@@ -6,7 +6,7 @@
 // ops each conversion is a stable sort, a count, a prefix sum and a handful of casts - ~14 launches, ~40 per batch,
 // more GPU time than the message round they prepare.  Here one workgroup does a conversion: counts by LDS integer
 // atomics (exact, order-free), a block-wide exclusive scan, and the stable position of every entry from its rank among
-// the earlier entries of the same row (a quadratic scan over LDS: 290 K comparisons for 760 edges).
+// the earlier entries of the same row (a quadratic scan over LDS, sixteen entries per step: 290 K comparisons for 760 edges).
 // Limits: n_entries <= 2048, n_rows <= 4096; larger matrices take the sort-based path (graph.csr_from_assignment).
 #include "common.h"
 
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(NT) void assign_csr_kernel(const int64_t* __restric
                                                         int32_t* __restrict__ rowptr, int32_t* __restrict__ order,
                                                         const float* __restrict__ vals, float* __restrict__ vals_out)
 {
-    __shared__ int idx[kMaxEntries];
+    __shared__ __attribute__((aligned(16))) int idx[kMaxEntries];
     __shared__ int cnt[kMaxRows + 1];
     __shared__ int wsum[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -56,8 +56,17 @@ __global__ __launch_bounds__(NT) void assign_csr_kernel(const int64_t* __restric
     for (int e = tid; e < E; e += NT) {
         const int r = idx[e];
         if (r < 0) continue;
+        // sixteen entries per iteration from four independent 16-byte LDS reads (all lanes read the same address: a
+        // broadcast): one entry per iteration was a chain of ~800 LDS round trips, 15 of the launch's 22 us
         int rank = 0;
-        for (int k = 0; k < e; ++k) rank += (idx[k] == r);
+        const int e16 = e & ~15;
+        for (int k = 0; k < e16; k += 16) {
+            const int4 a = *reinterpret_cast<const int4*>(idx + k), b = *reinterpret_cast<const int4*>(idx + k + 4);
+            const int4 c2 = *reinterpret_cast<const int4*>(idx + k + 8), d2 = *reinterpret_cast<const int4*>(idx + k + 12);
+            rank += (a.x == r) + (a.y == r) + (a.z == r) + (a.w == r) + (b.x == r) + (b.y == r) + (b.z == r) + (b.w == r);
+            rank += (c2.x == r) + (c2.y == r) + (c2.z == r) + (c2.w == r) + (d2.x == r) + (d2.y == r) + (d2.z == r) + (d2.w == r);
+        }
+        for (int k = e16; k < e; ++k) rank += (idx[k] == r);
         const int pos = cnt[r] + rank;
         order[pos] = e;
         if (vals_out) vals_out[pos] = vals ? vals[e] : 1.f;

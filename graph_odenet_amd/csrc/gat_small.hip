@@ -403,6 +403,172 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
     for (int i = threadIdx.x; i < PLENP; i += 256) out[i] = red[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// d = 64: the same launch on the fp32 matrix instruction.  The kernel above gives a wave a ROW at a time - a chain of
+// global load -> LDS -> 144 x 64 multiply-adds -> shuffles per row, three rows per wave on Citeseer, then a four-phase
+// block reduction of 9 700 partial sums: 29 us per adjoint stage, 23 % of the 8-head training step's kernel time
+// (profiles/r04_gat_citeseer_kernel_stats.txt).  Here a block owns TILES of 16 rows and both products are MFMA tiles
+// (v_mfma_f32_16x16x4_f32: exact fp32 multiply-adds, fixed order):
+//     dY (16 x 64)   = G (16 x NIN) . W^T (NIN x 64)            4 waves x 1 column tile, NIN / 4 k-steps
+//     dW (65 x NIN)  = [xn | 1]^T (65 x 16) . G (16 x NIN)      45 tiles of 16 x 16 (the ones row gives the column sums), 4 k-steps
+// with G = [dPs | dPt | dA2] staged in LDS (odd row stride: conflict-free as either operand), the weights' transposed
+// image read straight from L2 into the B operand (once per block), GroupNorm backward row-wise between the two.  The
+// partial row has the layout of the kernel above (gat_small_finish_kernel is shared); a block writes it from the
+// accumulators, no reduction phase.
+template <int CG, int NLP>
+__global__ __launch_bounds__(256) void gat_dense_vjp_d64_kernel(LinComb xin, int n_rows, float eps,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ Wsrc, const float* __restrict__ Wtgt,
+                                                               const float* __restrict__ Wlog, int nl,
+                                                               const float* __restrict__ dPs, const float* __restrict__ dPt,
+                                                               const float* __restrict__ dA2, float out_scale, LinComb pre,
+                                                               float* __restrict__ ka, float* __restrict__ part, MaxFix mf,
+                                                               const float* __restrict__ packed_t)
+{
+    constexpr int D = 64, R = 16, NIN = 2 * D + NLP, KS = NIN / 4, NT = 9, MT = 5;
+    constexpr int GS = 145, XS = 80, YS = 68;                    // LDS row strides (floats): G, xn, dY
+    using S = GatVjpShape<D, NLP>;
+    __shared__ __attribute__((aligned(16))) float Gs[R * GS];
+    __shared__ __attribute__((aligned(16))) float Xs[R * XS];
+    __shared__ __attribute__((aligned(16))) float Ys[R * YS];
+    __shared__ __attribute__((aligned(16))) float Pg[2][R][D];   // dy * xhat, dy: summed over the tile's rows below
+    __shared__ float valid[R], at_w[4];
+    __shared__ float mpT[8];
+    __shared__ int mpS[8], mpD[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+    const int r = threadIdx.x >> 4, q = threadIdx.x & 15;        // row-wise phases: thread (r, q) holds columns 4 q .. 4 q + 3 of row r
+    if (threadIdx.x < 8) {
+        float tsum = 0.f; int f = INT32_MAX;
+        if (mf.psum && (int)threadIdx.x < mf.H)
+            for (int b = 0; b < mf.n_part; ++b) { tsum += mf.psum[b * mf.H + threadIdx.x]; f = min(f, mf.pidx[b * mf.H + threadIdx.x]); }
+        const bool hit = mf.psum && f < mf.n_edges;
+        mpT[threadIdx.x] = hit ? tsum : 0.f;
+        mpS[threadIdx.x] = hit ? mf.esrc[f] / mf.H : -1;
+        mpD[threadIdx.x] = hit ? mf.etgt[f] / mf.H : -1;
+    }
+    for (int i = threadIdx.x; i < R * GS; i += 256) Gs[i] = 0.f;             // columns NIN .. 143 stay zero
+    // B operand of dY, once per block: W^T[c][k] for the wave's 16 output columns k = 16 wave + rl, rows c = 4 ks + g
+    float wt[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wt[ks] = packed_t[(4 * ks + g) * (D + 4) + 16 * wave + rl];
+    const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_l = 4 * q < NLP;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 acc[3][MT];                                            // dW tiles (mt, nt = wave + 4 u)
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[u][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dgb = 0.f;                                             // threads 0-63: dgamma[tid], 64-127: dbeta[tid - 64]
+    const int n_tiles = (n_rows + R - 1) / R;
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row = tile * R + r;
+        const bool ok = row < n_rows;
+        const int64_t o = (int64_t)(ok ? row : 0) * D + 4 * q;
+        float4 gs = ld4(dPs + o), gt = ld4(dPt + o), x = lc_load4(xin, o);
+        float4 gl = has_l ? load_logit4(dA2 + (int64_t)(ok ? row : 0) * nl, 4 * q, nl) : zero4;
+        if (!ok) { gs = zero4; gt = zero4; gl = zero4; x = zero4; }
+        if (mf.psum && has_l && ok) {                            // max-path fix of this row's logit cotangents (see MaxFix)
+            float gv[4] = {gl.x, gl.y, gl.z, gl.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int c = 4 * q + a, h = (c >> 1) & 7;
+                if (c < nl && row == ((c & 1) ? mpD[h] : mpS[h])) gv[a] -= mpT[h];
+            }
+            gl = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        }
+        float4 xn = gn_forward_v<CG>(x, eps, gm, bt);
+        if (!ok) xn = zero4;
+        {
+            float* gr = Gs + r * GS + 4 * q;                     // odd stride: scalar stores
+            gr[0] = gs.x; gr[1] = gs.y; gr[2] = gs.z; gr[3] = gs.w;
+            gr[D] = gt.x; gr[D + 1] = gt.y; gr[D + 2] = gt.z; gr[D + 3] = gt.w;
+            if (has_l) { gr[2 * D] = gl.x; gr[2 * D + 1] = gl.y; gr[2 * D + 2] = gl.z; gr[2 * D + 3] = gl.w; }
+            *reinterpret_cast<float4*>(Xs + r * XS + 4 * q) = xn;
+            if (q == 0) valid[r] = ok ? 1.f : 0.f;
+        }
+        __syncthreads();
+        // dY: A[i = rl][k = g] = G[rl][4 ks + g]
+        {
+            f32x4 dyacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(Gs[rl * GS + 4 * ks + g], wt[ks], dyacc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ys[(4 * g + e) * YS + 16 * wave + rl] = dyacc[e];
+        }
+        __syncthreads();
+        {
+            const float4 dy = *reinterpret_cast<const float4*>(Ys + r * YS + 4 * q);
+            float4 xh;
+            const float4 dx = gn_backward4<CG>(x, dy, gm, eps, xh);
+            if (ok) {
+                float4 out = make_float4(out_scale * dx.x, out_scale * dx.y, out_scale * dx.z, out_scale * dx.w);
+                if (pre.n > 0) add4(out, lc_load4(pre, o));
+                *reinterpret_cast<float4*>(ka + o) = out;
+            }
+            *reinterpret_cast<float4*>(&Pg[0][r][4 * q]) = make_float4(dy.x * xh.x, dy.y * xh.y, dy.z * xh.z, dy.w * xh.w);
+            *reinterpret_cast<float4*>(&Pg[1][r][4 * q]) = dy;
+        }
+        // dW: A[i = rl][k = g] = [xn | 1][4 ks + g][16 mt + rl],  B[k = g][j = rl] = G[4 ks + g][16 nt + rl]
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int nt = wave + 4 * u;
+            if (nt < NT) {                                       // wave-uniform
+                float bv[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) bv[ks] = Gs[(4 * ks + g) * GS + 16 * nt + rl];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const float av = mt < 4 ? Xs[(4 * ks + g) * XS + 16 * mt + rl] : (rl == 0 ? valid[4 * ks + g] : 0.f);
+                        acc[u][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[ks], acc[u][mt], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * D) {
+            const int which = threadIdx.x >> 6, m = threadIdx.x & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) sum += Pg[which][rr][m];
+            dgb += sum;
+        }
+        // (the next tile's LDS stores follow a barrier: every read of this tile is above the last one)
+    }
+    // the partial row, in the layout of gat_dense_vjp_small_kernel's block reduction
+    constexpr int RS = S::RS, RSL = S::RSL, rT = (D + 1) * RS, rL = 2 * rT, rG = rL + (D + 1) * RSL, rA = rG + 2 * D;
+    float* out = part + (int64_t)blockIdx.x * S::PMAX;
+    float at_share = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int nt = wave + 4 * u;
+        if (nt >= NT) continue;
+        const int c = 16 * nt + rl;                              // column of [dPs | dPt | dA2]
+        float* blk = nt < 4 ? out : (nt < 8 ? out + rT : out + rL);
+        const int cc = nt < 4 ? c : (nt < 8 ? c - D : c - 2 * D), stride = nt < 8 ? RS : RSL;
+        const bool col_ok = nt < 8 || cc < NLP;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col_ok) blk[(1 + 16 * mt + 4 * g + e) * stride + cc] = acc[u][mt][e];
+        if (g == 0) {                                            // row 64 of the A operand was the ones row: column sums
+            const float cs = acc[u][4][0];
+            if (col_ok) blk[cc] = cs;
+            const float w0 = nt < 4 ? Wsrc[cc] : (nt < 8 ? Wtgt[cc] : (cc < nl ? Wlog[cc] : 0.f));
+            at_share = fmaf(cs, w0, at_share);
+        }
+    }
+    if (threadIdx.x < 2 * D) out[rG + threadIdx.x] = dgb;        // dgamma | dbeta are contiguous
+    at_share = wave_sum(at_share);
+    if (lane == 0) at_w[wave] = at_share;
+    __syncthreads();
+    if (threadIdx.x == 0) out[rA] = (at_w[0] + at_w[1]) + (at_w[2] + at_w[3]);
+}
+
 // k_theta = [Wsrc | Wtgt | Wlog | bf | bw | gamma | beta] (time rows scaled by t) and k_a_t from the block partials:
 // 1 024 threads = 32 part-groups x 32 outputs, 16 loads per thread in flight together (512 partial rows: one round).
 struct GatFinish {
@@ -490,7 +656,7 @@ extern "C" int gode_gat_small_supported(int64_t n_rows, int64_t d, int32_t group
 // fewer blocks.  Measured at d = 64 (Citeseer, 8 heads, training step): 64 / 128 / 256 / 512 blocks 11.2 / 10.2 / 9.8 /
 // 11.0 ms (512 blocks write and re-read 19 MB per stage).
 extern "C" int64_t gode_gat_small_parts(int64_t n_rows, int64_t d) {
-    int64_t b = (n_rows + 3) / 4;
+    int64_t b = d == 64 ? (n_rows + 15) / 16 : (n_rows + 3) / 4;          // d = 64: a block per tile of 16 rows
     const int64_t cap = d <= 16 ? kGatPartBlocks : kGatPartBlocks / 2;
     if (b < 1) b = 1;
     if (b > cap) b = cap;
@@ -581,6 +747,15 @@ extern "C" int gode_gat_dense_vjp_small_f32(const gode_lincomb_t* xin, int64_t n
     if (((uintptr_t)packed) & 15) return GODE_E_ALIGN;
     const float* packed_t = packed ? packed + (d + 1) * (2 * d + nlp) : nullptr;      // the transposed image follows Wall
     const dim3 grid((unsigned)gode_gat_small_parts(n_rows, d));
+    if (d == 64 && packed_t) {                                   // tiles of 16 rows on the matrix instruction
+#define GODE_GV64(CGV, NLV) hipLaunchKernelGGL((gat_dense_vjp_d64_kernel<CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                               lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, dPs, dPt, dA2, out_scale, lp, ka, part, mf, packed_t);
+        if (nlp == 4) { if (cg == 1) { GODE_GV64(1, 4) } else if (cg == 2) { GODE_GV64(2, 4) } else { GODE_GV64(4, 4) } }
+        else { if (cg == 1) { GODE_GV64(1, 16) } else if (cg == 2) { GODE_GV64(2, 16) } else { GODE_GV64(4, 16) } }
+#undef GODE_GV64
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
 #define GODE_GVJ(DV, CGV, NLV) hipLaunchKernelGGL((gat_dense_vjp_small_kernel<DV, CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                   lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, dPs, dPt, dA2, out_scale, lp, ka, part, mf, packed_t);
     GODE_GATS_DISPATCH(GODE_GVJ)

@@ -239,6 +239,11 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
         ep.cot = ain;
         for (int j = 0; j < ep.cot.n; ++j) ep.cot.coef[j] = -ep.cot.coef[j];     // cotangent of the VJP is -a
         ep.Y2 = ws->dZ;
+        // colsum(dZ), the bias gradient of the stage: from the per-block column sums Sp(g) leaves in ws->y2_colsum (1/8 of
+        // dZ's bytes) when the workspace has them and the graph runs on the kernels that form them
+        const int64_t y2rows = (bw && ws->y2_colsum)
+            ? gode_spmm_y2_colsum_rows(f->A.items ? f->A.n_items : f->A.n_rows, f->A.items ? f->A.n_long : 0, d) : 0;
+        if (y2rows > 0) ep.Y2_colsum = ws->y2_colsum;
         gode_lincomb_t apre; apre.n = 0;
         if (s == 3) { ep.pre = combine_terms(ycur, ky, h); ep.alpha = (float)(h * B38[3]); apre = combine_terms(acur, ka, h); }
         if (two && g > 0) GODE_HIP(hipStreamWaitEvent(hs, ov->gf, 0));          // S of this stage was produced on the side stream
@@ -258,7 +263,8 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
             // forward block do not share a CU anyway); the small reductions of the stage run on the side stream beside
             // them: colsum(dZ) as soon as SpT(g) is done, the partial sums once the dense launch is
             if (two) GODE_HIP(hipStreamWaitEvent(ov->side, ov->spt, 0));
-            GODE_TRY(gode_colsum_f32(kt + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, side));
+            if (y2rows > 0) GODE_TRY(gode_colsum_f32(kt + nW, ws->y2_colsum, y2rows, d, 1.f, 0, ws->colsum_scratch, side));
+            else GODE_TRY(gode_colsum_f32(kt + nW, ws->dZ, n, d, 1.f, 0, ws->colsum_scratch, side));
             GODE_TRY(gode_gn_time_gemm_bwd_wgrad_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1, ws->dS,
                                                      s == 3 ? (float)(h * B38[3]) : 1.f, s == 3 ? &apre : nullptr, ka[s],
                                                      f->groups > 0 ? ws->gpart : nullptr, f->groups > 0 ? ws->bpart : nullptr,

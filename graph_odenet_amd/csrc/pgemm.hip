@@ -147,45 +147,108 @@ __device__ __forceinline__ void dma16(const short* src, lds_ptr lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- epilogues -------------------------------------------------------------------------------------------------------
+// D layout of v_mfma_f32_16x16x32_bf16: col = lane & 15, row = 4 (lane >> 4) + e.  Epilogue operands are loaded from
+// clamped coordinates (no load under a divergent branch); only the store is guarded.
+__device__ __forceinline__ void store_tile(const f32x4 (&v)[MI][NJ], int m0, int n0, int wm, int wn, int lane,
+                                           float* __restrict__ C, int64_t ldc, int M, int N, const float* __restrict__ bias,
+                                           int relu, const float* __restrict__ mask, int64_t ldmask)
+{
+    const bool has_bias = bias != nullptr, has_mask = mask != nullptr;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn + 16 * j + (lane & 15);
+        const int colc = col < N ? col : N - 1;
+        const float bv = has_bias ? bias[colc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rb = m0 + wm + 16 * i + 4 * (lane >> 4);
+            float mv[4] = {1.f, 1.f, 1.f, 1.f};
+            if (has_mask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rowc = rb + e < M ? rb + e : M - 1;
+                    mv[e] = mask[(int64_t)rowc * ldmask + colc];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[i][j][e] + bv;
+                if (relu) x = fmaxf(x, 0.f);
+                x = mv[e] > 0.f ? x : 0.f;
+                if (rb + e < M && col < N) C[(int64_t)(rb + e) * ldc + col] = x;
+            }
+        }
+    }
+}
+
+// A partial tile (a block that multiplied only part of a tile's contraction) in the workspace: raw sums in accumulator
+// order, 16 bytes per lane, lane-contiguous.  Slot 2 b + 0: the FIRST tile block b touched, slot 2 b + 1: its last.
+constexpr int64_t SLOT_F = (int64_t)TM * TN;     // floats per slot
+__device__ __forceinline__ f32x4* slot_ptr(float* ws, int64_t slot, int i, int j, int thread) {
+    return reinterpret_cast<f32x4*>(ws + slot * SLOT_F) + ((i * NJ + j) * 512 + thread);
+}
+
+// block of the launch whose share [W b / nwg, W (b + 1) / nwg) of the W = ntile * nk k-steps holds k-step x
+__device__ __forceinline__ int owner_of(int64_t x, int64_t W, int nwg) { return (int)(((x + 1) * nwg - 1) / W); }
+
 // C[M x N] = op(A) op(B) from piece planes.  A_KC: A stored [M][K] (else [K][M]);  B_KC: B stored [N][K] (else [K][N]).
-// lda / ldb: padded row lengths of the planes (elements); pa / pb: elements per plane.  Kp: padded K (multiple of 32).
-// PRODUCTS: 8, or 6 (mid*lo and lo*mid, 2^-24 of a product each, left out as well).
+// lda / ldb: padded row lengths of the planes (elements); pa / pb: elements per plane.  nk: k-steps of 32 (the planes are
+// zero beyond K).  PRODUCTS: 8, or 6 (mid*lo and lo*mid, 2^-24 of a product each, left out as well).
+//
+// Work division: the ntile * nk k-steps of the product, tiles in m-fastest order and k inside a tile, are dealt in equal
+// CONTIGUOUS shares to the gridDim.x blocks.  gridDim.x = ntile: a block per tile, the plain case.  gridDim.x = number of
+// CUs when the tiles do not fill whole rounds of the chip (294 tiles on 256 CUs: the second round is 85 % idle; 147
+// tiles: 43 % of the chip idle): every block then multiplies the same number of k-steps, a share may start and end in
+// the middle of a tile, whole tiles in between go straight to C and the (at most two) partial ones to workspace slots,
+// which pgemm_finish_kernel adds in block order - a fixed order, results do not depend on timing.  The LDS pipeline
+// runs through tile changes (the loads of the next tile's first steps are in flight during an epilogue).
 template <bool A_KC, bool B_KC, int PRODUCTS>
 __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__ Ap, int64_t lda, int64_t pa,
                                                        const short* __restrict__ Bp, int64_t ldb, int64_t pb,
-                                                       float* __restrict__ C, int64_t ldc, int M, int N, int Kp,
-                                                       int tiles_m, int tiles_n, int ksplit, float* __restrict__ ws,
+                                                       float* __restrict__ C, int64_t ldc, int M, int N, int nk,
+                                                       int tiles_m, int tiles_n, float* __restrict__ ws,
                                                        const float* __restrict__ bias, int relu,
                                                        const float* __restrict__ mask, int64_t ldmask)
 {
     extern __shared__ __attribute__((aligned(1024))) char lds_generic[];  // STAGES x 48 KB, the only LDS object
     lds_ptr const lds = (lds_ptr)lds_generic;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // tile of this block: ids are dealt to the XCDs round-robin by the hardware (b and b + 8 share an L2); renumber so
-    // that one XCD works on CONSECUTIVE tiles, m fastest: its blocks share the B panel of a column tile and re-use the
-    // A panels of all row tiles (speed only - any placement is correct)
-    const int ntile = tiles_m * tiles_n, nwg = ntile * ksplit, orig = blockIdx.x;
+    // share of this block: ids are dealt to the XCDs round-robin by the hardware (b and b + 8 share an L2); renumber so
+    // that one XCD works on CONSECUTIVE shares: its blocks share the B panel of a column tile and re-use the A panels of
+    // all row tiles (speed only - any placement is correct)
+    const int ntile = tiles_m * tiles_n, nwg = (int)gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int ks = wid / ntile, tid = wid - ks * ntile;           // k slice (slowest), tile
-    const int tn = tid / tiles_m, tm = tid - tn * tiles_m;
-    const int m0 = tm * TM, n0 = tn * TN;
+    const int64_t W = (int64_t)ntile * nk;
+    const bool per_tile = nwg == ntile;                            // (exact, and no 64-bit overflow for huge tile counts)
+    const int64_t f0 = per_tile ? (int64_t)wid * nk : W * wid / nwg;
+    const int n = per_tile ? nk : (int)(W * (wid + 1) / nwg - f0);  // k-steps of this block (block-uniform)
+    if (n <= 0) return;
     const int wm = (wave / WN) * (TM / WM), wn = (wave % WN) * (TN / WN);
 
-    // LDS-DMA sources: piece p of A / B, this lane's 16 bytes of the wave's 1 KB slice; advanced by k_step per k-step
-    const short* asrc = Ap + (A_KC ? (int64_t)m0 * lda : (int64_t)m0) + Operand<A_KC>::dma_src(wave, lane, lda);
-    const short* bsrc = Bp + (B_KC ? (int64_t)n0 * ldb : (int64_t)n0) + Operand<B_KC>::dma_src(wave, lane, ldb);
+    // LDS-DMA sources: piece p of A / B, this lane's 16 bytes of the wave's 1 KB slice; a cursor (tile it, k-step ik) runs
+    // two k-steps ahead of the multiplication and steps over tile ends
+    const int64_t adma = Operand<A_KC>::dma_src(wave, lane, lda), bdma = Operand<B_KC>::dma_src(wave, lane, ldb);
     const int64_t astep = Operand<A_KC>::k_step(lda), bstep = Operand<B_KC>::k_step(ldb);
     lds_ptr const wbase = lds + 1024 * wave;
-
-    auto issue = [&](int stage, int kt) {
+    int it = (int)(f0 / nk), ik = (int)(f0 - (int64_t)it * nk);
+    const short *ia, *ib;
+    auto seek = [&](int t, int k) {
+        const int tn = t / tiles_m, tm = t - tn * tiles_m;
+        ia = Ap + (A_KC ? (int64_t)tm * TM * lda : (int64_t)tm * TM) + adma + k * astep;
+        ib = Bp + (B_KC ? (int64_t)tn * TN * ldb : (int64_t)tn * TN) + bdma + k * bstep;
+    };
+    seek(it, ik);
+    auto issue = [&](int stage) {
         lds_ptr d = wbase + stage * STAGE_B;
-        const short* a = asrc + kt * astep;
-        const short* b = bsrc + kt * bstep;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dma16(a + p * pa, d + p * PIECE_B);
+        for (int p = 0; p < 3; ++p) dma16(ia + p * pa, d + p * PIECE_B);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dma16(b + p * pb, d + OPER_B + p * PIECE_B);
+        for (int p = 0; p < 3; ++p) dma16(ib + p * pb, d + OPER_B + p * PIECE_B);
+        ia += astep;
+        ib += bstep;
+        if (++ik == nk) { ik = 0; ++it; seek(it < ntile ? it : 0, 0); }       // no loads in this branch
     };
 
     f32x4 big[MI][NJ], small[MI][NJ];
@@ -203,26 +266,22 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
     const bool late = __builtin_amdgcn_readfirstlane(wave) >= (WM * WN) / 2;       // wave-uniform by construction
 
-    // k-steps of this block: slice ks of ksplit (ksplit > 1: few tiles - the blocks of a tile split the contraction and
-    // write raw partial sums to the workspace, finished by pgemm_finish_kernel)
-    const int nk_all = Kp / BK;
-    const int kt_lo = (int)((int64_t)nk_all * ks / ksplit), nk = (int)((int64_t)nk_all * (ks + 1) / ksplit) - kt_lo;
-    asrc += kt_lo * astep;
-    bsrc += kt_lo * bstep;
-    if (nk > 0) issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    for (int kt = 0; kt < nk; ++kt) {
-        // this wave's share of step kt has landed (the six DMAs of step kt + 1 may stay in flight) ...
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // the multiplication's cursor: tile ct, k-step ck, first k-step of this block in the tile k_lo, tiles seen so far seg
+    int ct = (int)(f0 / nk), ck = (int)(f0 - (int64_t)ct * nk), k_lo = ck, seg = 0;
+    issue(0);
+    if (n > 1) issue(1);
+    for (int s = 0; s < n; ++s) {
+        // this wave's share of step s has landed (the six DMAs of step s + 1 may stay in flight) ...
+        if (s + 1 < n) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and after the barrier everybody's has, and everybody has finished reading step kt - 1, whose buffer the
-        // DMAs of step kt + 2 may now overwrite
+        // ... and after the barrier everybody's has, and everybody has finished reading step s - 1, whose buffer the
+        // DMAs of step s + 2 may now overwrite
         __builtin_amdgcn_s_barrier();
         // The two waves of a SIMD (w and w + 4) leave the barrier together and would spend the same ~600 cycles issuing
         // their six DMAs while the matrix pipe idles (counters, profiles/r04_pgemm_pmc.txt: pipe busy 51 % of the launch).
         // Waves 0-3 issue theirs now, waves 4-7 after the MFMAs of their second slice: the partner multiplies meanwhile.
-        if (!late && kt + 2 < nk) issue((kt + 2) % STAGES, kt + 2);
-        const unsigned st = lds_base + (kt % STAGES) * STAGE_B;
+        if (!late && s + 2 < n) issue((s + 2) % STAGES);
+        const unsigned st = lds_base + (s % STAGES) * STAGE_B;
         bf16x8_t a[MI][3], b[NJ][3];
         // operand reads run one 16-row slice of A ahead of the MFMAs: all of B and slice 0, then slice i + 1 is requested
         // before the 16 MFMAs of slice i are issued
@@ -259,106 +318,117 @@ __global__ __launch_bounds__(512, 2) void pgemm_kernel(const short* __restrict__
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (late && i == MI / 2 - 1 && kt + 2 < nk) {
-                issue((kt + 2) % STAGES, kt + 2);
+            if (late && i == MI / 2 - 1 && s + 2 < n) {
+                issue((s + 2) % STAGES);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
-
-    // D layout of v_mfma_f32_16x16x32_bf16: col = lane & 15, row = 4 (lane >> 4) + e.  Epilogue operands are loaded from
-    // clamped coordinates (no load under a divergent branch); only the store is guarded.
-    if (ksplit > 1) {
-        float* w = ws + (int64_t)ks * M * N;
+        if (++ck < nk && s + 1 < n) continue;
+        // end of this block's part of tile ct: k-steps [k_lo, ck) of it
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int col = n0 + wn + 16 * j + (lane & 15);
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int rb = m0 + wm + 16 * i + 4 * (lane >> 4);
+            for (int j = 0; j < NJ; ++j) big[i][j] += small[i][j];
+        if (k_lo == 0 && ck == nk) {
+            const int tn = ct / tiles_m, tm = ct - tn * tiles_m;
+            store_tile(big, tm * TM, tn * TN, wm, wn, lane, C, ldc, M, N, bias, relu, mask, ldmask);
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (rb + e < M && col < N) w[(int64_t)(rb + e) * N + col] = big[i][j][e] + small[i][j][e];
-            }
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) *slot_ptr(ws, 2 * (int64_t)wid + (seg > 0), i, j, threadIdx.x) = big[i][j];
         }
-        return;
-    }
-    const bool has_bias = bias != nullptr, has_mask = mask != nullptr;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + wn + 16 * j + (lane & 15);
-        const int colc = col < N ? col : N - 1;
-        const float bv = has_bias ? bias[colc] : 0.f;
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int rb = m0 + wm + 16 * i + 4 * (lane >> 4);
-            float mv[4] = {1.f, 1.f, 1.f, 1.f};
-            if (has_mask) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int rowc = rb + e < M ? rb + e : M - 1;
-                    mv[e] = mask[(int64_t)rowc * ldmask + colc];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = (big[i][j][e] + small[i][j][e]) + bv;
-                if (relu) v = fmaxf(v, 0.f);
-                v = mv[e] > 0.f ? v : 0.f;
-                if (rb + e < M && col < N) C[(int64_t)(rb + e) * ldc + col] = v;
-            }
-        }
+            for (int j = 0; j < NJ; ++j) { big[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; small[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        ++ct; ck = 0; k_lo = 0; ++seg;
+        // (The epilogue's stores share the vector-memory counter with the DMAs in flight.  The counted wait of the next
+        // step stays correct: loads complete in order among loads and the DMAs of step s + 1 are older than those of
+        // s + 2, so "at most six operations outstanding" still implies that step s + 1 has landed - stores can only make
+        // the wait longer, never shorter.)
     }
 }
 
-// C = sum over the k slices of the workspace (+ bias) (relu) (* [mask > 0]); a thread per element, rows of N contiguous
-__global__ __launch_bounds__(256) void pgemm_finish_kernel(const float* __restrict__ ws, int ksplit, float* __restrict__ C,
-                                                           int64_t ldc, int M, int N, const float* __restrict__ bias, int relu,
+// The tiles that more than one block multiplied: C tile = sum of the blocks' partial tiles, in block order, + epilogue.
+// One block per tile, same thread -> element map as the product kernel; tiles a single block finished return at once.
+__global__ __launch_bounds__(512) void pgemm_finish_kernel(float* __restrict__ ws, int nwg, int nk, int tiles_m, int tiles_n,
+                                                           float* __restrict__ C, int64_t ldc, int M, int N,
+                                                           const float* __restrict__ bias, int relu,
                                                            const float* __restrict__ mask, int64_t ldmask)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)M * N;
-    if (idx >= total) return;
-    const int row = (int)(idx / N), col = (int)(idx - (int64_t)row * N);
-    float v = 0.f;
-    for (int s = 0; s < ksplit; ++s) v += ws[(int64_t)s * total + idx];
-    if (bias) v += bias[col];
-    if (relu) v = fmaxf(v, 0.f);
-    if (mask) v = mask[(int64_t)row * ldmask + col] > 0.f ? v : 0.f;
-    C[(int64_t)row * ldc + col] = v;
+    const int t = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t W = (int64_t)tiles_m * tiles_n * nk, x0 = (int64_t)t * nk;
+    const int b_lo = owner_of(x0, W, nwg), b_hi = owner_of(x0 + nk - 1, W, nwg);
+    if (b_lo == b_hi) return;
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = b_lo; b <= b_hi; ++b) {
+        const int64_t slot = 2 * (int64_t)b + (W * b / nwg < x0);       // a block that began in an earlier tile: its last tile
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] += *slot_ptr(ws, slot, i, j, threadIdx.x);
+    }
+    const int tn = t / tiles_m, tm = t - tn * tiles_m;
+    const int wm = (wave / WN) * (TM / WM), wn = (wave % WN) * (TN / WN);
+    store_tile(acc, tm * TM, tn * TN, wm, wn, lane, C, ldc, M, N, bias, relu, mask, ldmask);
 }
 
-// k slices per tile: 1 when the tiles alone fill the chip; else as many as keep every slice >= 16 k-steps deep
-int choose_ksplit(int64_t tiles, int64_t nk) {
-    int s = 1;
-    while (tiles * (s + 1) <= 256 && nk / (s + 1) >= 16 && s < 8) ++s;
-    return s;
+// Blocks of the launch (measured, tools/dev/pgemm_bench.py --sweep, 256 CUs; every partial tile costs a 64 KB store, its
+// share of the finishing launch and a tile change inside the block, so splitting has to win back ~25 us):
+//   a block per tile            when the tiles fill their rounds of the chip to >= 80 % (252 / 210 of 256: 151 / ~150 us),
+//                               when there is no workspace, or when a block would walk through more than 1.5 tiles
+//                               (H^T dA, 882 tiles of 24 k-steps: 176 us against 191 with shares);
+//   s blocks per tile           the contraction cut in s ALIGNED parts when that fills ONE round to >= 80 % (dA W2^T at
+//                               126 tiles: 2 x 126 blocks, 147 us against 168 with free shares - one partial per block);
+//   one block per CU, equal shares of the k-steps
+//                               otherwise (294 tiles: 193 us against ~230 for two rounds; 147 tiles: 197 against 230).
+int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+int choose_blocks(int64_t ntile, int64_t nk, bool have_ws) {
+    const int64_t cus = cu_count(), rounds = (ntile + cus - 1) / cus;
+    if (!have_ws || ntile * 100 >= rounds * cus * 80 || ntile * nk < cus * 8 || ntile > (int64_t)1 << 24) return (int)ntile;
+    for (int64_t sp = 8; sp >= 2; --sp)
+        if (ntile * sp <= cus && ntile * sp * 100 >= cus * 80 && nk / sp >= 16) return (int)(ntile * sp);
+    if (ntile * 2 > cus * 3) return (int)ntile;
+    return (int)cus;
 }
 
 template <bool A_KC, bool B_KC>
 int launch(int products, const short* Ap, int64_t lda, int64_t pa, const short* Bp, int64_t ldb, int64_t pb, float* C,
-           int64_t ldc, int M, int N, int Kp, const float* bias, int relu, const float* mask, int64_t ldmask, float* ws,
+           int64_t ldc, int M, int N, int nk, const float* bias, int relu, const float* mask, int64_t ldmask, float* ws,
            hipStream_t s)
 {
     const int tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const size_t lds = (size_t)STAGES * STAGE_B;
-    const int ksplit = ws ? choose_ksplit((int64_t)tiles_m * tiles_n, Kp / BK) : 1;
-    const dim3 grid(tiles_m * tiles_n * ksplit), block(512);
+    const int nwg = choose_blocks((int64_t)tiles_m * tiles_n, nk, ws != nullptr);
+    const dim3 grid(nwg), block(512);
     if (products == 6) {
         auto* k = pgemm_kernel<A_KC, B_KC, 6>;
         const int rc = gode_set_lds_once((const void*)k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, block, lds, s, Ap, lda, pa, Bp, ldb, pb, C, ldc, M, N, Kp, tiles_m, tiles_n, ksplit, ws, bias, relu, mask, ldmask);
+        hipLaunchKernelGGL(k, grid, block, lds, s, Ap, lda, pa, Bp, ldb, pb, C, ldc, M, N, nk, tiles_m, tiles_n, ws, bias, relu, mask, ldmask);
     } else {
         auto* k = pgemm_kernel<A_KC, B_KC, 8>;
         const int rc = gode_set_lds_once((const void*)k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, block, lds, s, Ap, lda, pa, Bp, ldb, pb, C, ldc, M, N, Kp, tiles_m, tiles_n, ksplit, ws, bias, relu, mask, ldmask);
+        hipLaunchKernelGGL(k, grid, block, lds, s, Ap, lda, pa, Bp, ldb, pb, C, ldc, M, N, nk, tiles_m, tiles_n, ws, bias, relu, mask, ldmask);
     }
     GODE_LAUNCH_CHECK();
-    if (ksplit > 1) {
-        const int64_t total = (int64_t)M * N;
-        hipLaunchKernelGGL(pgemm_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, ksplit, C, ldc, M, N,
-                           bias, relu, mask, ldmask);
+    if (nwg != tiles_m * tiles_n) {
+        hipLaunchKernelGGL(pgemm_finish_kernel, dim3(tiles_m * tiles_n), dim3(512), 0, s, ws, nwg, nk, tiles_m, tiles_n, C, ldc,
+                           M, N, bias, relu, mask, ldmask);
         GODE_LAUNCH_CHECK();
     }
     return 0;
@@ -388,8 +458,8 @@ extern "C" int64_t gode_pgemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int64_t tiles = (gode_cut_pad(M) / TM) * (gode_cut_pad(N) / TN);
-    const int ks = choose_ksplit(tiles, gode_cut_pad(K) / BK);
-    return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
+    const int nwg = choose_blocks(tiles, (K + BK - 1) / BK, true);
+    return nwg != tiles ? 2 * (int64_t)nwg * SLOT_F * 4 : 0;      // two partial-tile slots per block
 }
 
 extern "C" int gode_pgemm_bf16x3(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void* A_planes,
@@ -415,8 +485,8 @@ extern "C" int gode_pgemm_bf16x3(int trans_a, int trans_b, int64_t M, int64_t N,
     float* ws = reinterpret_cast<float*>(workspace);          // nullable: without it the contraction is never split
     if (ws && (((uintptr_t)ws) & 15)) return GODE_E_ALIGN;
     const bool akc = !trans_a, bkc = trans_b != 0;
-    if (akc && bkc) return launch<true, true>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, ws, s);
-    if (akc && !bkc) return launch<true, false>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, ws, s);
-    if (!akc && bkc) return launch<false, true>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, ws, s);
-    return launch<false, false>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)Kp, bias, relu, mask, ldmask, ws, s);
+    if (akc && bkc) return launch<true, true>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)((K + BK - 1) / BK), bias, relu, mask, ldmask, ws, s);
+    if (akc && !bkc) return launch<true, false>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)((K + BK - 1) / BK), bias, relu, mask, ldmask, ws, s);
+    if (!akc && bkc) return launch<false, true>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)((K + BK - 1) / BK), bias, relu, mask, ldmask, ws, s);
+    return launch<false, false>(products, Ap, lda, pa, Bp, ldb, pb, C, ldc, (int)M, (int)N, (int)((K + BK - 1) / BK), bias, relu, mask, ldmask, ws, s);
 }

@@ -25,11 +25,14 @@ struct Epilogue {
     LinComb pre;     // n == 0: Y = alpha * act(Z + bias)
     LinComb cot;
     float* Y2;
+    float* colpart;  // with Y2 (vec4 kernels, a thread group per record): block b writes the column sums of the Y2 rows it stored
+                     // to colpart[b][d]; the finishing launch continues at row `colpart_row0`
+    int64_t colpart_row0;
 };
 
 template <int LPR>
-__device__ __forceinline__ void epilogue_store4(const Epilogue& ep, float4 z, int row, int lane,
-                                                int64_t d, float* Y, int64_t ldy) {
+__device__ __forceinline__ float4 epilogue_store4(const Epilogue& ep, float4 z, int row, int lane,
+                                                  int64_t d, float* Y, int64_t ldy) {
     if (ep.bias) {
         const float4 b = *reinterpret_cast<const float4*>(ep.bias + lane * 4);
         z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;
@@ -50,6 +53,27 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& ep, float4 z, in
         g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f;
         g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
         *reinterpret_cast<float4*>(ep.Y2 + o) = g;
+        return g;
+    }
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Column sums of the Y2 rows a block stored (the bias gradient of a layer is colsum of its masked cotangent: formed here
+// the 2^20 x 128 array is never read again for it - the caller reduces gridDim.x partial rows instead, 1/8 of the bytes).
+// Every thread of the block calls this (threads without a row pass zeros); rows are added in thread-group order.
+template <int LPR>
+__device__ __forceinline__ void block_colsum_store(const float4 g, float* __restrict__ colpart_row) {
+    __shared__ float4 cs[256];
+    cs[threadIdx.x] = g;
+    __syncthreads();
+    if (threadIdx.x < LPR) {
+        float4 t = cs[threadIdx.x];
+#pragma unroll
+        for (int r = 1; r < 256 / LPR; ++r) {
+            const float4 a = cs[r * LPR + threadIdx.x];
+            t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+        }
+        *reinterpret_cast<float4*>(colpart_row + 4 * threadIdx.x) = t;
     }
 }
 
@@ -101,6 +125,15 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
                 acc.z = fmaf(vv[u], xv[u].z, acc.z); acc.w = fmaf(vv[u], xv[u].w, acc.w);
             }
         }
+    }
+    if (ep.colpart) {                                  // (block-uniform) nobody leaves before the block's column sums
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) {
+            if (slot < 0) g = epilogue_store4<LPR>(ep, acc, row, lane, (int64_t)LPR * 4, Y, ldy);
+            else *reinterpret_cast<float4*>(partial + (int64_t)slot * (LPR * 4) + lane * 4) = acc;
+        }
+        block_colsum_store<LPR>(g, ep.colpart + (int64_t)blockIdx.x * (LPR * 4));
+        return;
     }
     if (!active) return;
     if (slot < 0) epilogue_store4<LPR>(ep, acc, row, lane, (int64_t)LPR * 4, Y, ldy);
@@ -171,8 +204,9 @@ __global__ __launch_bounds__(256) void spmm_finish_vec4_kernel(
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int gid = (int)(tid / LPR);
     const int lane = threadIdx.x & (LPR - 1);
-    if (gid >= n_long) return;
-    const int4 lr = long_rows[gid];
+    const bool active = gid < n_long;
+    if (!active && !ep.colpart) return;
+    const int4 lr = active ? long_rows[gid] : make_int4(0, 0, 0, 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int s = lr.y;
     for (; s + 3 < lr.z; s += 4) {          // 4 independent loads in flight, added in slot order
@@ -188,6 +222,12 @@ __global__ __launch_bounds__(256) void spmm_finish_vec4_kernel(
     for (; s < lr.z; ++s) {
         const float4 p = *reinterpret_cast<const float4*>(partial + (int64_t)s * (LPR * 4) + lane * 4);
         acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    if (ep.colpart) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) g = epilogue_store4<LPR>(ep, acc, lr.x, lane, (int64_t)LPR * 4, Y, ldy);
+        block_colsum_store<LPR>(g, ep.colpart + (ep.colpart_row0 + blockIdx.x) * (LPR * 4));
+        return;
     }
     epilogue_store4<LPR>(ep, acc, lr.x, lane, (int64_t)LPR * 4, Y, ldy);
 }
@@ -284,6 +324,7 @@ int launch_vec4(const int* rowptr, const int* col, const float* val, const int4*
                 const int4* long_rows, int n_long, float* partial, const float* X, int64_t ldx,
                 float* Y, int64_t ldy, const Epilogue& ep, hipStream_t s) {
     if (LPR < 64 && n_items > 0 && n_items <= 65536) {         // too few records to fill the chip: a wave per record
+        if (ep.colpart) return GODE_E_UNSUPPORTED;             // (gode_spmm_y2_colsum_rows is 0 for such a graph)
         const int64_t wb = ((int64_t)n_items * 64 + 255) / 256;
         const int slot = gode_prof_begin(s, (int64_t)LPR * 4, n_items, (int64_t)ep.pre.n + ep.cot.n + (ep.Y2 ? 1 : 0));
         hipLaunchKernelGGL(spmm_vec4_wave_kernel<LPR>, dim3((unsigned)wb), dim3(256), 0, s,
@@ -309,14 +350,25 @@ int launch_vec4(const int* rowptr, const int* col, const float* val, const int4*
     }
     if (n_long > 0) {
         const int64_t b2 = ((int64_t)n_long * LPR + 255) / 256;
+        Epilogue ep2 = ep;
+        ep2.colpart_row0 = blocks;                             // its partial rows follow the main launch's
         hipLaunchKernelGGL(spmm_finish_vec4_kernel<LPR>, dim3((unsigned)b2), dim3(256), 0, s,
-                           long_rows, n_long, partial, Y, ldy, ep);
+                           long_rows, n_long, partial, Y, ldy, ep2);
         GODE_LAUNCH_CHECK();
     }
     return 0;
 }
 
 }  // namespace
+
+extern "C" int64_t gode_spmm_y2_colsum_rows(int64_t n_items, int64_t n_long, int64_t d)
+{
+    if (n_items <= 0 || n_long < 0 || d <= 0 || d % 4) return 0;
+    const int64_t lpr = d / 4;
+    if (lpr > 64 || (lpr & (lpr - 1))) return 0;              // the 16-byte-lane kernels only
+    if (lpr < 64 && n_items <= 65536) return 0;                // small graphs run a wave per record: no per-block sums
+    return (n_items * lpr + 255) / 256 + (n_long * lpr + 255) / 256;
+}
 
 extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                  const int32_t* items, int64_t n_items,
@@ -344,6 +396,8 @@ extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
     Epilogue ep;
     ep.bias = bias; ep.relu = epi ? epi->relu : 0; ep.alpha = epi ? epi->alpha : 1.f;
     ep.pre = make_lincomb(pre); ep.cot = make_lincomb(cot); ep.Y2 = Y2;
+    ep.colpart = (epi && Y2) ? epi->Y2_colsum : nullptr; ep.colpart_row0 = 0;
+    if (ep.colpart && ((((uintptr_t)ep.colpart) & 15) || gode_spmm_y2_colsum_rows(n_items, n_long, d) == 0)) return GODE_E_UNSUPPORTED;
 
     const bool al = !(((uintptr_t)X) & 15) && !(((uintptr_t)Y) & 15) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
                     (!bias || !(((uintptr_t)bias) & 15)) && (!partial || !(((uintptr_t)partial) & 15)) &&
@@ -358,6 +412,7 @@ extern "C" int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, cons
             default: break;
         }
     }
+    if (ep.colpart) return GODE_E_UNSUPPORTED;                 // unaligned operands: no per-block column sums on the generic kernels
     int G = 1; while (G < d && G < 64) G <<= 1;
     if (d == 1 && it4 != nullptr) {                    // record lists only: whole short rows are cheaper one thread each
         const int64_t blocks = ((int64_t)n_items * 64 + 255) / 256;

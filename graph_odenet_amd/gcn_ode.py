@@ -45,6 +45,9 @@ class _Shared:
         self.device = device
         self._ky = self._ka = self._kt = None
         self._parts = None
+        # rows of the per-block column sums the forward-recompute SpMM of an adjoint stage can leave (0: not on this shape)
+        self.y2_rows = _lib.load().gode_spmm_y2_colsum_rows(graph.n_items if graph.items is not None else n, graph.n_long, d)
+        self._y2_colsum = None
 
     def bwd(self):
         if self.dZ is None:
@@ -90,6 +93,10 @@ class _Shared:
             ws.X[0], ws.X[1] = self.X2[0].data_ptr(), self.X2[1].data_ptr()
             sp = self.small_part(groups)
             ws.small_part = sp.data_ptr() if sp is not None else None
+            if self.y2_rows > 0:
+                if self._y2_colsum is None:
+                    self._y2_colsum = torch.empty(self.y2_rows, self.d, dtype=torch.float32, device=self.device)
+                ws.y2_colsum = self._y2_colsum.data_ptr()
         return ws
 
     def small_part(self, groups):

@@ -34,8 +34,10 @@ def _need_terms(terms, name):
     return n
 
 
-def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None, pre_terms=None, alpha=1.0):
-    """Y = (sum pre_terms) + alpha * relu?(A @ X + bias); optionally out2 = (sum cot_terms) * (A@X+bias > 0)."""
+def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None, pre_terms=None, alpha=1.0, out2_colsum=None):
+    """Y = (sum pre_terms) + alpha * relu?(A @ X + bias); optionally out2 = (sum cot_terms) * (A@X+bias > 0).
+    out2_colsum ([spmm_y2_colsum_rows(graph, d), d], with cot_terms): the launch also leaves per-block column sums of out2
+    there - their sum over the rows is out2.sum(0)."""
     lib = _lib.load()
     _need(X, "X")
     _need(bias, "bias")
@@ -79,6 +81,11 @@ def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None, p
                 out2 = torch.empty(graph.n_rows, d, dtype=torch.float32, device=X.device)
             _need(out2, "out2")
             ep.Y2 = out2.data_ptr()
+            if out2_colsum is not None:
+                _need(out2_colsum, "out2_colsum")
+                if out2_colsum.numel() != spmm_y2_colsum_rows(graph, d) * d or out2_colsum.numel() == 0:
+                    raise ValueError("spmm: out2_colsum must be spmm_y2_colsum_rows(graph, d) x d (and the shape must support it)")
+                ep.Y2_colsum = out2_colsum.data_ptr()
     partial = graph.partial(d)
     rc = lib.gode_spmm_csr_f32(ptr(graph.rowptr), ptr(graph.col), ptr(graph.val),
                                ptr(graph.items), graph.n_items,
@@ -87,6 +94,11 @@ def spmm(graph, X, bias=None, relu=False, out=None, cot_terms=None, out2=None, p
                                ctypes.byref(ep) if ep is not None else None, stream_ptr())
     check(rc, "gode_spmm_csr_f32")
     return (out, out2) if cot_terms is not None else out
+
+
+def spmm_y2_colsum_rows(graph, d):
+    """Rows of the out2_colsum array of spmm() for this graph and width (0: this shape runs on kernels without it)."""
+    return int(_lib.load().gode_spmm_y2_colsum_rows(graph.n_items if graph.items is not None else graph.n_rows, graph.n_long, int(d)))
 
 
 def lincomb_(out, terms):

@@ -100,7 +100,14 @@ typedef struct gode_spmm_epilogue {
     gode_lincomb_t pre;     /* host-side struct; n == 0 = absent */
     gode_lincomb_t cot;     /* used when Y2 != NULL */
     float*         Y2;      /* nullable */
+    float*         Y2_colsum; /* nullable, with Y2: per-block column sums of the rows of Y2 - gode_spmm_y2_colsum_rows(n_items,
+                               n_long, d) rows of d floats (16-byte aligned); their sum over the rows (gode_colsum_f32 on this
+                               array) is colsum(Y2), the bias gradient of the layer, without reading Y2 again */
 } gode_spmm_epilogue_t;
+
+/* rows of the Y2_colsum array for a graph's record lists (0: the shape runs on kernels without it - small graphs,
+ * d not 4 * 2^k <= 256 - and a call with Y2_colsum set returns GODE_E_UNSUPPORTED) */
+int64_t gode_spmm_y2_colsum_rows(int64_t n_items, int64_t n_long, int64_t d);
 
 int gode_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                       const int32_t* items, int64_t n_items,
@@ -482,6 +489,9 @@ typedef struct gode_rk4_workspace {
                                            the VJP and weight-gradient launches */
     float* small_part;                  /* nullable: 4 * gode_gcn_small_parts(n) * gode_gcn_small_part_len(d) floats - enables
                                            the fused launch-bound path of the adjoint drivers (csrc/small.hip) */
+    float* y2_colsum;                   /* nullable: gode_spmm_y2_colsum_rows(A.n_items, A.n_long, d) * d floats - the bias
+                                           gradient of an adjoint stage is reduced from the per-block column sums the
+                                           forward-recompute SpMM leaves there instead of from dZ */
 } gode_rk4_workspace_t;
 
 /* Launch-bound graphs (n <= 65 536, d in {16, 32}, 1 / 2 / 4 channels per GroupNorm group): ODEfunc.forward

@@ -416,7 +416,7 @@ def test_native_dopri5_step_for_heads_matches_python_driver(golden, d, H):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n", [1, 37, 3327])
+@pytest.mark.parametrize("n", [1, 37, 3327, 4500])
 @pytest.mark.parametrize("d,H", [(16, 1), (32, 1), (64, 1), (16, 2), (32, 4), (64, 8), (16, 8), (64, 3)])
 def test_one_launch_dense_half_vs_float64_autograd(n, d, H):
     """csrc/gat_small.hip (launch-bound graphs): the node-level products of GAT/layers.py:43,45 behind GroupNorm and the
@@ -489,11 +489,23 @@ def test_one_launch_dense_half_vs_float64_autograd(n, d, H):
     part2, ka2 = ops.gat_small_part(n, d, H, D), torch.empty_like(ka)
     ops.gat_dense_vjp_small([(1.0, X)], n, d, groups, eps, gamma.to(D), beta.to(D), Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H,
                             dPs.to(D), dPt.to(D), dA2.to(D), ka2, part2, out_scale=-0.5, pre_terms=[(2.0, pre.to(D))], packed=packed)
-    kth2, kat2 = torch.empty_like(kth), torch.empty_like(kat)
+    kth2, kat2 = torch.full_like(kth, float("nan")), torch.full_like(kat, float("nan"))
     ops.gat_small_finish(part2, n, d, H, t, kth2, kat2)
-    assert torch.equal(ka2, ka) and torch.equal(kth2, kth) and torch.equal(kat2, kat)
     want_at = (cs[0] * Wsrc[0].double()).sum() + (cs[1] * Wtgt[0].double()).sum() + (cs[2] * Wlog[0].double()).sum()
     assert abs(kat.item() - want_at.item()) <= 4e-6 * max(1.0, abs(want_at.item())) * max(1.0, n ** 0.5)
+    if d < 64:
+        assert torch.equal(ka2, ka) and torch.equal(kth2, kth) and torch.equal(kat2, kat)
+    else:
+        # d = 64 with the packed images: tiles of 16 rows on the fp32 matrix instruction (gat_dense_vjp_d64_kernel; n = 4500:
+        # more tiles than blocks) - another summation order, the same bars against float64
+        assert (ka2.cpu().double() - want_ka).abs().max().item() <= xtol * max(1.0, want_ka.abs().max().item())
+        got2 = kth2.cpu().double()
+        for lo, hi, tol, nm in ((0, i_gamma, wtol, "weights and biases"), (i_gamma, i_gamma + d, 2e-3 if cg == 1 else 2e-5, "dgamma"),
+                                (i_gamma + d, nth, 2e-5, "dbeta")):
+            scale = max(1.0, want[lo:hi].abs().max().item())
+            bad = (got2[lo:hi] - want[lo:hi]).abs().max().item()
+            assert bad <= tol * scale * max(1.0, n ** 0.5), (nm, "matrix-instruction form", bad, scale)
+        assert abs(kat2.item() - want_at.item()) <= 4e-6 * max(1.0, abs(want_at.item())) * max(1.0, n ** 0.5)
 
 
 @pytest.mark.parametrize("heads,d", [(1, 16), (1, 64), (8, 64), (4, 32)])
@@ -601,15 +613,18 @@ def test_dense_vjp_closes_the_max_path_step_bit_for_bit(d, H):
         assert heads_of[e] == h
         fixed[int(esrc[e]) // H, 2 * h] -= T.to(D)
         fixed[int(etgt[e]) // H, 2 * h + 1] -= T.to(D)
-    outs = []
-    for da2, mfx in ((fixed, None), (dA2, (scratch, esrc.to(D), etgt.to(D)))):
-        part = ops.gat_small_part(n, d, H, D)
-        ka = torch.empty(n, d, **f)
-        ops.gat_dense_vjp_small([(1.0, x)], n, d, min(32, d), 1e-5, gamma, beta, Wsrc, Wtgt, Wlog, H, dPs, dPt, da2, ka, part, maxfix=mfx)
-        kth = torch.empty(2 * (d + 1) * d + (d + 1) * 2 * H + d + H + 2 * d, **f)
-        kat = torch.empty(1, **f)
-        ops.gat_small_finish(part, n, d, H, 0.3, kth, kat)
-        outs.append((ka, kth, kat))
     assert not torch.equal(fixed, dA2)
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
+    # without and with the weights' packed images (at d = 64 the latter is the matrix-instruction form of the launch)
+    for packed in (None, ops.gat_small_pack(Wsrc, Wtgt, Wlog, H)):
+        outs = []
+        for da2, mfx in ((fixed, None), (dA2, (scratch, esrc.to(D), etgt.to(D)))):
+            part = ops.gat_small_part(n, d, H, D)
+            ka = torch.empty(n, d, **f)
+            ops.gat_dense_vjp_small([(1.0, x)], n, d, min(32, d), 1e-5, gamma, beta, Wsrc, Wtgt, Wlog, H, dPs, dPt, da2, ka, part,
+                                    maxfix=mfx, packed=packed)
+            kth = torch.empty(2 * (d + 1) * d + (d + 1) * 2 * H + d + H + 2 * d, **f)
+            kat = torch.empty(1, **f)
+            ops.gat_small_finish(part, n, d, H, 0.3, kth, kat)
+            outs.append((ka, kth, kat))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)

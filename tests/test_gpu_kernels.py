@@ -99,6 +99,45 @@ def test_spmm_masked_cotangent_epilogue():
     close(out2.cpu() * safe, ref2 * safe, what="masked cotangent")
 
 
+@pytest.mark.parametrize("d", [128, 16, 256])
+def test_spmm_leaves_block_column_sums_of_the_masked_cotangent(d):
+    """gode_spmm_csr_f32 with Y2_colsum: the launch that writes the relu-masked cotangent of an adjoint stage also leaves
+    the column sums of the rows each block stored (the bias gradient is colsum of that array: the driver reduces these
+    partial rows instead of reading the n x d array again).  Y and Y2 are bit for bit those of the launch without the
+    option; the partial rows add up to Y2.sum(0); rows split over several records (finished by the second launch) are in;
+    a small graph (a wave per record) reports 0 rows and refuses the option."""
+    from graph_odenet_amd import graph as G, ops
+    n = 70_000
+    r, c, v = powerlaw_graph(n, n, 5, 11, long_row=900, empty=3)
+    g = G.from_coo(r.to(dev()), c.to(dev()), v.to(dev()), n, n, split=128)
+    assert g.n_long >= 1 and g.n_items > 65536
+    gen = torch.Generator().manual_seed(d)
+    X, b = torch.randn(n, d, generator=gen).to(dev()), torch.randn(d, generator=gen).to(dev())
+    a0, a1 = torch.randn(n, d, generator=gen).to(dev()), torch.randn(n, d, generator=gen).to(dev())
+    cot = [(-1.0, a0), (0.25, a1)]
+    rows = ops.spmm_y2_colsum_rows(g, d)
+    lpr = d // 4
+    assert rows == (g.n_items * lpr + 255) // 256 + (g.n_long * lpr + 255) // 256
+    out, out2 = ops.spmm(g, X, bias=b, relu=True, cot_terms=cot)
+    part = torch.full((rows, d), float("nan"), device=dev())
+    outb, out2b = ops.spmm(g, X, bias=b, relu=True, cot_terms=cot, out2_colsum=part)
+    assert torch.equal(outb, out) and torch.equal(out2b, out2)
+    assert bool(torch.isfinite(part).all())
+    want = out2.double().sum(0)
+    got = part.double().sum(0)
+    assert (got - want).abs().max().item() <= 2e-6 * out2.abs().double().sum(0).max().item()
+    # and through the library's own column sum, as the adjoint driver does
+    cs = ops.colsum_(torch.empty(d, device=dev()), part)
+    assert (cs.double() - want).abs().max().item() <= 2e-6 * out2.abs().double().sum(0).max().item()
+    # small graph: no per-block sums
+    r2, c2, v2 = powerlaw_graph(500, 500, 5, 12)
+    g2 = G.from_coo(r2.to(dev()), c2.to(dev()), v2.to(dev()), 500, 500)
+    assert ops.spmm_y2_colsum_rows(g2, 16) == 0
+    with pytest.raises(ValueError):
+        ops.spmm(g2, torch.randn(500, 16, device=dev()), relu=True, cot_terms=[(1.0, torch.randn(500, 16, device=dev()))],
+                 out2_colsum=torch.empty(4, 16, device=dev()))
+
+
 def test_spmm_row_sum_property_full_size():
     """Size-independent property at BASELINE's full size (2^20 nodes, ~10M edges, d=128):
     a row-normalised A_hat maps the all-ones matrix to all-ones, and SpMM is linear."""
@@ -842,16 +881,21 @@ def test_exact_three_way_cut_planes():
     assert bool((hi.abs() <= X.abs()).all()) and bool(((X - hi).abs() <= X.abs() * 2.0 ** -7).all())   # truncation, 8 bits
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 300, 150), (129, 257, 33), (1, 1, 1), (384, 256, 512), (130, 100, 2100)])
+@pytest.mark.parametrize("M,N,K", [(200, 300, 150), (129, 257, 33), (1, 1, 1), (384, 256, 512), (300, 2600, 2100),
+                                   (1100, 5329, 520)])
 def test_piece_gemm_all_operand_layouts_and_epilogues(M, N, K):
     """csrc/pgemm.hip gode_pgemm_bf16x3 (large products of the QC edge encoder on the bf16 matrix cores from exact cuts):
     C = op(A) op(B) for the four operand layouts - each operand read from LDS by ds_read_b128 or by the transposing
     ds_read_b64_tr_b16 - ragged sizes, the fused epilogues, 8 and 6 piece products, against float64 at the bar of the
-    exact-fp32 kernel; the cut of a matrix serves both of its roles.  (130, 100, 2100): two tiles, 66 k-steps - the
-    contraction is split over four blocks per tile and summed by the finishing launch."""
+    exact-fp32 kernel; the cut of a matrix serves both of its roles.  The last two sizes do not fill whole rounds of the
+    chip with tiles: 63 tiles of 66 k-steps - four blocks per tile, each an aligned quarter of the contraction; 378 tiles
+    of 17 k-steps (and 289 of 10, the A^T A product below) - the k-steps are dealt in equal shares to one block per CU,
+    shares begin and end inside tiles.  The finishing launch adds the partial tiles."""
     from graph_odenet_amd import _lib, ops
-    if (M, N, K) == (130, 100, 2100):
-        assert _lib.load().gode_pgemm_workspace_bytes(M, N, K) == 4 * M * N * 4
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    want_blocks = {(300, 2600, 2100): 252 if cus == 256 else None, (1100, 5329, 520): cus}.get((M, N, K), 0)
+    if want_blocks is not None:
+        assert _lib.load().gode_pgemm_workspace_bytes(M, N, K) == 2 * want_blocks * 128 * 128 * 4
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / max(K, 1) ** 0.5
     bias, mask = torch.randn(N, generator=g), torch.randn(M, N, generator=g)

@@ -10,6 +10,32 @@ from graph_odenet_amd import _lib, ops
 D = torch.device("cuda:0")
 lib = _lib.load()
 E, Hd, O = 760, 2667, 5329
+if "--sweep" in sys.argv:
+    # edge counts of real mini-batches vary (650 .. 950 for 20 molecules): 6, 7 or 8 row tiles - 252 / 294 / 336 tiles of
+    # the forward product on 256 CUs.  Piece kernel only, per product.
+    def t_us(fn, n=20):
+        for _ in range(3):
+            fn()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize(); ev[0].record()
+        for _ in range(n):
+            fn()
+        ev[1].record(); torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / n * 1e3
+    g = torch.Generator(device=D).manual_seed(0)
+    W2 = torch.randn(Hd, O, device=D, generator=g) / Hd ** 0.5
+    Wc = ops.cut3(W2)
+    for e in (640, 700, 760, 768, 800, 850, 896, 950, 1024, 1500):
+        H = torch.relu(torch.randn(e, Hd, device=D, generator=g)); dA = torch.randn(e, O, device=D, generator=g)
+        Hc, dc = ops.cut3(H), ops.cut3(dA)
+        t = (t_us(lambda: ops.pgemm(Hc, Wc)), t_us(lambda: ops.pgemm(dc, Wc, trans_b=True, mask=H)),
+             t_us(lambda: ops.pgemm(Hc, dc, trans_a=True)))
+        fl = 2.0 * e * Hd * O
+        print("E %5d   H W2 %7.1f us (%5.1f)   dA W2^T %7.1f us (%5.1f)   H^T dA %7.1f us (%5.1f)   [fp32-equiv TFLOP/s]   ws bytes %s"
+              % (e, t[0], fl / t[0] / 1e6, t[1], fl / t[1] / 1e6, t[2], fl / t[2] / 1e6,
+                 [lib.gode_pgemm_workspace_bytes(e, O, Hd), lib.gode_pgemm_workspace_bytes(e, Hd, O),
+                  lib.gode_pgemm_workspace_bytes(Hd, O, e)]), flush=True)
+    sys.exit(0)
 g = torch.Generator(device=D).manual_seed(0)
 H = torch.relu(torch.randn(E, Hd, device=D, generator=g))
 W2 = torch.randn(Hd, O, device=D, generator=g) / Hd ** 0.5
