@@ -140,7 +140,7 @@ def secondary(args, model, x, g, step, barrier):
     # against the default (bf16-piece kernels for the weight gradient and the <= 2-term forward launches)
     from graph_odenet_amd import _lib
     lib = _lib.load()
-    names = (b"gemm_split", b"wgrad_split", b"fwd_pc", b"bwd_pc", b"bwd_wgrad")
+    names = (b"gemm_split", b"wgrad_split", b"fwd_pc", b"bwd_pc", b"bwd_wgrad", b"y2_colsum")
     was = [lib.gode_get_option(k) for k in names]
 
     def timed(settings, reps=2):
@@ -162,9 +162,10 @@ def secondary(args, model, x, g, step, barrier):
     # kernels, <= 2-term forward on gn_gemm_fwd_split_kernel), every dense product on the fp32-MFMA kernels, and the
     # default again (the first and last figure bracket the drift of the box)
     out["steps_per_s_default_kernels"] = timed(was)
-    out["steps_per_s_with_separate_vjp_and_weight_gradient_launches"] = timed((was[0], was[1], was[2], was[3], 0))   # round 3
-    out["steps_per_s_with_round2_dense_kernels"] = timed((2, was[1], 0, 0, 0))
-    out["steps_per_s_with_fp32_mfma_dense_kernels_only"] = timed((0, 0, 0, 0, 0))
+    out["steps_per_s_with_bias_gradient_from_a_pass_over_dZ"] = timed((was[0], was[1], was[2], was[3], was[4], 0))   # before round 4's SpMM epilogue sums
+    out["steps_per_s_with_separate_vjp_and_weight_gradient_launches"] = timed((was[0], was[1], was[2], was[3], 0, was[5]))   # round 3
+    out["steps_per_s_with_round2_dense_kernels"] = timed((2, was[1], 0, 0, 0, was[5]))
+    out["steps_per_s_with_fp32_mfma_dense_kernels_only"] = timed((0, 0, 0, 0, 0, was[5]))
     out["steps_per_s_default_kernels_again"] = timed(was)
     return out
 

@@ -24,7 +24,7 @@ extern "C" const char* gode_error_string(int code) {
 
 namespace {
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-int g_gemm_split = -1, g_overlap = -1, g_wgrad_split = -1, g_wgrad_split_small = 0, g_bwd_pc = -1, g_fwd_pc = -1, g_small_fused = -1, g_bwd_wgrad = -1;
+int g_gemm_split = -1, g_overlap = -1, g_wgrad_split = -1, g_wgrad_split_small = 0, g_bwd_pc = -1, g_fwd_pc = -1, g_small_fused = -1, g_bwd_wgrad = -1, g_y2_colsum = -1;
 }
 
 int gode_opt_gemm_split() { if (g_gemm_split < 0) { const int v = env_int("GODE_GEMM_SPLIT", 2); g_gemm_split = (v == 1 || v == 2) ? v : 0; } return g_gemm_split; }
@@ -37,6 +37,7 @@ int gode_opt_bwd_pc() { if (g_bwd_pc < 0) g_bwd_pc = env_int("GODE_BWD_PC", 1) !
 int gode_opt_fwd_pc() { if (g_fwd_pc < 0) g_fwd_pc = env_int("GODE_FWD_PC", 3) & 3; return g_fwd_pc; }
 int gode_opt_small_fused() { if (g_small_fused < 0) g_small_fused = env_int("GODE_SMALL_FUSED", 1) != 0; return g_small_fused; }
 int gode_opt_bwd_wgrad() { if (g_bwd_wgrad < 0) g_bwd_wgrad = env_int("GODE_BWD_WGRAD", 1) != 0; return g_bwd_wgrad; }
+int gode_opt_y2_colsum() { if (g_y2_colsum < 0) g_y2_colsum = env_int("GODE_Y2_COLSUM", 1) != 0; return g_y2_colsum; }
 int gode_opt_overlap() { if (g_overlap < 0) g_overlap = env_int("GODE_OVERLAP", 1) != 0; return g_overlap; }
 
 extern "C" int gode_set_option(const char* name, int value) {
@@ -47,6 +48,7 @@ extern "C" int gode_set_option(const char* name, int value) {
     if (!strcmp(name, "bwd_pc")) { g_bwd_pc = value != 0; return 0; }
     if (!strcmp(name, "small_fused")) { g_small_fused = value != 0; return 0; }
     if (!strcmp(name, "bwd_wgrad")) { g_bwd_wgrad = value != 0; return 0; }
+    if (!strcmp(name, "y2_colsum")) { g_y2_colsum = value != 0; return 0; }
     if (!strcmp(name, "fwd_pc")) { if (value < 0 || value > 3) return GODE_E_UNSUPPORTED; g_fwd_pc = value; return 0; }
     if (!strcmp(name, "wgrad_split")) { if (value != 0 && value != 6 && value != 8) return GODE_E_UNSUPPORTED; g_wgrad_split = value; return 0; }
     return GODE_E_UNSUPPORTED;
@@ -60,6 +62,7 @@ extern "C" int gode_get_option(const char* name) {
     if (!strcmp(name, "bwd_pc")) return gode_opt_bwd_pc();
     if (!strcmp(name, "small_fused")) return gode_opt_small_fused();
     if (!strcmp(name, "bwd_wgrad")) return gode_opt_bwd_wgrad();
+    if (!strcmp(name, "y2_colsum")) return gode_opt_y2_colsum();
     if (!strcmp(name, "fwd_pc")) return gode_opt_fwd_pc();
     return GODE_E_UNSUPPORTED;
 }

@@ -241,7 +241,7 @@ extern "C" int gode_gcn_ode_rk4_adjoint(const gode_gcn_odefunc_t* f, float* y, f
         ep.Y2 = ws->dZ;
         // colsum(dZ), the bias gradient of the stage: from the per-block column sums Sp(g) leaves in ws->y2_colsum (1/8 of
         // dZ's bytes) when the workspace has them and the graph runs on the kernels that form them
-        const int64_t y2rows = (bw && ws->y2_colsum)
+        const int64_t y2rows = (bw && ws->y2_colsum && gode_opt_y2_colsum())
             ? gode_spmm_y2_colsum_rows(f->A.items ? f->A.n_items : f->A.n_rows, f->A.items ? f->A.n_long : 0, d) : 0;
         if (y2rows > 0) ep.Y2_colsum = ws->y2_colsum;
         gode_lincomb_t apre; apre.n = 0;

@@ -8,3 +8,4 @@ int gode_opt_bwd_pc();       // GODE_BWD_PC (default 1): VJP at d = 128, >= 65 5
 int gode_opt_fwd_pc();       // GODE_FWD_PC (default 3): forward product likewise; bit 0 = launches of <= 2 terms, bit 1 = launches of >= 3 terms or with x_out
 int gode_opt_small_fused();   // GODE_SMALL_FUSED (default 1): launch-bound graphs take the fused one-launch f-eval / VJP of csrc/small.hip
 int gode_opt_bwd_wgrad();     // GODE_BWD_WGRAD (default 1): VJP and weight gradient of the ODE function at d = 128, >= 65 536 rows in ONE pass (gemm_pc.hip: gn_gemm_bwd_wgrad_pc_kernel) where the drivers issue both
+int gode_opt_y2_colsum();     // GODE_Y2_COLSUM (default 1): the adjoint rk4 driver reduces a stage's bias gradient from the per-block column sums its forward-recompute SpMM leaves (workspace y2_colsum) instead of from dZ

@@ -42,6 +42,24 @@ __device__ __forceinline__ void xor_combine4(float4& v, int from, int upto = 64)
     }
 }
 
+// lc_load4 (same order of the multiply-adds: bit for bit what a later launch would combine from memory) with the term
+// that names `self` taken from a register
+__device__ __forceinline__ float4 lc_load4_self(const LinComb& lc, int64_t idx, const float* self, const float4 self_v) {
+    float4 v[GODE_MAX_TERMS];
+#pragma unroll
+    for (int j = 0; j < GODE_MAX_TERMS; ++j)
+        if (j < lc.n && lc.ptr[j] != self) v[j] = *reinterpret_cast<const float4*>(lc.ptr[j] + idx);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < GODE_MAX_TERMS; ++j)
+        if (j < lc.n) {
+            const float4 x = lc.ptr[j] == self ? self_v : v[j];
+            const float c = lc.coef[j];
+            r.x = fmaf(c, x.x, r.x); r.y = fmaf(c, x.y, r.y); r.z = fmaf(c, x.z, r.z); r.w = fmaf(c, x.w, r.w);
+        }
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward: out[i] = (sum pre)[i] + alpha * relu(z_i),  z_i = (sum_j a_ij [t | GN(x_j)]) W + b;  Y2[i] = (sum cot)[i] * [z_i > 0]
 // ---------------------------------------------------------------------------------------------------------------
@@ -56,7 +74,7 @@ __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restr
                                                              const float* __restrict__ beta, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float t, float alpha,
                                                              LinComb pre, LinComb cot, float* __restrict__ Y2,
-                                                             float* __restrict__ out)
+                                                             float* __restrict__ out, LinComb nxt, float* __restrict__ x_next)
 {
     constexpr int LPR = D / 4, SG = GW / LPR, RPW = 64 / GW, PU = 4;   // lanes per row, sub-groups per row, rows per wave, gathers in flight per lane
     __shared__ __attribute__((aligned(16))) float Ws[(D + 1) * D];
@@ -135,6 +153,10 @@ __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restr
                 g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f; g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
                 *reinterpret_cast<float4*>(Y2 + o) = g;
             }
+            // the NEXT stage's combined input, row by row (a term that names `out` takes this row's value from the
+            // register): the next evaluation then gathers ONE array per neighbour instead of one per term of its stage
+            // input - 4.3 terms on average over the six stages of a dopri5 step, and the gather is what this kernel waits for
+            if (x_next) *reinterpret_cast<float4*>(x_next + o) = lc_load4_self(nxt, o, out, y);
         }
         __builtin_amdgcn_wave_barrier();                         // the next row's mrow stores follow these reads
     }
@@ -439,7 +461,21 @@ extern "C" int gode_gcn_feval_small_f32(const gode_gcn_odefunc_t* f, const gode_
                                         float alpha, const gode_lincomb_t* pre, const gode_lincomb_t* cot, float* Y2,
                                         float* out, void* stream)
 {
+    return gode_gcn_feval_small_next_f32(f, xin, t, alpha, pre, cot, Y2, out, nullptr, nullptr, stream);
+}
+
+extern "C" int gode_gcn_feval_small_next_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin, float t,
+                                             float alpha, const gode_lincomb_t* pre, const gode_lincomb_t* cot, float* Y2,
+                                             float* out, const gode_lincomb_t* next, float* x_next, void* stream)
+{
     if (!f || !xin || !out) return GODE_E_NULLPTR;
+    if (x_next) {
+        if (!next) return GODE_E_NULLPTR;
+        int rcn = check_lincomb(next, true); if (rcn) return rcn;
+        if (!lincomb_aligned16(next) || (((uintptr_t)x_next) & 15)) return GODE_E_ALIGN;
+        if (x_next == out) return GODE_E_SHAPE;
+        for (int j = 0; j < xin->n; ++j) if (xin->ptr[j] == x_next) return GODE_E_SHAPE;      // rows of xin are gathered by other blocks
+    } else next = nullptr;
     if (!gode_gcn_small_supported(f->n, f->d, f->groups)) return GODE_E_UNSUPPORTED;
     if (!f->A.rowptr || !f->A.col || !f->W) return GODE_E_NULLPTR;
     int rc = check_lincomb(xin, true); if (rc) return rc;
@@ -447,7 +483,7 @@ extern "C" int gode_gcn_feval_small_f32(const gode_gcn_odefunc_t* f, const gode_
     if (Y2) { rc = check_lincomb(cot, true); if (rc) return rc; } else cot = nullptr;
     if (!lincomb_aligned16(xin) || !lincomb_aligned16(pre) || !lincomb_aligned16(cot) ||
         ((((uintptr_t)out) | ((uintptr_t)Y2) | ((uintptr_t)f->gamma) | ((uintptr_t)f->beta) | ((uintptr_t)f->b)) & 15)) return GODE_E_ALIGN;
-    const LinComb lx = make_lincomb(xin), lp = make_lincomb(pre), lcot = make_lincomb(cot);
+    const LinComb lx = make_lincomb(xin), lp = make_lincomb(pre), lcot = make_lincomb(cot), lnext = make_lincomb(next);
     const int64_t d = f->d;
     const int cg = small_cg(d, f->groups);
     const dim3 grid((unsigned)feval_blocks(f->n));
@@ -455,7 +491,7 @@ extern "C" int gode_gcn_feval_small_f32(const gode_gcn_odefunc_t* f, const gode_
 #define GODE_FEV(DV, CGV) if (r4) GODE_FEV_(DV, CGV, 16) else GODE_FEV_(DV, CGV, 64)
 #define GODE_FEV_(DV, CGV, GWV) hipLaunchKernelGGL((gcn_feval_small_kernel<DV, CGV, GWV>), grid, dim3(256), 0, (hipStream_t)stream,         \
                                              f->A.rowptr, f->A.col, f->A.val, lx, (int)f->n, f->eps, f->gamma, f->beta, f->W,    \
-                                             f->b, t, alpha, lp, lcot, Y2, out);
+                                             f->b, t, alpha, lp, lcot, Y2, out, lnext, x_next);
     GODE_SMALL_DISPATCH(GODE_FEV)
 #undef GODE_FEV
 #undef GODE_FEV_

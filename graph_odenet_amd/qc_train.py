@@ -74,7 +74,11 @@ class TrainStep:
             if not by_index:
                 Etgt = (Etgt != 0).to(torch.uint8).argmax(0)         # one entry per edge column (the collate's layout)
             Etgt, batch = prepare(Esrc, Etgt, batch, x.shape[0], n_graphs)
-        self.opt.zero_grad(set_to_none=False)
+        # Without an exchange the gradients are DROPPED, not zeroed: autograd then hands every parameter its gradient
+        # tensor as it is (no fill launch before the step, no `grad += new` launch after it - ~2 x 25 launches of a
+        # ~300-launch step); optim.Adam takes the new addresses by value in its kernel arguments.  With an exchange the
+        # gradients are views of parallel.GradBucket's flat buffer and have to stay in place.
+        self.opt.zero_grad(set_to_none=self.exchange is None)
         loss = self.criterion(self.model(x, edge_feat, Esrc, Etgt, batch), target)
         loss.backward()
         if self.exchange is not None:

@@ -95,6 +95,40 @@ def test_ode_block_full_size_semigroup(rmat):
     assert f.nfe == 16 + 8 + 8 + 16
 
 
+def test_adjoint_bias_gradient_from_the_spmm_column_sums_full_size(rmat):
+    """The adjoint rk4 driver at the benchmark size: the bias gradient of every stage reduced from the per-block column
+    sums its forward-recompute SpMM leaves (option y2_colsum, the default) against the same solve with a column-sum pass
+    over dZ (option off): every other gradient bit for bit the same (nothing else changes), the bias gradient to fp32
+    summation accuracy (2^20 rows in another order)."""
+    from graph_odenet_amd import _lib, models, odeint as OI
+    lib = _lib.load()
+    torch.manual_seed(1)
+    f = models.ODEfunc(D).to(dev())
+    f.set_adj(rmat)
+    x0 = torch.randn(N, D, device=dev()).relu()
+    gout = torch.randn(N, D, generator=torch.Generator(device=dev()).manual_seed(2), device=dev())
+    res = {}
+    try:
+        for on in (1, 0):
+            assert lib.gode_set_option(b"y2_colsum", on) == 0 and lib.gode_get_option(b"y2_colsum") == on
+            x = x0.clone().requires_grad_(True)
+            for p in f.parameters():
+                p.grad = None
+            y = OI.odeint_adjoint(f, x, torch.tensor([0.0, 1.0]), method="rk4", options={"step_size": 0.5})[1]
+            y.backward(gout)
+            res[on] = (x.grad.clone(), {n: p.grad.clone() for n, p in f.named_parameters() if p.grad is not None})
+    finally:
+        lib.gode_set_option(b"y2_colsum", 1)
+    assert torch.equal(res[1][0], res[0][0])
+    differ = []
+    for n in res[1][1]:
+        a, b = res[1][1][n], res[0][1][n]
+        if not torch.equal(a, b):
+            differ.append(n)
+            assert rel(a, b) < 1e-5, n
+    assert set(differ) <= {"gc1.bias"}, differ
+
+
 def test_gat_record_kernels_full_size_properties(rmat):
     """Attention aggregation on the R-MAT edge list (record path): with constant projections every edge carries the
     same message, so out = relu(c) * s / (s + eps) row by row; the weights sum to the denominator; the VJP's node sums

@@ -16,7 +16,7 @@ import qc_bench
 
 dev = torch.device("cuda:0")
 model = sys.argv[1] if len(sys.argv) > 1 else "EdgeGCN_K_Sum"
-net, batches = qc_bench.build(dev, model, 0, 4, 20, by_index=True)
+net, batches = qc_bench.build(dev, model, 0, 4, 20)
 lib = _lib.load()
 seen = collections.Counter()
 real = lib.gode_gemm_f32

@@ -83,7 +83,7 @@ def run(dev, rank, world, backend, model="MPNN_ENN_K_Set2Set", steps=50, warmup=
     net, batches = build(dev, model, rank, steps + warmup, batch_size, bucket_pad, prepared)
     broadcast_parameters(net, 0)
     opt = Adam(net.parameters(), lr=1e-3)
-    bucket = GradBucket(net, overlap=not captured)
+    bucket = GradBucket(net, overlap=not captured) if (world > 1 or captured) else None     # one rank: gradients stay autograd's own tensors
     cstep = None
     if captured:
         from graph_odenet_amd.qc_step import CapturedQCStep
@@ -97,10 +97,11 @@ def run(dev, rank, world, backend, model="MPNN_ENN_K_Set2Set", steps=50, warmup=
             from graph_odenet_amd.qc_batch import prepare
             n_graphs = tgt.shape[0] + (1 if bucket_pad else 0)
             Etgt, batch = prepare(Esrc, Etgt, batch, x.shape[0], n_graphs)          # timed: part of every step
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad(set_to_none=bucket is None)                # (as qc_train.TrainStep: dropped, not zeroed, without an exchange)
         loss = F.mse_loss(net(x, ef, Esrc, Etgt, batch)[:tgt.shape[0]], tgt)
         loss.backward()
-        bucket.allreduce_mean()
+        if bucket is not None:
+            bucket.allreduce_mean()
         opt.step()
         return loss
 
@@ -131,7 +132,7 @@ def run(dev, rank, world, backend, model="MPNN_ENN_K_Set2Set", steps=50, warmup=
                                      ", one HIP-graph replay per step and bucket" if captured else ""),
                       "params": sum(p.numel() for p in net.parameters()),
                       "gradient_bytes_allreduced_per_step": 4 * bucket.flat.numel() if world > 1 else 0,
-                      "exchange_buckets": len(bucket.buckets)}}
+                      "exchange_buckets": len(bucket.buckets) if bucket is not None else 0}}
     if cstep is not None:
         res["config"]["shape_buckets_captured"] = sum(1 for b in cstep.buckets.values() if b.graph is not None)
         res["config"]["shape_buckets_seen"] = len(cstep.buckets)
