@@ -157,6 +157,8 @@ SIGNATURES = {
     "gode_gcn_small_part_len": (c_i64, [c_i64]),
     "gode_gcn_feval_small_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), ctypes.POINTER(LinComb), c_f, c_f, ctypes.POINTER(LinComb),
                                        ctypes.POINTER(LinComb), c_p, c_p, c_p]),
+    "gode_gcn_feval_small_next_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), ctypes.POINTER(LinComb), c_f, c_f, ctypes.POINTER(LinComb),
+                                            ctypes.POINTER(LinComb), c_p, c_p, ctypes.POINTER(LinComb), c_p, c_p]),
     "gode_gcn_vjp_small_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), ctypes.POINTER(LinComb), c_p, c_f, ctypes.POINTER(LinComb),
                                      c_p, c_p, c_p]),
     "gode_gcn_small_finish_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_f, c_p]),

@@ -840,52 +840,71 @@ __global__ __launch_bounds__(256) void time_row_fixup_kernel(float* __restrict__
 
 // ---------------- QC edge-conditioned messages ------------------------------------------------
 // block per target row v: M_v = sum_{(e,val) in row v} val * A_e * x[src_e]
+// An edge matrix goes through LDS in tiles of whole rows, read from memory as ONE flat run with every load of a thread in
+// flight (h = 73: the whole 21 KB matrix, 21 loads per thread), the next tile's loads (and the next edge's index, value
+// and source row) requested into registers BEFORE the current tile is multiplied; thread r then sums row r out of LDS.
+// (The first version gave a wave four matrix rows per trip: five dependent trips per edge with 4-8 loads in flight, then
+// a 24-step shuffle reduction - 37 us per launch for a 760-edge mini-batch whose matrices are 16 MB: a latency chain.)
+constexpr int kMsgTile = 8192;        // floats of LDS per tile (32 KB)
 __global__ __launch_bounds__(256) void edge_matvec_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                               const float* __restrict__ val, const int* __restrict__ src,
                                                               const float* __restrict__ A, const float* __restrict__ X,
                                                               int64_t ldx, int h, float* __restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;          // [h]
-    float* macc = smem + h;    // [h]
-    const int v = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < h; i += 256) macc[i] = 0.f;
-    for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
+    constexpr int PF = kMsgTile / 256, XP = 4096 / 256;           // registers of a prefetched tile / source row (h <= 4096)
+    const int hp = (h + 3) & ~3;
+    float* xs = smem;              // [h]
+    float* macc = smem + hp;       // [h]
+    float* tile = smem + 2 * hp;   // [rows per tile][h]
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int rb = rowptr[v], ne = rowptr[v + 1] - rb;
+    const int rpt = kMsgTile / h > 0 ? kMsgTile / h : 1, ntiles = (h + rpt - 1) / rpt, T = ne * ntiles;
+    for (int i = tid; i < h; i += 256) macc[i] = 0.f;
+    float pre[PF], xpre[XP], vv_next = 0.f, vv = 0.f;
+    auto issue = [&](int it) {
+        const int k = rb + it / ntiles, ti = it % ntiles;
         const int e = eid ? eid[k] : k;
-        const float vv = val ? val[k] : 1.f;
+        const int i0 = ti * rpt, run = min(rpt, h - i0) * h;
+        const float* Ar = A + (int64_t)e * h * h + (int64_t)i0 * h;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const int p = tid + 256 * u; pre[u] = p < run ? Ar[p] : 0.f; }
+        if (ti == 0) {
+            vv_next = val ? val[k] : 1.f;
+            const float* xr = X + (int64_t)src[e] * ldx;
+#pragma unroll
+            for (int u = 0; u < XP; ++u) { const int j = tid + 256 * u; xpre[u] = j < h ? xr[j] : 0.f; }
+        }
+    };
+    if (T > 0) issue(0);
+    for (int it = 0; it < T; ++it) {
+        const int ti = it % ntiles, i0 = ti * rpt, rows = min(rpt, h - i0), run = rows * h;
+        __syncthreads();                                           // the previous tile (and macc's zeros) are done with
+#pragma unroll
+        for (int u = 0; u < PF; ++u) { const int p = tid + 256 * u; if (p < run) tile[p] = pre[u]; }
+        if (ti == 0) {
+            vv = vv_next;
+#pragma unroll
+            for (int u = 0; u < XP; ++u) { const int j = tid + 256 * u; if (j < h) xs[j] = xpre[u]; }
+        }
         __syncthreads();
-        for (int j = threadIdx.x; j < h; j += 256) xs[j] = X[(int64_t)src[e] * ldx + j];
-        __syncthreads();
-        const float* Ae = A + (int64_t)e * h * h;
-        // four matrix rows per trip and wave: their loads are issued together and the four wave reductions interleave
-        // (one row at a time leaves two loads in flight per wave: 1.7 TB/s at E = 76 000, h = 73)
-        for (int i0 = wave * 4; i0 < h; i0 += 16) {
-            float s[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int j = lane; j < h; j += 64) {
-                const float xj = xs[j];
-                float av[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) av[r] = (i0 + r < h) ? Ae[(int64_t)(i0 + r) * h + j] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[r] = fmaf(av[r], xj, s[r]);
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[r] += __shfl_xor(s[r], off, 64);
-            }
-            if (lane < 4 && i0 + lane < h) macc[i0 + lane] += vv * s[lane];     // rows i0..i0+3 belong to this wave only
+        if (it + 1 < T) issue(it + 1);                             // in flight while this tile is multiplied
+        for (int r = tid; r < rows; r += 256) {
+            const float* row = tile + r * h;
+            float s0 = 0.f, s1 = 0.f;
+            int j = 0;
+            for (; j + 1 < h; j += 2) { s0 = fmaf(row[j], xs[j], s0); s1 = fmaf(row[j + 1], xs[j + 1], s1); }
+            if (j < h) s0 = fmaf(row[j], xs[j], s0);
+            macc[i0 + r] += vv * (s0 + s1);                        // row i0 + r belongs to this thread in every tile of every edge
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < h; i += 256) out[(int64_t)v * ldo + i] = macc[i];
+    for (int i = tid; i < h; i += 256) out[(int64_t)v * ldo + i] = macc[i];
 }
 
 // block per edge e: msg[e, :] = A_e * x[src_e]  (large batches: every edge matrix is streamed by its own workgroup and
 // the per-target sum is a separate SpMM over Etgt; the fused per-target kernel above serialises a target's edges).
 // The matrix goes through LDS in tiles of whole rows, read from memory as one flat run (all loads of a tile in flight,
 // full-width accesses whatever h is); thread i then sums row i out of LDS - no cross-lane reduction.
-constexpr int kMsgTile = 8192;        // floats of LDS per tile (32 KB)
 __global__ __launch_bounds__(256) void edge_matvec_msg_kernel(const int* __restrict__ src, const float* __restrict__ A,
                                                               const float* __restrict__ X, int64_t ldx, int h,
                                                               float* __restrict__ msg) {
@@ -1568,7 +1587,10 @@ extern "C" int gode_edge_matvec_f32_fwd(const int32_t* rowptr, const int32_t* ei
     if (n_rows == 0) return 0;
     if (!rowptr || !eid || !src || !A || !X || !out) return GODE_E_NULLPTR;
     if (n_rows > INT32_MAX || h > 4096) return GODE_E_RANGE;
-    hipLaunchKernelGGL(edge_matvec_fwd_kernel, dim3((unsigned)n_rows), dim3(256), (size_t)2 * h * sizeof(float),
+    const int64_t rpt = kMsgTile / h > 0 ? kMsgTile / h : 1;
+    const size_t lds = (size_t)(2 * ((h + 3) & ~(int64_t)3) + (rpt < h ? rpt : h) * h) * sizeof(float);
+    if (lds > 48 * 1024) { const int rc = gode_set_lds_once((const void*)edge_matvec_fwd_kernel, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(edge_matvec_fwd_kernel, dim3((unsigned)n_rows), dim3(256), lds,
                        (hipStream_t)stream, rowptr, eid, val, src, A, X, ldx, (int)h, out, ldo);
     GODE_LAUNCH_CHECK();
     return 0;

@@ -376,9 +376,10 @@ gode_lincomb_t dp_terms(const float* y, float* const* k, const double* coef, int
     return lc;
 }
 
+// next / x_next (fused launch-bound path only): the stage's launch also writes the next stage's combined input
 int dp_eval_forward(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws, const gode_lincomb_t* yin, float t,
-                    float* k_out, void* stream) {
-    if (fused_small(f)) return gode_gcn_feval_small_f32(f, yin, t, 1.f, nullptr, nullptr, nullptr, k_out, stream);
+                    float* k_out, const gode_lincomb_t* next, float* x_next, void* stream) {
+    if (fused_small(f)) return gode_gcn_feval_small_next_f32(f, yin, t, 1.f, nullptr, nullptr, nullptr, k_out, next, x_next, stream);
     GODE_TRY(gode_gn_time_gemm_f32(yin, f->n, f->d, f->groups, f->eps, f->gamma, f->beta, f->W, f->d, 1, t, ws->S, stream));
     gode_spmm_epilogue_t ep = {};
     ep.bias = f->b; ep.relu = 1; ep.alpha = 1.f;
@@ -388,11 +389,12 @@ int dp_eval_forward(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws,
 // One evaluation of the augmented adjoint field: k_y = f(t, y), k_a = -a^T df/dy, k_theta = [-a^T df/dW | .. b | .. gamma |
 // .. beta | -a^T df/dt]  (the launch sequence of GcnOdeAdjointField._stage, single stream).
 int dp_eval_adjoint(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws, gode_lincomb_t yin,
-                    const gode_lincomb_t& ain, float t, float* ky, float* ka, float* kth, void* stream) {
+                    const gode_lincomb_t& ain, float t, float* ky, float* ka, float* kth, const gode_lincomb_t* next,
+                    float* x_next, void* stream) {
     const int64_t n = f->n, d = f->d, nW = (d + 1) * d, P = gode_gcn_ode_theta_len(d);
     if (fused_small(f) && ws->small_part) {
         const gode_lincomb_t cot = negated(ain);
-        GODE_TRY(gode_gcn_feval_small_f32(f, &yin, t, 1.f, nullptr, &cot, ws->dZ, ky, stream));
+        GODE_TRY(gode_gcn_feval_small_next_f32(f, &yin, t, 1.f, nullptr, &cot, ws->dZ, ky, next, x_next, stream));
         GODE_TRY(gode_gcn_vjp_small_f32(f, &yin, ws->dZ, 1.f, nullptr, ka, ws->small_part, stream));
         return gode_gcn_small_finish_f32(f, ws->small_part, kth, t, stream);
     }
@@ -434,9 +436,16 @@ extern "C" int gode_gcn_ode_dopri5_step_forward(const gode_gcn_odefunc_t* f, con
     for (int s = 0; s < 7; ++s) if (!k[s]) return GODE_E_NULLPTR;
     if (!ws->S) return GODE_E_NULLPTR;
     const int64_t nd = f->n * f->d;
+    // launch-bound graphs: from the second stage on a stage reads its combined input from X[s & 1], written row by row by
+    // the stage before it (same multiply-adds in the same order as combining the terms on the fly: bit-identical)
+    const bool chain = fused_small(f) && ws->X[0] && ws->X[1];
     for (int s = 1; s < 7; ++s) {
         gode_lincomb_t yin = dp_terms(y, k, DPA[s], s, h, true);
-        GODE_TRY(dp_eval_forward(f, ws, &yin, (float)(t + DPC[s] * h), k[s], stream));
+        if (chain && s >= 2) { yin.n = 1; yin.coef[0] = 1.f; yin.ptr[0] = ws->X[s & 1]; }
+        gode_lincomb_t nxt; nxt.n = 0;
+        if (chain && s < 6) nxt = dp_terms(y, k, DPA[s + 1], s + 1, h, true);
+        GODE_TRY(dp_eval_forward(f, ws, &yin, (float)(t + DPC[s] * h), k[s], nxt.n > 0 ? &nxt : nullptr,
+                                 nxt.n > 0 ? ws->X[(s + 1) & 1] : nullptr, stream));
     }
     gode_lincomb_t sol = dp_terms(y, k, DPB, 7, h, true);
     GODE_TRY(gode_lincomb_f32(y1, &sol, nd, stream));
@@ -457,10 +466,15 @@ extern "C" int gode_gcn_ode_dopri5_step_adjoint(const gode_gcn_odefunc_t* f, con
     if (!ws->S || !ws->dZ || !ws->dS || !ws->wpart || !ws->colsum_scratch) return GODE_E_NULLPTR;
     if (f->groups > 0 && (!ws->gpart || !ws->bpart)) return GODE_E_NULLPTR;
     const int64_t nd = f->n * f->d, P = gode_gcn_ode_theta_len(f->d);
+    const bool chain = fused_small(f) && ws->small_part && ws->X[0] && ws->X[1];       // as in the forward step
     for (int s = 1; s < 7; ++s) {
         gode_lincomb_t yin = dp_terms(y, ky, DPA[s], s, h, true);
+        if (chain && s >= 2) { yin.n = 1; yin.coef[0] = 1.f; yin.ptr[0] = ws->X[s & 1]; }
         gode_lincomb_t ain = dp_terms(a, ka, DPA[s], s, h, true);
-        GODE_TRY(dp_eval_adjoint(f, ws, yin, ain, (float)(t + DPC[s] * h), ky[s], ka[s], kth[s], stream));
+        gode_lincomb_t nxt; nxt.n = 0;
+        if (chain && s < 6) nxt = dp_terms(y, ky, DPA[s + 1], s + 1, h, true);
+        GODE_TRY(dp_eval_adjoint(f, ws, yin, ain, (float)(t + DPC[s] * h), ky[s], ka[s], kth[s], nxt.n > 0 ? &nxt : nullptr,
+                                 nxt.n > 0 ? ws->X[(s + 1) & 1] : nullptr, stream));
     }
     gode_lincomb_t sy = dp_terms(y, ky, DPB, 7, h, true), sa = dp_terms(a, ka, DPB, 7, h, true),
                    st = dp_terms(theta, kth, DPB, 7, h, true);

@@ -78,6 +78,11 @@ class _Shared:
         ws.S = self.S.data_ptr()
         for i in range(4):
             ws.ky[i] = ky[i].data_ptr()
+        if not adjoint and _lib.load().gode_gcn_small_supported(self.n, self.d, int(groups)):
+            # launch-bound graphs: the dopri5 step driver chains the stage inputs through this pair (csrc/ode_driver.hip)
+            if getattr(self, "X2", None) is None:
+                self.X2 = [torch.empty_like(self.S), torch.empty_like(self.S)]
+            ws.X[0], ws.X[1] = self.X2[0].data_ptr(), self.X2[1].data_ptr()
         if adjoint:
             dZ, dS = self.bwd()
             ws.dZ, ws.dS = dZ.data_ptr(), dS.data_ptr()
@@ -220,17 +225,22 @@ def small_fused(spec):
                 and lib.gode_gcn_small_supported(spec.graph.n_rows, spec.d, spec.groups))
 
 
-def _feval_small(spec, t, terms, out, pre=None, alpha=1.0, cot=None, out2=None):
+def _feval_small(spec, t, terms, out, pre=None, alpha=1.0, cot=None, out2=None, next_terms=None, x_next=None):
+    """next_terms / x_next: the launch also writes the next stage's combined input (a term that is `out` itself is this
+    launch's result) - what the C dopri5 step driver does between its stages."""
     lib = _lib.load()
     fs = _func_struct(spec)
     lx = _lib.lincomb(terms)
     lp = _lib.lincomb(pre) if pre is not None else None
     lc = _lib.lincomb(cot) if cot is not None else None
-    _lib.check(lib.gode_gcn_feval_small_f32(ctypes.byref(fs), ctypes.byref(lx), float(t), float(alpha),
-                                            ctypes.byref(lp) if lp is not None else None,
-                                            ctypes.byref(lc) if lc is not None else None,
-                                            _lib.ptr(out2) if cot is not None else None, _lib.ptr(out), _lib.stream_ptr()),
-               "gode_gcn_feval_small_f32")
+    ln = _lib.lincomb(next_terms) if next_terms is not None else None
+    _lib.check(lib.gode_gcn_feval_small_next_f32(ctypes.byref(fs), ctypes.byref(lx), float(t), float(alpha),
+                                                 ctypes.byref(lp) if lp is not None else None,
+                                                 ctypes.byref(lc) if lc is not None else None,
+                                                 _lib.ptr(out2) if cot is not None else None, _lib.ptr(out),
+                                                 ctypes.byref(ln) if ln is not None else None,
+                                                 _lib.ptr(x_next) if ln is not None else None, _lib.stream_ptr()),
+               "gode_gcn_feval_small_next_f32")
 
 
 class GcnOdeField(Field):

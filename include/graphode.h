@@ -508,6 +508,13 @@ int64_t gode_gcn_small_part_len(int64_t d);
 int gode_gcn_feval_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin /* host */, float t, float alpha,
                              const gode_lincomb_t* pre /* host, nullable */, const gode_lincomb_t* cot /* host, with Y2 */,
                              float* Y2 /* nullable */, float* out, void* stream);
+/* the same launch, which also writes the NEXT stage's combined input x_next = sum_j next.coef[j] * next.ptr[j] row by row
+ * (a term that names `out` is this launch's result): the next evaluation then gathers one array per neighbour instead
+ * of one per term of its stage input.  x_next must not be `out` or a term of xin.  next, x_next nullable together. */
+int gode_gcn_feval_small_next_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin /* host */, float t, float alpha,
+                                  const gode_lincomb_t* pre /* host, nullable */, const gode_lincomb_t* cot /* host, with Y2 */,
+                                  float* Y2 /* nullable */, float* out, const gode_lincomb_t* next /* host */, float* x_next,
+                                  void* stream);
 int gode_gcn_vjp_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xin /* host */, const float* dZ,
                            float out_scale, const gode_lincomb_t* pre /* host, nullable */, float* ka, float* part,
                            void* stream);

@@ -766,11 +766,58 @@ def test_native_dopri5_step_matches_python_driver(d):
         finally:
             SV.DOPRI5_NATIVE = True
     assert res[True][3] == res[False][3] and res[True][4] == res[False][4] and res[True][3] >= 14
+    if d == 16:     # launch-bound path: the C driver chains the stage inputs through a buffer pair, the Python driver combines
+        assert torch.equal(res[True][0], res[False][0])          # them while gathering - the same bits (csrc/small.hip)
     close(res[True][0], res[False][0], 1e-6, "state")
     close(res[True][1], res[False][1], 1e-5, "gx")
     tol = 1e-4 if d == 16 else 1e-5          # d = 16: one channel per GroupNorm group (noise-floor gradients)
     for a, b in zip(res[True][2], res[False][2]):
         close(a, b, tol, "param grad")
+
+
+@pytest.mark.parametrize("d,n", [(16, 2000), (32, 9000)])
+def test_small_feval_writes_the_next_stage_input_bit_for_bit(d, n):
+    """gode_gcn_feval_small_next_f32 (what the C dopri5 step driver does between the stages of a launch-bound step): a
+    stage's launch also writes the NEXT stage's combined input y + h sum_j a_j k_j row by row, the term it has just computed
+    taken from the register; the next evaluation then gathers that one array.  Same multiply-adds in the same order as
+    combining the term list while gathering: the next stage's output is bit for bit the same either way, and the
+    stage's own outputs do not change."""
+    from graph_odenet_amd import gcn_ode, graph as G
+    gen = torch.Generator().manual_seed(d + n)
+    r = torch.randint(0, n, (5 * n,), generator=gen); c = torch.randint(0, n, (5 * n,), generator=gen)
+    key = torch.unique(r * n + c)
+    r, c = key // n, key % n
+    v = torch.rand(key.numel(), generator=gen) + 0.1
+    g = G.from_coo(r.to(dev()), c.to(dev()), v.to(dev()), n, n)
+    f = dict(dtype=torch.float32, device=dev())
+    W = (torch.randn(d + 1, d, generator=gen) / d ** 0.5).to(dev())
+    b, gam, bet = (torch.randn(d, generator=gen) * 0.1).to(dev()), (torch.rand(d, generator=gen) + 0.5).to(dev()), (torch.rand(d, generator=gen) - 0.5).to(dev())
+    spec = gcn_ode.GcnOdeSpec(g, W, b, gam, bet, min(32, d), 1e-5)
+    y = torch.randn(n, d, generator=gen).to(dev()).relu()
+    k = [torch.randn(n, d, generator=gen).to(dev()) for _ in range(3)]
+    h = 0.37
+    terms_s = [(1.0, y), (h * 0.3, k[0]), (h * -0.9, k[1])]                 # stage s: three terms
+    k_s_plain = torch.empty(n, d, **f)
+    gcn_ode._feval_small(spec, 0.4, terms_s, k_s_plain)
+    # stage s + 1 names the result of stage s among its terms
+    k_s, x_next = torch.empty(n, d, **f), torch.full((n, d), float("nan"), **f)
+    terms_next = [(1.0, y), (h * 0.2, k[0]), (h * 1.1, k_s), (h * -0.4, k[2])]
+    cot = [(-1.0, k[2])]
+    dz_plain, dz = torch.empty(n, d, **f), torch.empty(n, d, **f)
+    gcn_ode._feval_small(spec, 0.4, terms_s, k_s_plain, cot=cot, out2=dz_plain)
+    gcn_ode._feval_small(spec, 0.4, terms_s, k_s, cot=cot, out2=dz, next_terms=terms_next, x_next=x_next)
+    assert torch.equal(k_s, k_s_plain) and torch.equal(dz, dz_plain)
+    want = y + (h * 0.2) * k[0] + (h * 1.1) * k_s + (h * -0.4) * k[2]
+    assert (x_next - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    out_terms, out_chain = torch.empty(n, d, **f), torch.empty(n, d, **f)
+    gcn_ode._feval_small(spec, 0.6, terms_next, out_terms)                  # term list combined while gathering
+    gcn_ode._feval_small(spec, 0.6, [(1.0, x_next)], out_chain)             # the one array
+    assert torch.equal(out_chain, out_terms)
+    # refused: writing the next input over an array this launch gathers from, or over its own output
+    with pytest.raises(Exception):
+        gcn_ode._feval_small(spec, 0.4, terms_s, k_s, next_terms=terms_next, x_next=y)
+    with pytest.raises(Exception):
+        gcn_ode._feval_small(spec, 0.4, terms_s, k_s, next_terms=terms_next, x_next=k_s)
 
 
 @pytest.mark.parametrize("d", [16, 128])

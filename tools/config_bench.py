@@ -251,7 +251,7 @@ def c4_qc(dev, model_name, cpu=True, n_timed=100):
     return res
 
 
-def all_configs(dev, cpu=True):
+def all_configs(dev, cpu=True, only=None):
     out = {}
     for key, fn in (("C1_cora_gcn_ode_rk4", lambda: c1_cora(dev, cpu)),
                     ("C2_pubmed_dense_paper_ode_dopri5", lambda: c2_pubmed(dev, cpu)),
@@ -259,6 +259,8 @@ def all_configs(dev, cpu=True):
                     ("C3_citeseer_gat_1head_ode_rk4", lambda: c3_citeseer_gat(dev, 1, 16, cpu)),
                     ("C4_qc_edge_gcn_sum", lambda: c4_qc(dev, "EdgeGCN_K_Sum", cpu)),
                     ("C4_qc_mpnn_enn_set2set", lambda: c4_qc(dev, "MPNN_ENN_K_Set2Set", cpu))):
+        if only and not any(key.startswith(o) for o in only):
+            continue
         try:
             out[key] = fn()
         except Exception as e:                     # a secondary number must never take the contract line down
@@ -271,4 +273,5 @@ if __name__ == "__main__":
     # stand-alone, and as bench.py's child process (a fresh process: HIP-graph captures of arbitrary autograd stay away
     # from the process that has to print the contract line): one JSON object on the LAST line of stdout
     cpu_leg = "--no-cpu" not in sys.argv
-    print(json.dumps(all_configs(torch.device("cuda:0"), cpu=cpu_leg), indent=None if "--one-line" in sys.argv else 1))
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]          # e.g. C4 or C2_pubmed (development)
+    print(json.dumps(all_configs(torch.device("cuda:0"), cpu=cpu_leg, only=only), indent=None if "--one-line" in sys.argv else 1))
