@@ -132,6 +132,8 @@ SIGNATURES = {
     "gode_rect_wgrad_parts": (c_i64, [c_i64]),
     "gode_rect_wgrad_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p]),
     "gode_gemm_f32": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p, c_i64, c_p]),
+    "gode_gemm_splitk_parts": (c_i64, [c_i64, c_i64, c_i64]),
+    "gode_gemm_splitk_f32": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "gode_cut_pad": (c_i64, [c_i64]),
     "gode_cut_bf16x3_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "gode_pgemm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
@@ -162,6 +164,7 @@ SIGNATURES = {
     "gode_gcn_vjp_small_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), ctypes.POINTER(LinComb), c_p, c_f, ctypes.POINTER(LinComb),
                                      c_p, c_p, c_p]),
     "gode_gcn_small_finish_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_f, c_p]),
+    "gode_gcn_small_finish_multi_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, ctypes.c_int32, ctypes.POINTER(c_p), ctypes.POINTER(c_f), c_p]),
     "gode_gcn_small_finish4_f32": (c_i, [ctypes.POINTER(GcnOdeFunc), c_p, c_p, c_p, c_p, c_p]),
     "gode_wgrad_parts": (c_i64, [c_i64]),
     "gode_wgrad_f32": (c_i, [ctypes.POINTER(LinComb), c_i64, c_i64, ctypes.c_int32, c_f, c_p, c_p,

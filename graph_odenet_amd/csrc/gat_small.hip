@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void gat_dense_vjp_small_kernel(LinComb xin, i
                                                                  const float* __restrict__ packed_t)
 {
     using S = GatVjpShape<D, NLP>;
-    constexpr int LPR = S::LPR, SG = S::SG, NS = S::NS, NSL = S::NSL, NIN = S::NIN, nW = (D + 1) * D;
+    constexpr int LPR = S::LPR, SG = S::SG, NS = S::NS, NSL = S::NSL, NIN = S::NIN;
     // Wt[c][k] = W(k + 1, c) over the 2 D + NLP input columns c; the same storage holds the block partial afterwards
     __shared__ __attribute__((aligned(16))) float buf[S::BUF];
     __shared__ __attribute__((aligned(16))) float dsrow[4][NIN];

@@ -74,9 +74,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                                                           const float* __restrict__ B, int64_t ldb,
                                                           float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                           const float* __restrict__ bias, int relu,
-                                                          const float* __restrict__ mask, int64_t ldmask)
+                                                          const float* __restrict__ mask, int64_t ldmask,
+                                                          int k_chunk, int64_t c_zstride)
 {
     constexpr int TM = 64 * MT, TN = 64 * NTW;                    // block tile rows / columns
+    // gridDim.z > 1: block z multiplies the k range [z k_chunk, (z + 1) k_chunk) and writes its raw partial product to
+    // C + z c_zstride (gode_gemm_splitk_f32: tall contractions with a handful of output tiles)
+    const int kbeg = blockIdx.z * k_chunk, kend = min(K, kbeg + k_chunk);
+    C += blockIdx.z * c_zstride;
     constexpr int LDA = TM + 1, LDB = TN + 1;
     __shared__ float As[2][BK * LDA];
     __shared__ float Bs[2][BK * LDB];
@@ -92,16 +97,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     float ra[TM * BK / 256], rb[TN * BK / 256];
-    tile_load<A_KC, TM, BK>(A, lda, m0, M, 0, K, ra);
-    tile_load<B_KC, TN, BK>(B, ldb, n0, N, 0, K, rb);
+    tile_load<A_KC, TM, BK>(A, lda, m0, M, kbeg, kend, ra);
+    tile_load<B_KC, TN, BK>(B, ldb, n0, N, kbeg, kend, rb);
     tile_store<A_KC, TM, BK>(As[0], ra);
     tile_store<B_KC, TN, BK>(Bs[0], rb);
     __syncthreads();
-    const int n_kt = (K + BK - 1) / BK;
+    const int n_kt = (kend - kbeg + BK - 1) / BK;
     for (int kt = 0; kt < n_kt; ++kt) {
         const int cur = kt & 1;
-        tile_load<A_KC, TM, BK>(A, lda, m0, M, (kt + 1) * BK, K, ra);     // next tile (zeros past K): in flight during the
-        tile_load<B_KC, TN, BK>(B, ldb, n0, N, (kt + 1) * BK, K, rb);     // matrix phase
+        tile_load<A_KC, TM, BK>(A, lda, m0, M, kbeg + (kt + 1) * BK, kend, ra);     // next tile (zeros past the range): in flight
+        tile_load<B_KC, TN, BK>(B, ldb, n0, N, kbeg + (kt + 1) * BK, kend, rb);     // during the matrix phase
         const float* as = As[cur] + lk * LDA + wm + li;
         const float* bs = Bs[cur] + lk * LDB + wn + li;
 #pragma unroll
@@ -209,7 +214,8 @@ extern "C" int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
     if (grid.y > 65535) return GODE_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
 #define GODE_GEMM2(AKC, BKC, MTV, NTV, BKV) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, MTV, NTV, BKV>), grid, dim3(256), 0, s, A, lda, \
-                                                               B, ldb, C, ldc, (int)M, (int)N, (int)K, bias, relu ? 1 : 0, mask, ldmask)
+                                                               B, ldb, C, ldc, (int)M, (int)N, (int)K, bias, relu ? 1 : 0, mask, ldmask, \
+                                                               (int)K, (int64_t)0)
 #define GODE_GEMM(AKC, BKC) { if (shape == 22) GODE_GEMM2(AKC, BKC, 2, 2, 16); else if (shape == 12) GODE_GEMM2(AKC, BKC, 1, 2, 32); \
                               else GODE_GEMM2(AKC, BKC, 1, 1, 32); }
     if (!trans_a && !trans_b) GODE_GEMM(true, false)
@@ -218,6 +224,47 @@ extern "C" int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
     else GODE_GEMM(false, true)
 #undef GODE_GEMM
 #undef GODE_GEMM2
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Tall contractions with a handful of output tiles (weight gradients x^T dy of the QC models' small layers: 73 x 42 from
+// 380 rows, 5 x 2667 from 760): one block per output tile walks the whole contraction, 12-24 dependent k-steps - 15-28 us
+// for a few MFLOP.  Here the contraction is cut into parts of >= 64 (a multiple of 32) and block (x, y, z) writes the
+// raw product of part z to part[z][M][N]; the caller adds the parts (gode_reduce_parts_f32: fixed order).
+static int splitk_chunk(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K < 192) return 0;
+    const int64_t tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles > 64) return 0;
+    int64_t parts = K / 64;
+    if (parts > 16) parts = 16;
+    while (parts > 1 && tiles * parts > 1024) --parts;
+    if (parts < 2) return 0;
+    return (int)((((K + parts - 1) / parts) + 31) & ~(int64_t)31);
+}
+extern "C" int64_t gode_gemm_splitk_parts(int64_t M, int64_t N, int64_t K) {
+    const int ch = splitk_chunk(M, N, K);
+    return ch > 0 ? (K + ch - 1) / ch : 1;
+}
+extern "C" int gode_gemm_splitk_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                    const float* B, int64_t ldb, float* part, void* stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return GODE_E_SHAPE;
+    if (!A || !B || !part) return GODE_E_NULLPTR;
+    if (M > INT32_MAX - 256 || N > INT32_MAX - 256 || K > INT32_MAX - 256) return GODE_E_RANGE;
+    if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N)) return GODE_E_SHAPE;
+    const int ch = splitk_chunk(M, N, K);
+    if (ch <= 0) return GODE_E_UNSUPPORTED;                       // gode_gemm_splitk_parts says 1: use gode_gemm_f32
+    const int64_t parts = (K + ch - 1) / ch;
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)parts);
+    hipStream_t s = (hipStream_t)stream;
+#define GODE_GEMMK(AKC, BKC) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, 1, 1, 32>), grid, dim3(256), 0, s, A, lda, B, ldb, part, N, \
+                                                (int)M, (int)N, (int)K, (const float*)nullptr, 0, (const float*)nullptr, (int64_t)0, ch, M * N)
+    if (!trans_a && !trans_b) GODE_GEMMK(true, false);
+    else if (!trans_a && trans_b) GODE_GEMMK(true, true);
+    else if (trans_a && !trans_b) GODE_GEMMK(false, false);
+    else GODE_GEMMK(false, true);
+#undef GODE_GEMMK
     GODE_LAUNCH_CHECK();
     return 0;
 }

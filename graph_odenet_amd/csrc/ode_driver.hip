@@ -388,15 +388,19 @@ int dp_eval_forward(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws,
 
 // One evaluation of the augmented adjoint field: k_y = f(t, y), k_a = -a^T df/dy, k_theta = [-a^T df/dW | .. b | .. gamma |
 // .. beta | -a^T df/dt]  (the launch sequence of GcnOdeAdjointField._stage, single stream).
+// part_slot >= 0 (fused path): the stage's block partials go to that slot of ws->small_part and the caller closes all
+// stages of the step in one launch (gode_gcn_small_finish_multi_f32); -1: the stage is closed here
 int dp_eval_adjoint(const gode_gcn_odefunc_t* f, const gode_rk4_workspace_t* ws, gode_lincomb_t yin,
                     const gode_lincomb_t& ain, float t, float* ky, float* ka, float* kth, const gode_lincomb_t* next,
-                    float* x_next, void* stream) {
+                    float* x_next, int part_slot, void* stream) {
     const int64_t n = f->n, d = f->d, nW = (d + 1) * d, P = gode_gcn_ode_theta_len(d);
     if (fused_small(f) && ws->small_part) {
         const gode_lincomb_t cot = negated(ain);
         GODE_TRY(gode_gcn_feval_small_next_f32(f, &yin, t, 1.f, nullptr, &cot, ws->dZ, ky, next, x_next, stream));
-        GODE_TRY(gode_gcn_vjp_small_f32(f, &yin, ws->dZ, 1.f, nullptr, ka, ws->small_part, stream));
-        return gode_gcn_small_finish_f32(f, ws->small_part, kth, t, stream);
+        float* part = ws->small_part + (part_slot > 0 ? part_slot : 0) * gode_gcn_small_parts(n) * gode_gcn_small_part_len(d);
+        GODE_TRY(gode_gcn_vjp_small_f32(f, &yin, ws->dZ, 1.f, nullptr, ka, part, stream));
+        if (part_slot >= 0) return 0;
+        return gode_gcn_small_finish_f32(f, part, kth, t, stream);
     }
     float* xo = (yin.n >= 3 && ws->X[0]) ? ws->X[0] : nullptr;
     GODE_TRY(gode_gn_time_gemm_xout_f32(&yin, n, d, f->groups, f->eps, f->gamma, f->beta, f->W, d, 1, t, ws->S, xo, stream));
@@ -466,7 +470,8 @@ extern "C" int gode_gcn_ode_dopri5_step_adjoint(const gode_gcn_odefunc_t* f, con
     if (!ws->S || !ws->dZ || !ws->dS || !ws->wpart || !ws->colsum_scratch) return GODE_E_NULLPTR;
     if (f->groups > 0 && (!ws->gpart || !ws->bpart)) return GODE_E_NULLPTR;
     const int64_t nd = f->n * f->d, P = gode_gcn_ode_theta_len(f->d);
-    const bool chain = fused_small(f) && ws->small_part && ws->X[0] && ws->X[1];       // as in the forward step
+    const bool fused = fused_small(f) && ws->small_part;
+    const bool chain = fused && ws->X[0] && ws->X[1];                                   // as in the forward step
     for (int s = 1; s < 7; ++s) {
         gode_lincomb_t yin = dp_terms(y, ky, DPA[s], s, h, true);
         if (chain && s >= 2) { yin.n = 1; yin.coef[0] = 1.f; yin.ptr[0] = ws->X[s & 1]; }
@@ -474,7 +479,12 @@ extern "C" int gode_gcn_ode_dopri5_step_adjoint(const gode_gcn_odefunc_t* f, con
         gode_lincomb_t nxt; nxt.n = 0;
         if (chain && s < 6) nxt = dp_terms(y, ky, DPA[s + 1], s + 1, h, true);
         GODE_TRY(dp_eval_adjoint(f, ws, yin, ain, (float)(t + DPC[s] * h), ky[s], ka[s], kth[s], nxt.n > 0 ? &nxt : nullptr,
-                                 nxt.n > 0 ? ws->X[(s + 1) & 1] : nullptr, stream));
+                                 nxt.n > 0 ? ws->X[(s + 1) & 1] : nullptr, fused ? s - 1 : -1, stream));
+    }
+    if (fused) {      // the six stages' small components in one launch: nothing inside the step reads them
+        float* kout[6]; float tsv[6];
+        for (int s = 1; s < 7; ++s) { kout[s - 1] = kth[s]; tsv[s - 1] = (float)(t + DPC[s] * h); }
+        GODE_TRY(gode_gcn_small_finish_multi_f32(f, ws->small_part, 6, kout, tsv, stream));
     }
     gode_lincomb_t sy = dp_terms(y, ky, DPB, 7, h, true), sa = dp_terms(a, ka, DPB, 7, h, true),
                    st = dp_terms(theta, kth, DPB, 7, h, true);

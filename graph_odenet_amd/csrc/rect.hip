@@ -52,32 +52,60 @@ __global__ __launch_bounds__(256) void rect_gemm_kernel(const float* __restrict_
         f32x4 acc[NT];
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < inner; k0 += 16) {
-            // memory layout (lane m: row m >> 2, floats 4 (m & 3) .. + 3 of the 16-wide k chunk: four lanes cover the 64
-            // contiguous bytes of a row) in both cases; rows that are not 16-byte aligned (K = 3703, 1433) take four dword
-            // loads per lane instead of one 16-byte load.  (The first version read unaligned operands in the MFMA layout -
-            // adjacent lanes 4 K bytes apart: 0.68 ms for Citeseer's 3327 x 3703 input layer.)
-            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            {
-                const int row = tile * 16 + mr, k = k0 + 4 * mg;
-                if (row < n_rows && k < inner) {
-                    const float* p = in + (int64_t)row * ld_in + k;
-                    if (VEC && k + 3 < inner) xv = ld4(p);
-                    else { xv.x = p[0]; if (k + 1 < inner) xv.y = p[1]; if (k + 2 < inner) xv.z = p[2]; if (k + 3 < inner) xv.w = p[3]; }
-                }
-                xv = to_f_layout(xv, to_f);
+        // One 16-wide k chunk: the streamed operand in the memory layout (lane m: row m >> 2, floats 4 (m & 3) .. + 3 of
+        // the chunk: four lanes cover the 64 contiguous bytes of a row; rows that are not 16-byte aligned - K = 3703,
+        // 1433, 73 - take four dword loads per lane instead of one 16-byte load; the first version read unaligned
+        // operands in the MFMA layout, adjacent lanes 4 K bytes apart: 0.68 ms for Citeseer's 3327 x 3703 input layer) and
+        // the 4 x NT weight values of the chunk's MFMAs.  The NEXT chunk is requested before the current one is
+        // multiplied: on a short operand (a QM9 mini-batch: 380 rows, K = 73 - every wave has ONE tile) the loop was a
+        // chain of five load round trips, 34 us per launch.
+        // Every load of a chunk is unconditional, from clamped coordinates (a load under a branch is waited for at the
+        // join, which would put the wait in front of the MFMAs); out-of-range values are zeroed when they are used.
+        float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+        float wn[4][NT];
+        const int row = tile * 16 + mr, rowc = row < n_rows ? row : n_rows - 1;
+        auto fetch = [&](int k0) {
+            const int k = k0 + 4 * mg;
+            const float* p = in + (int64_t)rowc * ld_in;
+            if (VEC) {                                            // rows are 16-byte aligned and ld % 4 == 0: the clamped chunk lies inside the row
+                const int k4 = k < inner ? k : ((inner - 1) & ~3);
+                xn = ld4(p + k4);
+            } else {
+                xn.x = p[k < inner ? k : inner - 1]; xn.y = p[k + 1 < inner ? k + 1 : inner - 1];
+                xn.z = p[k + 2 < inner ? k + 2 : inner - 1]; xn.w = p[k + 3 < inner ? k + 3 : inner - 1];
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int k = k0 + 4 * g + c;
-                const float xb = c == 0 ? xv.x : (c == 1 ? xv.y : (c == 2 ? xv.z : xv.w));
+                const int kk = k0 + 4 * g + c, kc = kk < inner ? kk : inner - 1;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const int col = c_base + 16 * tt + r;
-                    float a = 0.f;
-                    if (k < inner && col < n_out) a = TRANSW ? W[(int64_t)col * w_ld + k] : W[(int64_t)k * w_ld + col];
-                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xb, acc[tt], 0, 0, 0);
+                    const int col = c_base + 16 * tt + r, cc = col < n_out ? col : n_out - 1;
+                    wn[c][tt] = TRANSW ? W[(int64_t)cc * w_ld + kc] : W[(int64_t)kc * w_ld + cc];
                 }
+            }
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < inner; k0 += 16) {
+            float4 xv = xn;
+            {
+                const int k = k0 + 4 * mg;
+                const bool rok = row < n_rows;
+                xv.x = (rok && k < inner) ? xv.x : 0.f; xv.y = (rok && k + 1 < inner) ? xv.y : 0.f;
+                xv.z = (rok && k + 2 < inner) ? xv.z : 0.f; xv.w = (rok && k + 3 < inner) ? xv.w : 0.f;
+            }
+            xv = to_f_layout(xv, to_f);
+            float wv[4][NT];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+                    wv[c][tt] = (k0 + 4 * g + c < inner && c_base + 16 * tt + r < n_out) ? wn[c][tt] : 0.f;
+            fetch(k0 + 16 < inner ? k0 + 16 : k0);               // (the last chunk again: no load under a branch)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float xb = c == 0 ? xv.x : (c == 1 ? xv.y : (c == 2 ? xv.z : xv.w));
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][tt], xb, acc[tt], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -101,7 +129,7 @@ __global__ __launch_bounds__(256) void rect_gemm_kernel(const float* __restrict_
 template <int MT, bool VECX>
 __global__ __launch_bounds__(256) void rect_wgrad_kernel(const float* __restrict__ X, int64_t ldx, int n_rows, int K,
                                                          const float* __restrict__ dS, int64_t ldds, int M,
-                                                         float* __restrict__ part)
+                                                         float* __restrict__ part, int per_wave)
 {
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, r = l & 15, g = l >> 4;
     const int kb = blockIdx.y;
@@ -131,8 +159,24 @@ __global__ __launch_bounds__(256) void rect_wgrad_kernel(const float* __restrict
             for (int mt = 0; mt < MT; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[mt], acc[q][mt], 0, 0, 0);
         }
     }
-    // block partial: the four waves add through LDS in wave order (fixed order: deterministic); acc[q][mt][e] is the
-    // entry (feature 64 kb + 4 (4 g + e) + q, column 16 mt + r)
+    // acc[q][mt][e] is the entry (feature 64 kb + 4 (4 g + e) + q, column 16 mt + r)
+    if (per_wave) {
+        // few rows (a QM9 mini-batch: 380 atoms, 24 blocks): every wave writes its own partial - four times the partial
+        // rows for the reduction launch, which reads 2 MB instead of 0.5, but no four-phase LDS reduction here (the
+        // kernel was 20 us for a 4 MFLOP product)
+        float* outw = part + ((int64_t)blockIdx.x * 4 + wave) * K * M;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = 64 * kb + 4 * (4 * g + e) + q, m = 16 * mt + r;
+                    if (kk < K && m < M) outw[(int64_t)kk * M + m] = acc[q][mt][e];
+                }
+        return;
+    }
+    // block partial: the four waves add through LDS in wave order (fixed order: deterministic)
     __shared__ float red[64 * 16 * MT];
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
@@ -209,11 +253,17 @@ extern "C" int gode_rect_gemm_nt_f32(const float* dS, int64_t ldds, int64_t n_ro
     return rect_launch<true>(dS, ldds, n_rows, M, W, M, K, dX, lddx, K, (hipStream_t)stream);
 }
 
-extern "C" int64_t gode_rect_wgrad_parts(int64_t n_rows) {
+static int64_t rect_wgrad_blocks(int64_t n_rows) {
     int64_t b = ((n_rows + 3) / 4 + 3) / 4;            // 16 rows per block and pass
     if (b < 1) b = 1;
     if (b > 512) b = 512;
     return b;
+}
+static constexpr int64_t kPerWaveBlocks = 32;                 // up to 512 rows: a partial row per WAVE (see rect_wgrad_kernel)
+
+extern "C" int64_t gode_rect_wgrad_parts(int64_t n_rows) {
+    const int64_t b = rect_wgrad_blocks(n_rows);
+    return b <= kPerWaveBlocks ? 4 * b : b;
 }
 
 extern "C" int gode_rect_wgrad_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, const float* dS, int64_t ldds,
@@ -223,12 +273,13 @@ extern "C" int gode_rect_wgrad_f32(const float* X, int64_t ldx, int64_t n_rows, 
     if (!part) return GODE_E_NULLPTR;
     if (ldx < K || ldds < M) return GODE_E_SHAPE;
     if (M > 128) return GODE_E_UNSUPPORTED;            // the caller splits wider outputs into column blocks
-    const int64_t blocks = gode_rect_wgrad_parts(n_rows);
+    const int64_t blocks = rect_wgrad_blocks(n_rows);
+    const int per_wave = blocks <= kPerWaveBlocks ? 1 : 0;
     const dim3 grid((unsigned)blocks, (unsigned)((K + 63) / 64));
     const bool vecx = !(((uintptr_t)X) & 15) && ldx % 4 == 0;
     hipStream_t s = (hipStream_t)stream;
     const int mt = M > 64 ? 8 : (M > 32 ? 4 : (M > 16 ? 2 : 1));
-#define GODE_RWG(MTV, VX) hipLaunchKernelGGL((rect_wgrad_kernel<MTV, VX>), grid, dim3(256), 0, s, X, ldx, (int)n_rows, (int)K, dS, ldds, (int)M, part)
+#define GODE_RWG(MTV, VX) hipLaunchKernelGGL((rect_wgrad_kernel<MTV, VX>), grid, dim3(256), 0, s, X, ldx, (int)n_rows, (int)K, dS, ldds, (int)M, part, per_wave)
 #define GODE_RWG_MT(VX) { if (mt == 8) GODE_RWG(8, VX); else if (mt == 4) GODE_RWG(4, VX); else if (mt == 2) GODE_RWG(2, VX); else GODE_RWG(1, VX); }
     if (vecx) GODE_RWG_MT(true) else GODE_RWG_MT(false)
 #undef GODE_RWG_MT

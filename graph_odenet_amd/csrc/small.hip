@@ -420,6 +420,40 @@ __global__ __launch_bounds__(1024) void small_finish1_kernel(const float* __rest
     }
 }
 
+// the same for up to eight stages in one launch (blockIdx.y = stage): an adaptive step closes all its stages at once -
+// nothing inside the step reads the small components' stage derivatives (csrc/ode_driver.hip).  Per stage the arithmetic is
+// small_finish1_kernel's.
+struct FinishN { const float* part[8]; float* ktheta[8]; float t[8]; };
+__global__ __launch_bounds__(1024) void small_finish_multi_kernel(FinishN g, int n_part, int plen, int d, int out_len)
+{
+    __shared__ float sm[32][33];
+    const float* __restrict__ part = g.part[blockIdx.y];
+    const int jj = threadIdx.x & 31, qq = threadIdx.x >> 5;
+    const int j = (int)blockIdx.x * 32 + jj;
+    const int src = j < out_len ? j : (j == out_len ? plen - 1 : -1);
+    float v = 0.f;
+    if (src >= 0) {
+        for (int p0 = qq; p0 < n_part; p0 += 32 * 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int p = p0 + 32 * u;
+                x[u] = p < n_part ? part[(int64_t)p * plen + src] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v += x[u];
+        }
+    }
+    sm[qq][jj] = v;
+    __syncthreads();
+    if (qq == 0 && src >= 0) {
+        float tsum = sm[0][jj];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) tsum += sm[k][jj];
+        g.ktheta[blockIdx.y][j] = j < d ? g.t[blockIdx.y] * tsum : tsum;
+    }
+}
+
 int small_cg(int64_t d, int32_t groups) {
     // channels per group when the fused small-graph kernels are instantiated for (d, groups), else -1
     // widths 16 and 32 only: at 64 the MFMA kernels of the multi-launch path are faster (measured on Cora, hidden 64,
@@ -535,6 +569,29 @@ extern "C" int gode_gcn_small_finish_f32(const gode_gcn_odefunc_t* f, const floa
     const int64_t blocks = (out_len + 1 + 31) / 32;
     hipLaunchKernelGGL(small_finish1_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, part, (int)parts, (int)plen,
                        (int)d, t, ktheta, (int)out_len);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+// n_stages <= 8 stages at once: stage s reads the partial buffer part + s * parts * part_len and writes ktheta[s] (evaluated
+// at ts[s]); every ktheta[s] is bit for bit what gode_gcn_small_finish_f32 writes
+extern "C" int gode_gcn_small_finish_multi_f32(const gode_gcn_odefunc_t* f, const float* part, int32_t n_stages,
+                                               float* const* ktheta /* host[n_stages] */, const float* ts /* host[n_stages] */,
+                                               void* stream)
+{
+    if (!f || !part || !ktheta || !ts) return GODE_E_NULLPTR;
+    if (n_stages < 1 || n_stages > 8) return GODE_E_SHAPE;
+    const int64_t d = f->d, out_len = (d + 1) * d + 3 * d, plen = gode_gcn_small_part_len(d);
+    const int64_t parts = gode_gcn_small_parts(f->n);
+    FinishN g;
+    for (int s = 0; s < 8; ++s) {
+        const bool on = s < n_stages;
+        if (on && !ktheta[s]) return GODE_E_NULLPTR;
+        g.part[s] = part + (int64_t)(on ? s : 0) * parts * plen; g.ktheta[s] = on ? ktheta[s] : nullptr; g.t[s] = on ? ts[s] : 0.f;
+    }
+    const int64_t blocks = (out_len + 1 + 31) / 32;
+    hipLaunchKernelGGL(small_finish_multi_kernel, dim3((unsigned)blocks, (unsigned)n_stages), dim3(1024), 0, (hipStream_t)stream, g,
+                       (int)parts, (int)plen, (int)d, (int)out_len);
     GODE_LAUNCH_CHECK();
     return 0;
 }

@@ -110,7 +110,7 @@ class _Shared:
         if not lib.gode_gcn_small_supported(self.n, self.d, int(groups)):
             return None                       # e.g. 2^20 x 128: 277 MB that nothing would ever read
         if getattr(self, "_small_part", None) is None:
-            self._small_part = torch.empty(4 * lib.gode_gcn_small_parts(self.n) * lib.gode_gcn_small_part_len(self.d),
+            self._small_part = torch.empty(6 * lib.gode_gcn_small_parts(self.n) * lib.gode_gcn_small_part_len(self.d),
                                            dtype=torch.float32, device=self.device)
         return self._small_part
 

@@ -505,6 +505,14 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, mask=None, o
         return out if bias is None else out.add_(bias)
     if pgemm_pays(M, N, K):
         return pgemm(cut3(A), cut3(B), trans_a, trans_b, bias, relu, mask, out)
+    if bias is None and not relu and mask is None and out.is_contiguous():
+        parts = lib.gode_gemm_splitk_parts(M, N, K)
+        if parts > 1:                                  # tall contraction, few output tiles (weight gradients of small layers)
+            part = torch.empty(parts, M * N, dtype=torch.float32, device=A.device)
+            check(lib.gode_gemm_splitk_f32(1 if trans_a else 0, 1 if trans_b else 0, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(part),
+                                           stream_ptr()), "gode_gemm_splitk_f32")
+            reduce_parts_(out.view(-1), part)
+            return out
     check(lib.gode_gemm_f32(1 if trans_a else 0, 1 if trans_b else 0, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
                             ptr(bias), 1 if relu else 0, ptr(mask), ldm, stream_ptr()), "gode_gemm_f32")
     return out

@@ -252,6 +252,13 @@ int gode_rect_wgrad_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, 
 int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int relu,
                   const float* mask, int64_t ldmask, void* stream);
+/* The same product for a TALL contraction with few output tiles (gode_gemm_splitk_parts(M, N, K) > 1: at most 64 tiles of
+ * 64 x 64 and K >= 192 - the weight gradients x^T dy of small layers): the contraction is cut into that many parts,
+ * part[z][M][N] (caller-owned, parts * M * N floats) receives the raw product of part z, and the caller adds them
+ * (gode_reduce_parts_f32).  No epilogue.  GODE_E_UNSUPPORTED when gode_gemm_splitk_parts is 1. */
+int64_t gode_gemm_splitk_parts(int64_t M, int64_t N, int64_t K);
+int gode_gemm_splitk_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, float* part, void* stream);
 
 /* The same products for LARGE shapes on the bf16 matrix cores, from exact three-way cuts of the fp32 operands
  * (csrc/pgemm.hip; replaces the three 21.6 GFLOP products of the edge encoder, QC/layers.py:46-86 and autograd:
@@ -487,7 +494,8 @@ typedef struct gode_rk4_workspace {
     float* X[2];                        /* nullable pair of n x d buffers (adjoint): the combined input of a stage with
                                            3 or 4 terms is written once by its forward launch and read as one array by
                                            the VJP and weight-gradient launches */
-    float* small_part;                  /* nullable: 4 * gode_gcn_small_parts(n) * gode_gcn_small_part_len(d) floats - enables
+    float* small_part;                  /* nullable: 6 * gode_gcn_small_parts(n) * gode_gcn_small_part_len(d) floats (rk4 uses 4 of
+                                           the 6 slots, a dopri5 step all of them) - enables
                                            the fused launch-bound path of the adjoint drivers (csrc/small.hip) */
     float* y2_colsum;                   /* nullable: gode_spmm_y2_colsum_rows(A.n_items, A.n_long, d) * d floats - the bias
                                            gradient of an adjoint stage is reduced from the per-block column sums the
@@ -519,6 +527,10 @@ int gode_gcn_vjp_small_f32(const gode_gcn_odefunc_t* f, const gode_lincomb_t* xi
                            float out_scale, const gode_lincomb_t* pre /* host, nullable */, float* ka, float* part,
                            void* stream);
 int gode_gcn_small_finish_f32(const gode_gcn_odefunc_t* f, const float* part, float* ktheta, float t, void* stream);
+/* n_stages <= 8 stages in one launch: stage s reads part + s * parts * part_len, writes ktheta[s] (time ts[s]); each result is
+ * bit for bit gode_gcn_small_finish_f32's (the dopri5 step driver closes its six stages at the end of the step) */
+int gode_gcn_small_finish_multi_f32(const gode_gcn_odefunc_t* f, const float* part, int32_t n_stages,
+                                    float* const* ktheta /* host */, const float* ts /* host */, void* stream);
 /* fixed-grid solves: the four stages of an RK step write their partials back to back (stage s at
  * part + s * parts * part_len) and ONE launch per step adds sum_s wb[s] * (stage derivative) to the packed small
  * components theta = [W | b | gamma | beta | a_t] (wb[s] = h * b_s, ts[s] = stage times; host arrays of 4) */

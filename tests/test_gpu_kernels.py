@@ -654,8 +654,8 @@ def test_vjp_and_weight_gradient_in_one_pass(n, groups):
     assert not ops.bwd_wgrad_supported(1000, d, groups)         # below 65 536 rows the drivers keep the two launches
 
 
-@pytest.mark.parametrize("n", [1, 17, 1000, 70001])
-@pytest.mark.parametrize("K,M", [(16, 7), (128, 16), (1433, 16), (500, 16), (3, 3), (100, 40), (64, 200), (130, 129), (3703, 64), (3703, 2)])
+@pytest.mark.parametrize("n", [1, 17, 380, 1000, 70001])
+@pytest.mark.parametrize("K,M", [(16, 7), (128, 16), (1433, 16), (500, 16), (3, 3), (100, 40), (64, 200), (130, 129), (3703, 64), (3703, 2), (73, 73)])
 def test_rectangular_products_vs_float64(n, K, M):
     """csrc/rect.hip: the dense products of a GraphConvolution with in_features != out_features (GCN/layers.py:32
     `torch.mm(input, self.weight)` and its autograd) on the exact fp32 matrix instruction - X W (with the output padded
@@ -717,7 +717,8 @@ def test_dense_on_a_mostly_zero_input_takes_the_csr_route():
             assert routes == [True, True, True], routes           # the tensor was already classified
 
 
-@pytest.mark.parametrize("M,N,K", [(760, 5329, 2667), (760, 2667, 5), (5, 2667, 760), (1, 1, 1), (129, 130, 17), (64, 128, 16), (300, 73, 200)])
+@pytest.mark.parametrize("M,N,K", [(760, 5329, 2667), (760, 2667, 5), (5, 2667, 760), (1, 1, 1), (129, 130, 17), (64, 128, 16), (300, 73, 200),
+                                   (73, 42, 363)])
 def test_tiled_gemm_all_operand_layouts_and_epilogues(M, N, K):
     """csrc/mlp.hip gode_gemm_f32 (the dense products of the QC edge encoder, QC/layers.py:46-86): C = op(A) op(B) for the
     four operand layouts, ragged sizes (rows of 2667 / 5329 floats are not 16-byte aligned), leading dimensions, and
