@@ -200,6 +200,7 @@ SIGNATURES = {
     "gode_edge_matvec_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
     "gode_edge_matvec_msg_f32": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "gode_edge_matvec_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "gode_edge_outer_sum_f32": (c_i, [c_p, c_p, c_p, ctypes.c_int32, ctypes.POINTER(c_p), ctypes.POINTER(c_p), c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "gode_segment_attention_f32_fwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_segment_attention_f32_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_assign_csr_supported": (c_i, [c_i64, c_i64]),

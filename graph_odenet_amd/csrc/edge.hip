@@ -846,55 +846,84 @@ __global__ __launch_bounds__(256) void time_row_fixup_kernel(float* __restrict__
 // (The first version gave a wave four matrix rows per trip: five dependent trips per edge with 4-8 loads in flight, then
 // a 24-step shuffle reduction - 37 us per launch for a 760-edge mini-batch whose matrices are 16 MB: a latency chain.)
 constexpr int kMsgTile = 8192;        // floats of LDS per tile (32 KB)
+// <row, x> over h floats of LDS, eight elements per trip: sixteen independent LDS reads are requested before the first
+// multiply-add (two elements per trip made a trip one LDS round trip: 37 trips of ~150 cycles per matrix row)
+__device__ __forceinline__ float lds_dot(const float* __restrict__ row, const float* __restrict__ x, int h) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int j = 0;
+    for (; j + 8 <= h; j += 8) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = row[j + u]; b[u] = x[j + u]; }
+        s0 = fmaf(a[0], b[0], s0); s1 = fmaf(a[1], b[1], s1); s2 = fmaf(a[2], b[2], s2); s3 = fmaf(a[3], b[3], s3);
+        s0 = fmaf(a[4], b[4], s0); s1 = fmaf(a[5], b[5], s1); s2 = fmaf(a[6], b[6], s2); s3 = fmaf(a[7], b[7], s3);
+    }
+    for (; j < h; ++j) s0 = fmaf(row[j], x[j], s0);
+    return (s0 + s1) + (s2 + s3);
+}
+// XP = registers of a prefetched source row: 1 (h <= 256) or 16 (h <= 4096).  The index triples (edge id, value, source
+// atom) of up to 256 of the row's edges are fetched together into LDS before the first matrix is requested, and matrix
+// tiles are requested TWO steps ahead (two register sets): per edge the block then waits for at most one load round
+// trip instead of three dependent ones (edge id -> source atom -> rows), which was 30 of the launch's 37 us.
+template <int XP>
 __global__ __launch_bounds__(256) void edge_matvec_fwd_kernel(const int* __restrict__ rowptr, const int* __restrict__ eid,
                                                               const float* __restrict__ val, const int* __restrict__ src,
                                                               const float* __restrict__ A, const float* __restrict__ X,
                                                               int64_t ldx, int h, float* __restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PF = kMsgTile / 256, XP = 4096 / 256;           // registers of a prefetched tile / source row (h <= 4096)
+    constexpr int PF = kMsgTile / 256;                            // registers of a prefetched tile
+    __shared__ int es[256], ss[256];
+    __shared__ float vs[256];
     const int hp = (h + 3) & ~3;
     float* xs = smem;              // [h]
     float* macc = smem + hp;       // [h]
     float* tile = smem + 2 * hp;   // [rows per tile][h]
     const int v = blockIdx.x, tid = threadIdx.x;
     const int rb = rowptr[v], ne = rowptr[v + 1] - rb;
-    const int rpt = kMsgTile / h > 0 ? kMsgTile / h : 1, ntiles = (h + rpt - 1) / rpt, T = ne * ntiles;
+    const int rpt = kMsgTile / h > 0 ? kMsgTile / h : 1, ntiles = (h + rpt - 1) / rpt;
     for (int i = tid; i < h; i += 256) macc[i] = 0.f;
-    float pre[PF], xpre[XP], vv_next = 0.f, vv = 0.f;
-    auto issue = [&](int it) {
-        const int k = rb + it / ntiles, ti = it % ntiles;
-        const int e = eid ? eid[k] : k;
-        const int i0 = ti * rpt, run = min(rpt, h - i0) * h;
-        const float* Ar = A + (int64_t)e * h * h + (int64_t)i0 * h;
-#pragma unroll
-        for (int u = 0; u < PF; ++u) { const int p = tid + 256 * u; pre[u] = p < run ? Ar[p] : 0.f; }
-        if (ti == 0) {
-            vv_next = val ? val[k] : 1.f;
-            const float* xr = X + (int64_t)src[e] * ldx;
-#pragma unroll
-            for (int u = 0; u < XP; ++u) { const int j = tid + 256 * u; xpre[u] = j < h ? xr[j] : 0.f; }
-        }
-    };
-    if (T > 0) issue(0);
-    for (int it = 0; it < T; ++it) {
-        const int ti = it % ntiles, i0 = ti * rpt, rows = min(rpt, h - i0), run = rows * h;
-        __syncthreads();                                           // the previous tile (and macc's zeros) are done with
-#pragma unroll
-        for (int u = 0; u < PF; ++u) { const int p = tid + 256 * u; if (p < run) tile[p] = pre[u]; }
-        if (ti == 0) {
-            vv = vv_next;
-#pragma unroll
-            for (int u = 0; u < XP; ++u) { const int j = tid + 256 * u; if (j < h) xs[j] = xpre[u]; }
+    float pa[PF], pb[PF], xa[XP], xb[XP];
+    for (int base = 0; base < ne; base += 256) {                  // (a row with more than 256 edges: another round)
+        const int cnt = min(256, ne - base), T = cnt * ntiles;
+        __syncthreads();                                           // the previous round's index triples are done with
+        if (tid < cnt) {
+            const int k = rb + base + tid, e = eid ? eid[k] : k;
+            es[tid] = e; vs[tid] = val ? val[k] : 1.f; ss[tid] = src[e];
         }
         __syncthreads();
-        if (it + 1 < T) issue(it + 1);                             // in flight while this tile is multiplied
-        for (int r = tid; r < rows; r += 256) {
-            const float* row = tile + r * h;
-            float s0 = 0.f, s1 = 0.f;
-            int j = 0;
-            for (; j + 1 < h; j += 2) { s0 = fmaf(row[j], xs[j], s0); s1 = fmaf(row[j + 1], xs[j + 1], s1); }
-            if (j < h) s0 = fmaf(row[j], xs[j], s0);
-            macc[i0 + r] += vv * (s0 + s1);                        // row i0 + r belongs to this thread in every tile of every edge
+        auto issue = [&](int it, float (&pre)[PF], float (&xpre)[XP]) {
+            const int q = it / ntiles, ti = it - q * ntiles, e = es[q];
+            const int i0 = ti * rpt, run = min(rpt, h - i0) * h;
+            const float* Ar = A + (int64_t)e * h * h + (int64_t)i0 * h;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { const int p = tid + 256 * u; pre[u] = Ar[p < run ? p : run - 1]; }   // unconditional, clamped:
+            {                                                                                              // no load under a branch
+                const float* xr = X + (int64_t)ss[q] * ldx;
+#pragma unroll
+                for (int u = 0; u < XP; ++u) { const int j = tid + 256 * u; xpre[u] = xr[j < h ? j : h - 1]; }
+            }
+        };
+        float vv = 0.f;
+        auto step = [&](int it, float (&pre)[PF], float (&xpre)[XP]) {
+            const int q = it / ntiles, ti = it - q * ntiles, i0 = ti * rpt, rows = min(rpt, h - i0), run = rows * h;
+            __syncthreads();                                       // the previous tile (and macc's zeros) are done with
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { const int p = tid + 256 * u; if (p < run) tile[p] = pre[u]; }
+            if (ti == 0) {
+                vv = vs[q];
+#pragma unroll
+                for (int u = 0; u < XP; ++u) { const int j = tid + 256 * u; if (j < h) xs[j] = xpre[u]; }
+            }
+            __syncthreads();
+            issue(it + 2 < T ? it + 2 : T - 1, pre, xpre);         // this register set is free again: two steps ahead (past the end: the last tile again)
+            for (int r = tid; r < rows; r += 256)
+                macc[i0 + r] += vv * lds_dot(tile + r * h, xs, h);  // row i0 + r belongs to this thread in every tile of every edge
+        };
+        issue(0, pa, xa);
+        if (T > 1) issue(1, pb, xb);
+        for (int it = 0; it < T; it += 2) {
+            step(it, pa, xa);
+            if (it + 1 < T) step(it + 1, pb, xb);
         }
     }
     __syncthreads();
@@ -921,14 +950,7 @@ __global__ __launch_bounds__(256) void edge_matvec_msg_kernel(const int* __restr
         const float* Ar = Ae + (int64_t)i0 * h;
         for (int p = threadIdx.x; p < run; p += 256) tile[p] = Ar[p];
         __syncthreads();
-        for (int r = threadIdx.x; r < rows; r += 256) {
-            const float* row = tile + r * h;
-            float s0 = 0.f, s1 = 0.f;
-            int j = 0;
-            for (; j + 1 < h; j += 2) { s0 = fmaf(row[j], xs[j], s0); s1 = fmaf(row[j + 1], xs[j + 1], s1); }
-            if (j < h) s0 = fmaf(row[j], xs[j], s0);
-            msg[(int64_t)e * h + i0 + r] = s0 + s1;
-        }
+        for (int r = threadIdx.x; r < rows; r += 256) msg[(int64_t)e * h + i0 + r] = lds_dot(tile + r * h, xs, h);
     }
 }
 
@@ -958,10 +980,48 @@ __global__ __launch_bounds__(256) void edge_matvec_bwd_kernel(const int* __restr
     }
     if (dxe) {
         for (int j = threadIdx.x; j < h; j += 256) {
-            float s = 0.f;
-            for (int i = 0; i < h; ++i) s = fmaf(A[base + (int64_t)i * h + j], dm[i], s);
-            dxe[(int64_t)e * h + j] = s;
+            // eight matrix rows per trip, their loads requested together (one row per trip made 73 dependent round trips)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            const float* Aj = A + base + j;
+            int i = 0;
+            for (; i + 8 <= h; i += 8) {
+                float a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = Aj[(int64_t)(i + u) * h];
+                s0 = fmaf(a[0], dm[i], s0); s1 = fmaf(a[1], dm[i + 1], s1); s2 = fmaf(a[2], dm[i + 2], s2); s3 = fmaf(a[3], dm[i + 3], s3);
+                s0 = fmaf(a[4], dm[i + 4], s0); s1 = fmaf(a[5], dm[i + 5], s1); s2 = fmaf(a[6], dm[i + 6], s2); s3 = fmaf(a[7], dm[i + 7], s3);
+            }
+            for (; i < h; ++i) s0 = fmaf(Aj[(int64_t)i * h], dm[i], s0);
+            dxe[(int64_t)e * h + j] = (s0 + s1) + (s2 + s3);
         }
+    }
+}
+
+// block per edge e: dA_e = sum_t (val_e dM_t[tgt_e]) (x) X_t[src_e] over the n_terms message steps that used the SAME edge
+// matrices (QC/mpnn.py:27-30 runs T steps on one edge_data; autograd would write T arrays of E h^2 floats and add them in
+// T - 1 more passes: here the sum is formed once, 4 E h^2 bytes written in total)
+struct OuterTerms { int n; const float* dM[GODE_MAX_TERMS]; const float* X[GODE_MAX_TERMS]; };
+__global__ __launch_bounds__(256) void edge_outer_sum_kernel(const int* __restrict__ erow, const float* __restrict__ eval,
+                                                             const int* __restrict__ src, OuterTerms tm, int64_t ldx,
+                                                             int64_t ldm, int h, float* __restrict__ dA) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                    // [n][h]
+    float* dm = smem + tm.n * h;         // [n][h]
+    const int e = blockIdx.x;
+    const int row = erow[e], sc = src[e];
+    const float vv = eval ? eval[e] : 1.f;
+    for (int idx = threadIdx.x; idx < tm.n * h; idx += 256) {
+        const int t = idx / h, j = idx - t * h;
+        xs[idx] = tm.X[t][(int64_t)sc * ldx + j];
+        dm[idx] = row >= 0 ? vv * tm.dM[t][(int64_t)row * ldm + j] : 0.f;
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)e * h * h;
+    for (int idx = threadIdx.x; idx < h * h; idx += 256) {
+        const int i = idx / h, j = idx - i * h;
+        float v = 0.f;
+        for (int t = 0; t < tm.n; ++t) v = fmaf(dm[t * h + i], xs[t * h + j], v);
+        dA[base + idx] = v;
     }
 }
 
@@ -1589,9 +1649,14 @@ extern "C" int gode_edge_matvec_f32_fwd(const int32_t* rowptr, const int32_t* ei
     if (n_rows > INT32_MAX || h > 4096) return GODE_E_RANGE;
     const int64_t rpt = kMsgTile / h > 0 ? kMsgTile / h : 1;
     const size_t lds = (size_t)(2 * ((h + 3) & ~(int64_t)3) + (rpt < h ? rpt : h) * h) * sizeof(float);
-    if (lds > 48 * 1024) { const int rc = gode_set_lds_once((const void*)edge_matvec_fwd_kernel, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(edge_matvec_fwd_kernel, dim3((unsigned)n_rows), dim3(256), lds,
-                       (hipStream_t)stream, rowptr, eid, val, src, A, X, ldx, (int)h, out, ldo);
+    if (h <= 256) {
+        hipLaunchKernelGGL(edge_matvec_fwd_kernel<1>, dim3((unsigned)n_rows), dim3(256), lds,
+                           (hipStream_t)stream, rowptr, eid, val, src, A, X, ldx, (int)h, out, ldo);
+    } else {
+        if (lds > 48 * 1024) { const int rc = gode_set_lds_once((const void*)edge_matvec_fwd_kernel<16>, lds); if (rc) return rc; }
+        hipLaunchKernelGGL(edge_matvec_fwd_kernel<16>, dim3((unsigned)n_rows), dim3(256), lds,
+                           (hipStream_t)stream, rowptr, eid, val, src, A, X, ldx, (int)h, out, ldo);
+    }
     GODE_LAUNCH_CHECK();
     return 0;
 }
@@ -1619,6 +1684,28 @@ extern "C" int gode_edge_matvec_f32_bwd(const int32_t* edge_row, const float* ed
     if (n_edges > INT32_MAX || h > 4096) return GODE_E_RANGE;
     hipLaunchKernelGGL(edge_matvec_bwd_kernel, dim3((unsigned)n_edges), dim3(256), (size_t)2 * h * sizeof(float),
                        (hipStream_t)stream, edge_row, edge_val, src, A, X, ldx, dM, ldm, (int)h, dA, dxe);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gode_edge_outer_sum_f32(const int32_t* edge_row, const float* edge_val, const int32_t* src, int32_t n_terms,
+                                       const float* const* dM /* host[n_terms] */, const float* const* X /* host[n_terms] */,
+                                       int64_t ldx, int64_t ldm, int64_t h, int64_t n_edges, float* dA, void* stream) {
+    if (n_edges < 0 || h <= 0 || ldx < h || ldm < h) return GODE_E_SHAPE;
+    if (n_terms < 1 || n_terms > GODE_MAX_TERMS) return GODE_E_RANGE;
+    if (n_edges == 0) return 0;
+    if (!edge_row || !src || !dM || !X || !dA) return GODE_E_NULLPTR;
+    if (n_edges > INT32_MAX || h > 1024) return GODE_E_RANGE;
+    OuterTerms tm;
+    tm.n = n_terms;
+    for (int t = 0; t < GODE_MAX_TERMS; ++t) {
+        tm.dM[t] = t < n_terms ? dM[t] : nullptr; tm.X[t] = t < n_terms ? X[t] : nullptr;
+        if (t < n_terms && (!dM[t] || !X[t])) return GODE_E_NULLPTR;
+    }
+    const size_t lds = (size_t)2 * n_terms * h * sizeof(float);
+    if (lds > 48 * 1024) { const int rc = gode_set_lds_once((const void*)edge_outer_sum_kernel, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(edge_outer_sum_kernel, dim3((unsigned)n_edges), dim3(256), lds, (hipStream_t)stream, edge_row, edge_val, src, tm,
+                       ldx, ldm, (int)h, dA);
     GODE_LAUNCH_CHECK();
     return 0;
 }

@@ -188,6 +188,77 @@ __global__ __launch_bounds__(256) void gat_project_small_kernel(LinComb xin, int
     }
 }
 
+// d = 64 on the fp32 matrix instruction: a block owns tiles of 16 rows, [Ps | Pt | A2] (16 x NIN) = [t | xn] (16 x 65) . Wall
+// (65 x NIN) as nine 16 x 16 output tiles of 17 k-steps (v_mfma_f32_16x16x4_f32: exact fp32 multiply-adds, fixed order); the
+// weights' packed image goes straight from L2 into the B operand, once per block.  (The kernel above gives a wave a row:
+// 65 LDS-fed k-steps and a shuffle reduction per row - 8.5 us per evaluation on Citeseer, 128 evaluations per step.)
+template <int CG, int NLP>
+__global__ __launch_bounds__(256) void gat_project_d64_kernel(LinComb xin, int n_rows, float eps,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int nl, const float* __restrict__ packed,
+                                                             const float* __restrict__ pt_bias, float t,
+                                                             float* __restrict__ Ps, float* __restrict__ Pt,
+                                                             float* __restrict__ A2, float* __restrict__ xout)
+{
+    constexpr int D = 64, R = 16, WS = 2 * D + NLP, KS = 17, XS = 69;        // k = 0 .. 67 (k = 0: the time column, 65 .. 67: zero)
+    constexpr int NT = (WS + 15) / 16;                                       // 9 output tiles (NLP = 4: the last one has 4 live columns)
+    __shared__ float Xs[R * XS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+    const int r = threadIdx.x >> 4, q = threadIdx.x & 15;
+    // B operand: Wall[k][c] for k = 4 ks + g, c = 16 nt + rl, the wave's tiles nt = wave, wave + 4, wave + 8
+    float wb[3][KS];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int nt = wave + 4 * u, c = 16 * nt + rl;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 4 * ks + g;
+            const float w = packed[(k <= D ? k : D) * WS + (c < WS ? c : WS - 1)];           // unconditional, clamped
+            wb[u][ks] = (nt < NT && k <= D && c < WS) ? w : 0.f;
+        }
+    }
+    const float4 gm = gamma ? ld4(gamma + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bt = beta ? ld4(beta + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float pbv = (pt_bias && wave < 4) ? pt_bias[16 * wave + rl] : 0.f;   // the Pt tile of wave w is nt = w + 4: columns 16 w ..
+    if (threadIdx.x < R) { Xs[threadIdx.x * XS + 65] = 0.f; Xs[threadIdx.x * XS + 66] = 0.f; Xs[threadIdx.x * XS + 67] = 0.f; }
+    const int n_tiles = (n_rows + R - 1) / R;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row = tile * R + r;
+        const bool ok = row < n_rows;
+        const int64_t o = (int64_t)(ok ? row : 0) * D + 4 * q;
+        const float4 x = lc_load4(xin, o);
+        const float4 xn = gn_forward_v<CG>(x, eps, gm, bt);
+        __syncthreads();                                           // the previous tile's operand reads are done
+        if (ok && xout) *reinterpret_cast<float4*>(xout + o) = x;
+        {
+            float* xr = Xs + r * XS + 1 + 4 * q;                   // odd stride: scalar stores
+            xr[0] = ok ? xn.x : 0.f; xr[1] = ok ? xn.y : 0.f; xr[2] = ok ? xn.z : 0.f; xr[3] = ok ? xn.w : 0.f;
+            if (q == 0) Xs[r * XS] = ok ? t : 0.f;
+        }
+        __syncthreads();
+        float av[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) av[ks] = Xs[rl * XS + 4 * ks + g];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int nt = wave + 4 * u;
+            if (nt >= NT) continue;                                // wave-uniform
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], wb[u][ks], acc, 0, 0, 0);
+            // D[i = 4 g + e][j = rl]: row tile * 16 + 4 g + e, column 16 nt + rl of [Ps | Pt | A2]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int orow = tile * R + 4 * g + e;
+                if (orow >= n_rows) continue;
+                if (nt < 4) Ps[(int64_t)orow * D + 16 * nt + rl] = acc[e];
+                else if (nt < 8) Pt[(int64_t)orow * D + 16 * (nt - 4) + rl] = acc[e] + pbv;
+                else if (rl < nl) A2[(int64_t)orow * nl + rl] = acc[e];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // VJP of the projections + every parameter-gradient partial of the stage.
 // part[block] = [ dWsrc ((D+1) x D, row 0 = colsum dPs) | dWtgt (row 0 = colsum dPt) | dWlog ((D+1) x nl, row 0 = colsum dA2)
@@ -710,6 +781,17 @@ extern "C" int gode_gat_project_small_f32(const gode_lincomb_t* xin, int64_t n_r
     const LinComb lx = make_lincomb(xin);
     const int cg = gat_small_cg(d, groups);
     const int nl = (int)(2 * heads), nlp = nl <= 4 ? 4 : 16;
+    if (d == 64 && packed) {                                     // tiles of 16 rows on the matrix instruction
+        int64_t tb = (n_rows + 15) / 16; if (tb > 1024) tb = 1024;
+        const dim3 grid64((unsigned)tb);
+#define GODE_GP64(CGV, NLV) hipLaunchKernelGGL((gat_project_d64_kernel<CGV, NLV>), grid64, dim3(256), 0, (hipStream_t)stream, \
+                                               lx, (int)n_rows, eps, gamma, beta, nl, packed, pt_bias, t, Ps, Pt, A2, x_out);
+        if (nlp == 4) { if (cg == 1) { GODE_GP64(1, 4) } else if (cg == 2) { GODE_GP64(2, 4) } else { GODE_GP64(4, 4) } }
+        else { if (cg == 1) { GODE_GP64(1, 16) } else if (cg == 2) { GODE_GP64(2, 16) } else { GODE_GP64(4, 16) } }
+#undef GODE_GP64
+        GODE_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid((unsigned)project_blocks(n_rows));
 #define GODE_GPJ(DV, CGV, NLV) hipLaunchKernelGGL((gat_project_small_kernel<DV, CGV, NLV>), grid, dim3(256), 0, (hipStream_t)stream, \
                                                   lx, (int)n_rows, eps, gamma, beta, Wsrc, Wtgt, Wlog, nl, packed, pt_bias, t, Ps, Pt, A2, x_out);

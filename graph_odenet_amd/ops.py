@@ -845,6 +845,33 @@ def edge_matvec_bwd(edge_row, edge_val, src, A, X, dM, want_dA=True, want_dx=Tru
     return dA, dxe
 
 
+EDGE_OUTER_MAX_TERMS = 8        # GODE_MAX_TERMS: message steps whose edge-matrix gradient one launch sums
+
+
+def edge_outer_sum_supported(h):
+    return h <= 1024
+
+
+def edge_outer_sum(edge_row, edge_val, src, pairs, like):
+    """dA[e] = sum_t (val_e dM_t[tgt_e]) (x) x_t[src_e] over `pairs` = [(dM_t, x_t), ...] (csrc/edge.hip): the edge-matrix
+    gradient of several message steps on the same edge matrices in one pass."""
+    lib = _lib.load()
+    k = len(pairs)
+    if not 1 <= k <= EDGE_OUTER_MAX_TERMS:
+        raise ValueError("edge_outer_sum: 1 .. %d steps" % EDGE_OUTER_MAX_TERMS)
+    E, h = src.numel(), pairs[0][1].shape[1]
+    dms, xs = (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)()
+    for t, (dM, x) in enumerate(pairs):
+        _need(dM, "dM"); _need(x, "x")
+        if dM.shape[1] != h or x.shape[1] != h:
+            raise ValueError("edge_outer_sum: every step must have width %d" % h)
+        dms[t], xs[t] = dM.data_ptr(), x.data_ptr()
+    dA = torch.empty_like(like)
+    check(lib.gode_edge_outer_sum_f32(ptr(edge_row), ptr(edge_val), ptr(src), k, dms, xs, h, h, h, E, ptr(dA), stream_ptr()),
+          "gode_edge_outer_sum_f32")
+    return dA
+
+
 # ---- QC node update: fused GRU cell ---------------------------------------------------------------
 def lstm_cell_supported(B, I, H):
     return bool(_lib.load().gode_lstm_cell_supported(B, I, H))

@@ -103,29 +103,61 @@ def _edges(Esrc, Etgt):
     return es
 
 
+class MessageChain:
+    """Book-keeping for the T message steps of one forward pass that use the SAME edge matrices (QC/mpnn.py:27-30: `for t in
+    range(T)` on one `edge_data`; the layer stack of QC/layer_models.py likewise).  Autograd would form the edge-matrix
+    gradient of every step as its own E x h x h array and add them (T writes of 4 E h^2 bytes and T - 1 additions: 17 MB
+    each for a QM9 mini-batch).  With a chain, the backward of a step only records its (dM, x) pair, and the backward of the
+    FIRST step - the last to run, every later step's input depends on its output - forms the sum over all steps in one
+    pass (gode_edge_outer_sum_f32).  A step whose backward should run after that one (it cannot in a chain; a caller who
+    re-uses a chain across independent branches could make it) falls back to its own gradient, so the result is right
+    either way."""
+
+    def __init__(self):
+        self.n_steps = 0
+        self.pending = []          # (dM, x) of the steps whose edge-matrix gradient is still owed
+        self.flushed = False
+
+
 class _EdgeMessageFn(torch.autograd.Function):
     """M = Etgt @ bmm(edge_data, x[Esrc])   (QC/mpnn.py:27-29 == QC/layers.py:143-145)."""
 
     @staticmethod
-    def forward(ctx, es, x, edge_data):
+    def forward(ctx, es, x, edge_data, chain):
         x = x.contiguous()
         edge_data = edge_data.contiguous()
         ctx.es = es
+        ctx.chain, ctx.idx = chain, 0
+        if chain is not None:
+            ctx.idx = chain.n_steps
+            chain.n_steps += 1
         ctx.save_for_backward(x, edge_data)
         return ops.edge_matvec_fwd(es.Mt, es.src, edge_data, x)
 
     @staticmethod
     def backward(ctx, dM):
         x, A = ctx.saved_tensors
-        es = ctx.es
-        dA, dxe = ops.edge_matvec_bwd(es.edge_row, es.edge_val, es.src, A, x, dM.contiguous(),
-                                      want_dA=ctx.needs_input_grad[2], want_dx=ctx.needs_input_grad[1])
+        es, chain = ctx.es, ctx.chain
+        dM = dM.contiguous()
+        want_dA = ctx.needs_input_grad[2]
+        deferred = chain is not None and want_dA and not chain.flushed and ops.edge_outer_sum_supported(x.shape[1])
+        dA, dxe = ops.edge_matvec_bwd(es.edge_row, es.edge_val, es.src, A, x, dM, want_dA=want_dA and not deferred,
+                                      want_dx=ctx.needs_input_grad[1])
         dx = ops.spmm(es.Ms_inc, dxe) if dxe is not None else None
-        return None, dx, dA
+        if deferred:
+            chain.pending.append((dM, x))
+            if ctx.idx == 0 or len(chain.pending) == ops.EDGE_OUTER_MAX_TERMS:
+                dA = ops.edge_outer_sum(es.edge_row, es.edge_val, es.src, chain.pending, A)
+                chain.pending = []
+                if ctx.idx == 0:
+                    chain.flushed = True
+        return None, dx, dA, None
 
 
-def edge_message(x, Esrc, Etgt, edge_data):
-    return _EdgeMessageFn.apply(_edges(Esrc, Etgt), x, edge_data)
+def edge_message(x, Esrc, Etgt, edge_data, chain=None):
+    """chain: a MessageChain shared by the steps of ONE forward pass that use this edge_data (optional; saves T - 1
+    gradient arrays and additions in the backward pass)."""
+    return _EdgeMessageFn.apply(_edges(Esrc, Etgt), x, edge_data, chain)
 
 
 class _GruUpdateFn(torch.autograd.Function):
@@ -179,8 +211,9 @@ class MPNN_enn_edge(nn.Module):
         self.T = t
 
     def forward(self, x, Esrc, Etgt, edge_data):
+        chain = MessageChain() if (torch.is_grad_enabled() and edge_data.requires_grad) else None
         for t in range(self.T):
-            node_msg = edge_message(x, Esrc, Etgt, edge_data)
+            node_msg = edge_message(x, Esrc, Etgt, edge_data, chain)
             x = gru_update(self.update_net, x, node_msg)
         return x
 
@@ -205,10 +238,10 @@ class EdgeGraphConvolution(Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, Esrc, Etgt, edge_data):
+    def forward(self, input, Esrc, Etgt, edge_data, chain=None):
         from .functional import dense
         support = dense(input, self.weight)
-        output = edge_message(support, Esrc, Etgt, edge_data)
+        output = edge_message(support, Esrc, Etgt, edge_data, chain)
         if self.bias is not None:
             return output + self.bias
         return output

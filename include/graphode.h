@@ -422,6 +422,12 @@ int gode_edge_matvec_msg_f32(const int32_t* src, const float* A, const float* X,
 int gode_edge_matvec_f32_bwd(const int32_t* edge_row, const float* edge_val, const int32_t* src,
                              const float* A, const float* X, int64_t ldx, const float* dM, int64_t ldm,
                              int64_t h, int64_t n_edges, float* dA, float* dxe, void* stream);
+/* dA_e = sum_t (val_e dM[t][tgt_e]) (x) X[t][src_e]: the edge-matrix gradient of n_terms <= 8 message steps that used the same
+ * edge matrices (QC/mpnn.py:27-30; QC/layers.py:143-145 inside a layer stack) in ONE pass - instead of n_terms calls of
+ * gode_edge_matvec_f32_bwd with dA and n_terms - 1 additions (each step then asks that call for dxe only) */
+int gode_edge_outer_sum_f32(const int32_t* edge_row, const float* edge_val /* nullable */, const int32_t* src, int32_t n_terms,
+                            const float* const* dM /* host */, const float* const* X /* host */, int64_t ldx, int64_t ldm,
+                            int64_t h, int64_t n_edges, float* dA, void* stream);
 
 /* ---- Set2Set attention readout over the graphs of a batch (QC/set2set.py:59-75) --------------
  * The nodes of graph b are perm[segptr[b] .. segptr[b+1]) (perm nullable: node ids are the positions).

@@ -483,9 +483,15 @@ def test_one_launch_dense_half_vs_float64_autograd(n, d, H):
     # per solve from d = 32 on): a different way of staging the same numbers - every output bit for bit the same
     packed = ops.gat_small_pack(Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H)
     Ps2, Pt2, A22 = torch.empty_like(Ps), torch.empty_like(Pt), torch.empty_like(A2)
+    X2 = torch.full_like(X, float("nan"))
     ops.gat_project_small(dt, n, d, groups, eps, gamma.to(D), beta.to(D), Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H, bf.to(D), t, Ps2, Pt2, A22,
-                          packed=packed)
-    assert torch.equal(Ps2, Ps) and torch.equal(Pt2, Pt) and torch.equal(A22, A2)
+                          x_out=X2, packed=packed)
+    assert torch.equal(X2, X)
+    if d < 64:
+        assert torch.equal(Ps2, Ps) and torch.equal(Pt2, Pt) and torch.equal(A22, A2)
+    else:       # d = 64 with the packed image: 16-row tiles on the fp32 matrix instruction (gat_project_d64_kernel) - same bars
+        for got, ref, nm in ((Ps2, rPs, "Ps"), (Pt2, rPt, "Pt"), (A22, rA2, "A2")):
+            assert (got.cpu().double() - ref.detach()).abs().max().item() <= ftol * max(1.0, ref.abs().max().item()), (nm, "matrix-instruction form")
     part2, ka2 = ops.gat_small_part(n, d, H, D), torch.empty_like(ka)
     ops.gat_dense_vjp_small([(1.0, X)], n, d, groups, eps, gamma.to(D), beta.to(D), Wsrc.to(D), Wtgt.to(D), Wlog.to(D), H,
                             dPs.to(D), dPt.to(D), dA2.to(D), ka2, part2, out_scale=-0.5, pre_terms=[(2.0, pre.to(D))], packed=packed)
@@ -552,9 +558,14 @@ def test_one_launch_dense_half_matches_multi_launch_path(golden, heads, d, metho
             return ((a - b).abs() / (b.abs() + 1e-3)).median().item()
         assert typical(res[1][1], res[0][1]) <= 1e-2, "dx (median entry)"
         if method == "rk4":                                 # adaptive steps on those rows: accept / reject moves with rounding
-            assert rel(res[1][1], res[0][1]) <= 0.1, "dx"
+            # norm-wise bar: 0.25.  It was 0.1 while the one-launch path summed its products in sub-group order (rounds 2-3:
+            # 0.03-0.09 measured); with both of its products on the matrix instruction (round 4: gat_project_d64_kernel,
+            # gat_dense_vjp_d64_kernel - each within the same 2e-5 of float64 as the kernels they replace, test above) the
+            # one-head case measures 0.18: the norm is carried by the handful of rows with rstd ~ 316, where any change of
+            # summation order moves the result by this much (the median entry, asserted above, agrees to 1e-2)
+            assert rel(res[1][1], res[0][1]) <= 0.25, "dx"
             for a, b in zip(res[1][2], res[0][2]):
-                assert b.abs().max().item() < 1e-3 or rel(a, b) <= 0.1, "parameter gradient"
+                assert b.abs().max().item() < 1e-3 or rel(a, b) <= 0.25, "parameter gradient"
         return
     if method == "dopri5":
         # two fp32 runs of an adaptive solve take accept / reject decisions that move with rounding (and at one channel per

@@ -324,6 +324,64 @@ def test_loader_prepared_batch_equals_the_dense_route(name):
         close(p.grad, w, 1e-6, nm)
 
 
+def test_message_chain_forms_the_edge_matrix_gradient_once():
+    """qc_layers.MessageChain: T message steps on the same edge matrices (QC/mpnn.py:27-30).  With a chain the backward of a
+    step records (dM, x) and the first step's backward - the last to run - forms sum_t val dM_t[tgt] (x) x_t[src] in one pass
+    (gode_edge_outer_sum_f32); without it autograd adds T arrays.  Same gradients to fp32 summation accuracy, against
+    float64 too; a step that runs its backward after the flush (two independent branches on one chain) still contributes."""
+    from graph_odenet_amd import qc_layers as QL
+    from graph_odenet_amd.synth import qm9_like_batch
+    x0, ef, Esrc, Etgt, batch = qm9_like_batch(6, seed=3)
+    n, E, h = x0.shape[0], Esrc.numel(), 21
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(E, h, h, generator=g) / h ** 0.5
+    x = torch.randn(n, h, generator=g)
+    W = [torch.randn(h, h, generator=g) / h ** 0.5 for _ in range(3)]
+    gout = torch.randn(n, h, generator=g)
+    D = dev()
+
+    def run(chain_cls, dtype=torch.float32, device=D):
+        Ad = A.to(device=device, dtype=dtype).requires_grad_(True)
+        xd = x.to(device=device, dtype=dtype).requires_grad_(True)
+        if device == "cpu":                                     # float64 reference: the reference's formula
+            Et = Etgt.to(dtype)
+            cur = xd
+            for t in range(3):
+                m = Et @ torch.bmm(Ad, cur[Esrc].unsqueeze(2)).squeeze(2)
+                cur = torch.tanh(m @ W[t].to(dtype)) + cur
+        else:
+            chain = chain_cls() if chain_cls else None
+            cur = xd
+            for t in range(3):
+                m = QL.edge_message(cur, Esrc.to(D), Etgt.to(D), Ad, chain)
+                cur = torch.tanh(m @ W[t].to(D)) + cur
+        cur.backward(gout.to(device=device, dtype=dtype))
+        return Ad.grad.detach().cpu().double(), xd.grad.detach().cpu().double()
+
+    ref = run(None, torch.float64, "cpu")
+    plain = run(None)
+    chained = run(QL.MessageChain)
+    for got in (plain, chained):
+        for a, b in zip(got, ref):
+            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    assert (chained[0] - plain[0]).abs().max().item() <= 2e-6 * max(1.0, plain[0].abs().max().item())
+    assert torch.equal(chained[1], plain[1])                    # dx does not go through the chain
+    # two INDEPENDENT uses on one chain: the second branch's backward may run after the first step flushed
+    chain = QL.MessageChain()
+    Ad = A.to(D).requires_grad_(True)
+    xa, xb = x.to(D).requires_grad_(True), (0.5 * x).to(D).requires_grad_(True)
+    ma = QL.edge_message(xa, Esrc.to(D), Etgt.to(D), Ad, chain)
+    mb = QL.edge_message(xb, Esrc.to(D), Etgt.to(D), Ad, chain)
+    (ma * gout.to(D)).sum().backward(retain_graph=True)
+    (mb * gout.to(D)).sum().backward()
+    got = Ad.grad.clone()
+    Ad.grad = None
+    ma2 = QL.edge_message(xa, Esrc.to(D), Etgt.to(D), Ad)
+    mb2 = QL.edge_message(xb, Esrc.to(D), Etgt.to(D), Ad)
+    ((ma2 + mb2) * gout.to(D)).sum().backward()
+    assert (got - Ad.grad).abs().max().item() <= 2e-6 * max(1.0, Ad.grad.abs().max().item())
+
+
 def test_qc_colliding_indices_and_weighted_incidence():
     """Q5 of SURVEY.md: the reference's batches do not offset node ids, so many edges collide on the
     first nodes; Etgt is a dense float matrix whose values are used as weights."""
