@@ -237,6 +237,7 @@ SIGNATURES = {
     "gode_gru_cell_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_gru_cell_f32_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                     c_p]),
+    "gode_gru_wreduce_f32": (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "gode_prof_create": (c_p, [c_i]),
     "gode_prof_destroy": (None, [c_p]),
     "gode_prof_enable": (None, [c_p]),

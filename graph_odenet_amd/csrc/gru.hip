@@ -21,6 +21,25 @@ constexpr int WCHUNK = 64;       // rows per weight-gradient partial
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// a[rr] += sum_j dg[rr][j] W[j][col], j < h3 (dg in LDS, row stride h3; W row-major with leading dimension ldw): 32 weight
+// rows per trip, every load unconditional (clamped row index; a surplus row multiplies a zero).  16 rows per trip made the
+// loop 28 dependent L2 round trips - 42 us per backward launch at N = 380 (87 us before any were overlapped).
+__device__ __forceinline__ void gru_sweep(const float* __restrict__ W, int ldw, const float* __restrict__ dg, int col, int h3,
+                                          float (&a)[RB]) {
+    for (int j0 = 0; j0 < h3; j0 += 32) {
+        float w[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const int j = j0 + u; w[u] = W[(int64_t)(j < h3 ? j : h3 - 1) * ldw + col]; }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int j = j0 + u, jc = j < h3 ? j : h3 - 1;
+            const float wv = j < h3 ? w[u] : 0.f;
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dg[rr * h3 + jc], wv, a[rr]);
+        }
+    }
+}
+
 // forward: block = RB rows.  LDS: xm[RB][2h] | gi[RB][3h] | gh[RB][3h]
 __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
                                                       const float* __restrict__ w_ih, const float* __restrict__ w_hh,
@@ -141,39 +160,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         float a[RB];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) a[rr] = k < h ? dxd[rr * h + k] : 0.f;
-        // 16 weight loads in flight per thread: the loop is a chain of L2 round trips otherwise (87 us at N = 450)
-        int j = 0;
-        for (; j + 16 <= h3; j += 16) {
-            float w16[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) w16[u] = w_ih[(int64_t)(j + u) * h2 + k];
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-#pragma unroll
-                for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgi[rr * h3 + j + u], w16[u], a[rr]);
-        }
-        for (; j < h3; ++j) {
-            const float w = w_ih[(int64_t)j * h2 + k];
-#pragma unroll
-            for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgi[rr * h3 + j], w, a[rr]);
-        }
-        if (k < h) {
-            j = 0;
-            for (; j + 16 <= h3; j += 16) {
-                float w16[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) w16[u] = w_hh[(int64_t)(j + u) * h + k];
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-#pragma unroll
-                    for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgh[rr * h3 + j + u], w16[u], a[rr]);
-            }
-            for (; j < h3; ++j) {
-                const float w = w_hh[(int64_t)j * h + k];
-#pragma unroll
-                for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dgh[rr * h3 + j], w, a[rr]);
-            }
-        }
+        gru_sweep(w_ih, h2, dgi, k, h3, a);
+        if (k < h) gru_sweep(w_hh, h, dgh, k, h3, a);
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
             const int row = row0 + rr;
@@ -271,10 +259,11 @@ extern "C" int gode_gru_cell_f32_bwd(const float* x, const float* m, const float
                                      float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* stream)
 {
     if (n < 0 || h <= 0) return GODE_E_SHAPE;
-    if (!w_ih || !w_hh || !dw_ih || !dw_hh) return GODE_E_NULLPTR;
+    if (!w_ih || !w_hh || (!dw_ih) != (!dw_hh)) return GODE_E_NULLPTR;
     if (n > INT32_MAX || h > 1024) return GODE_E_RANGE;
     hipStream_t s = (hipStream_t)stream;
     const int64_t h3 = 3 * h;
+    if (n == 0 && !dw_ih) return GODE_E_SHAPE;         // partials only: there is nothing to write them from
     if (n == 0) {
         int rc = gode_zero_f32(dw_ih, h3 * 2 * h, stream); if (rc) return rc;
         rc = gode_zero_f32(dw_hh, h3 * h, stream); if (rc) return rc;
@@ -294,8 +283,26 @@ extern "C" int gode_gru_cell_f32_bwd(const float* x, const float* m, const float
     GODE_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_wgrad_kernel, dim3((unsigned)h3, (unsigned)parts), dim3(256), 0, s, x, m, dgi, dgh, (int)n, (int)h, part);
     GODE_LAUNCH_CHECK();
+    if (!dw_ih) return 0;                              // the caller sums the partials of several steps itself (gode_gru_wreduce_f32)
     int64_t rb = (h3 * (h3 + 2) + 255) / 256; if (rb > 1024) rb = 1024;
     hipLaunchKernelGGL(gru_wreduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, part, (int)parts, (int)h, dw_ih, dw_hh, db_ih, db_hh);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
+
+// dW_ih, dW_hh, db_ih, db_hh = sum of n_part partial rows (3h x (3h + 2) floats each, in order): the closing step of
+// gode_gru_cell_f32_bwd on its own, for callers that let several applications of the SAME cell (QC/mpnn.py:30 inside
+// `for t in range(T)`) write their partials back to back and sum them once
+extern "C" int gode_gru_wreduce_f32(const float* part, int64_t n_part, int64_t h, float* dw_ih, float* dw_hh, float* db_ih,
+                                    float* db_hh, void* stream)
+{
+    if (n_part <= 0 || h <= 0) return GODE_E_SHAPE;
+    if (!part || !dw_ih || !dw_hh) return GODE_E_NULLPTR;
+    if (n_part > INT32_MAX || h > 1024) return GODE_E_RANGE;
+    const int64_t h3 = 3 * h;
+    int64_t rb = (h3 * (h3 + 2) + 255) / 256; if (rb > 1024) rb = 1024;
+    hipLaunchKernelGGL(gru_wreduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, part, (int)n_part, (int)h, dw_ih, dw_hh,
+                       db_ih, db_hh);
     GODE_LAUNCH_CHECK();
     return 0;
 }

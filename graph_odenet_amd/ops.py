@@ -811,7 +811,11 @@ def time_row_fixup3_(rows, w_rows, t, at):
 
 
 # ---- QC edge-conditioned messages ---------------------------------------------------------------
-EDGE_MSG_MIN_EDGES = 4096      # from this many edges on, the message step runs as per-edge matvec + SpMM
+# from this many edges on, the message step runs as a block per edge + the per-target sum as an SpMM (two launches); below,
+# one launch whose blocks walk a target's edges one after the other.  Round 4: 256 (was 4 096) - on a 20-molecule batch
+# (760 edges, in-degree up to 8) the serial walk of the busiest target sets the fused launch's duration: 22-25 us against
+# 15-17 us for the two launches (tools/dev/edge_path_ab.py; the results are bit-identical)
+EDGE_MSG_MIN_EDGES = 256
 
 
 def edge_matvec_fwd(Mt, src, A, X):
@@ -931,15 +935,30 @@ def gru_cell_fwd(x, m, w_ih, w_hh, b_ih, b_hh, want_gates=True):
     return out, gates
 
 
-def gru_cell_bwd(x, m, w_ih, w_hh, gates, dout, has_bias=True):
-    """Returns (dx, dm, dw_ih, dw_hh, db_ih, db_hh)."""
+def gru_wgrad_part_len(n, h):
+    """Floats of the weight-gradient partials one gru_cell_bwd call writes."""
+    return int(_lib.load().gode_gru_wgrad_parts(n)) * 3 * h * (3 * h + 2)
+
+
+def gru_cell_bwd(x, m, w_ih, w_hh, gates, dout, has_bias=True, part_out=None):
+    """Returns (dx, dm, dw_ih, dw_hh, db_ih, db_hh).  part_out (a float32 view of gru_wgrad_part_len(n, h) elements): the
+    call writes its weight-gradient partials there and returns None for the four parameter gradients - the caller sums the
+    partials of several applications of the cell with gru_wreduce."""
     lib = _lib.load()
     _need(dout, "dout"); _need(gates, "gates")
     n, h = x.shape
     f = dict(dtype=torch.float32, device=x.device)
     dx, dm = torch.empty_like(x), torch.empty_like(x)
     dgi, dgh = torch.empty(n, 3 * h, **f), torch.empty(n, 3 * h, **f)
-    part = torch.empty(lib.gode_gru_wgrad_parts(n) * 3 * h * (3 * h + 2), **f)
+    if part_out is not None:
+        _need(part_out, "part_out")
+        if part_out.numel() != gru_wgrad_part_len(n, h) or n == 0:
+            raise ValueError("gru_cell_bwd: part_out must hold gru_wgrad_part_len(n, h) floats")
+        check(lib.gode_gru_cell_f32_bwd(ptr(x), ptr(m), ptr(w_ih), ptr(w_hh), ptr(gates), ptr(dout), n, h, ptr(dx), ptr(dm),
+                                        ptr(dgi), ptr(dgh), ptr(part_out), None, None, None, None, stream_ptr()),
+              "gode_gru_cell_f32_bwd")
+        return dx, dm, None, None, None, None
+    part = torch.empty(gru_wgrad_part_len(n, h), **f)
     dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
     db_ih = torch.empty(3 * h, **f) if has_bias else None
     db_hh = torch.empty(3 * h, **f) if has_bias else None
@@ -947,6 +966,22 @@ def gru_cell_bwd(x, m, w_ih, w_hh, gates, dout, has_bias=True):
                                     ptr(dgi), ptr(dgh), ptr(part), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh),
                                     stream_ptr()), "gode_gru_cell_f32_bwd")
     return dx, dm, dw_ih, dw_hh, db_ih, db_hh
+
+
+def gru_wreduce(part, n_part, w_ih, w_hh, has_bias=True):
+    """(dw_ih, dw_hh, db_ih, db_hh) = the sum of the first n_part partial rows of `part` (gode_gru_wreduce_f32)."""
+    lib = _lib.load()
+    _need(part, "part")
+    h = w_hh.shape[1]
+    f = dict(dtype=torch.float32, device=part.device)
+    if part.numel() < n_part * 3 * h * (3 * h + 2):
+        raise ValueError("gru_wreduce: part is too small")
+    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+    db_ih = torch.empty(3 * h, **f) if has_bias else None
+    db_hh = torch.empty(3 * h, **f) if has_bias else None
+    check(lib.gode_gru_wreduce_f32(ptr(part), n_part, h, ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh), stream_ptr()),
+          "gode_gru_wreduce_f32")
+    return dw_ih, dw_hh, db_ih, db_hh
 
 
 # ---- Set2Set attention readout ---------------------------------------------------------------------

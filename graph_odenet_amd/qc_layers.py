@@ -154,10 +154,45 @@ class _EdgeMessageFn(torch.autograd.Function):
         return None, dx, dA, None
 
 
+_CHAINS = {}          # id(edge_data) -> MessageChain of the forward pass that declared the tensor shared (shared_edge_data)
+
+
+class shared_edge_data:
+    """`with shared_edge_data(edge_data): ...` - every edge_message on this tensor inside the block (layers called with the
+    reference's own signatures, QC/layers.py:143-145) joins one MessageChain."""
+
+    def __init__(self, edge_data):
+        self.key = id(edge_data)
+        self.on = torch.is_grad_enabled() and edge_data.requires_grad
+
+    def __enter__(self):
+        if self.on:
+            _CHAINS[self.key] = MessageChain()
+        return self
+
+    def __exit__(self, *exc):
+        _CHAINS.pop(self.key, None)
+        return False
+
+
 def edge_message(x, Esrc, Etgt, edge_data, chain=None):
     """chain: a MessageChain shared by the steps of ONE forward pass that use this edge_data (optional; saves T - 1
-    gradient arrays and additions in the backward pass)."""
+    gradient arrays and additions in the backward pass); default: the one a surrounding shared_edge_data block declared."""
+    if chain is None:
+        chain = _CHAINS.get(id(edge_data))
     return _EdgeMessageFn.apply(_edges(Esrc, Etgt), x, edge_data, chain)
+
+
+class GruChain:
+    """The T applications of ONE update cell inside a message-passing loop (QC/mpnn.py:30): the backward of a step writes its
+    weight-gradient partials into a shared buffer, and the backward of the first step - the last to run - sums the partial
+    rows of all steps once (gode_gru_wreduce_f32).  Autograd would otherwise reduce T times and add the four parameter
+    gradients T - 1 times each.  As with MessageChain, a step whose backward runs after that sum falls back to its own
+    gradients."""
+
+    def __init__(self):
+        self.n_steps = 0
+        self.part, self.plen, self.written, self.flushed = None, 0, 0, False
 
 
 class _GruUpdateFn(torch.autograd.Function):
@@ -165,27 +200,49 @@ class _GruUpdateFn(torch.autograd.Function):
     backward (csrc/gru.hip) - no concatenated input, no library GEMM whose shape changes with every batch."""
 
     @staticmethod
-    def forward(ctx, x, m, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, m, w_ih, w_hh, b_ih, b_hh, chain):
         x, m = x.contiguous(), m.contiguous()
         out, gates = ops.gru_cell_fwd(x, m, w_ih.contiguous(), w_hh.contiguous(), b_ih, b_hh)
         ctx.has_bias = b_ih is not None
+        ctx.chain, ctx.idx = chain, 0
+        if chain is not None:
+            ctx.idx = chain.n_steps
+            chain.n_steps += 1
         ctx.save_for_backward(x, m, w_ih, w_hh, gates)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, m, w_ih, w_hh, gates = ctx.saved_tensors
+        chain = ctx.chain
+        n, h = x.shape
+        if chain is not None and not chain.flushed and n > 0:
+            plen = ops.gru_wgrad_part_len(n, h)
+            if chain.part is None:
+                chain.part, chain.plen = torch.empty(chain.n_steps * plen, dtype=torch.float32, device=x.device), plen
+            if plen == chain.plen and chain.written < chain.n_steps:
+                slot = chain.written
+                chain.written += 1
+                dx, dm = ops.gru_cell_bwd(x, m, w_ih.contiguous(), w_hh.contiguous(), gates, dout.contiguous(), ctx.has_bias,
+                                          part_out=chain.part[slot * plen:(slot + 1) * plen])[:2]
+                if ctx.idx != 0:
+                    return dx, dm, None, None, None, None, None
+                chain.flushed = True
+                rows = chain.written * (plen // (3 * h * (3 * h + 2)))
+                dw_ih, dw_hh, db_ih, db_hh = ops.gru_wreduce(chain.part, rows, w_ih, w_hh, ctx.has_bias)
+                return dx, dm, dw_ih, dw_hh, db_ih, db_hh, None
         dx, dm, dw_ih, dw_hh, db_ih, db_hh = ops.gru_cell_bwd(x, m, w_ih.contiguous(), w_hh.contiguous(), gates,
                                                               dout.contiguous(), ctx.has_bias)
-        return dx, dm, dw_ih, dw_hh, db_ih, db_hh
+        return dx, dm, dw_ih, dw_hh, db_ih, db_hh, None
 
 
 GRU_MAX_H = 640                  # 8 rows x 8h floats of LDS per block (csrc/gru.hip) must fit 160 KB
 GRU_MAX_ROWS = 65535 * 64        # grid.y of the weight-gradient launch (64-row chunks)
 
 
-def gru_update(cell, x, m):
-    """cell(torch.cat([x, m], 1), x) for cell = nn.GRUCell(2h, h), fused.  Outside the fused kernels' limits (h > 640,
+def gru_update(cell, x, m, chain=None):
+    """cell(torch.cat([x, m], 1), x) for cell = nn.GRUCell(2h, h), fused (chain: a GruChain shared by the applications of
+    this cell in one forward pass - optional).  Outside the fused kernels' limits (h > 640,
     more than 4.19 M rows, a state that is not fp32 on the GPU) the update is the module's own call on the
     concatenated input - the reference's line (QC/mpnn.py:30) on the GPU library path - instead of an error."""
     if cell.input_size != 2 * cell.hidden_size or x.shape[1] != cell.hidden_size:
@@ -194,7 +251,7 @@ def gru_update(cell, x, m):
             m.dtype != torch.float32:
         return cell(torch.cat([x, m], 1), x)
     return _GruUpdateFn.apply(x, m, cell.weight_ih, cell.weight_hh, getattr(cell, "bias_ih", None),
-                              getattr(cell, "bias_hh", None))
+                              getattr(cell, "bias_hh", None), chain)
 
 
 class MPNN_enn_edge(nn.Module):
@@ -212,9 +269,10 @@ class MPNN_enn_edge(nn.Module):
 
     def forward(self, x, Esrc, Etgt, edge_data):
         chain = MessageChain() if (torch.is_grad_enabled() and edge_data.requires_grad) else None
+        gchain = GruChain() if (torch.is_grad_enabled() and self.update_net.weight_ih.requires_grad) else None
         for t in range(self.T):
             node_msg = edge_message(x, Esrc, Etgt, edge_data, chain)
-            x = gru_update(self.update_net, x, node_msg)
+            x = gru_update(self.update_net, x, node_msg, gchain)
         return x
 
 
@@ -238,10 +296,10 @@ class EdgeGraphConvolution(Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, Esrc, Etgt, edge_data, chain=None):
+    def forward(self, input, Esrc, Etgt, edge_data):
         from .functional import dense
         support = dense(input, self.weight)
-        output = edge_message(support, Esrc, Etgt, edge_data, chain)
+        output = edge_message(support, Esrc, Etgt, edge_data)
         if self.bias is not None:
             return output + self.bias
         return output

@@ -14,7 +14,7 @@ from . import ops
 from .functional import GroupNorm
 from .functional import Linear as GodeLinear
 from .graph import RECORDS_MIN_NNZ, CSRGraph, csr_from_assignment, incidence_from_index
-from .qc_layers import EdgeGraphConvolution, MessageChain, MPNN_enn_edge
+from .qc_layers import EdgeGraphConvolution, MPNN_enn_edge, shared_edge_data
 
 
 # ---- dense helpers with the reference's module nesting (QC/layers.py:10-86) ------------------------
@@ -339,11 +339,10 @@ class MPNN_ENN_K_Set2Set(_QCBase):
 
 class _EdgeGCNStack(_QCBase):
     def _stack(self, x, Esrc, Etgt, ef):
-        # the layers share the edge matrices `ef`: one pass forms their gradient (qc_layers.MessageChain)
-        chain = MessageChain() if (torch.is_grad_enabled() and ef.requires_grad) else None
-        for gc in self.gcmid[:-1]:
-            x = F.dropout(F.relu(gc(x, Esrc, Etgt, ef, chain)), self.dropout, training=self.training)
-        return self.gcmid[-1](x, Esrc, Etgt, ef, chain)
+        with shared_edge_data(ef):       # the layers share the edge matrices: one pass forms their gradient (qc_layers.MessageChain)
+            for gc in self.gcmid[:-1]:
+                x = F.dropout(F.relu(gc(x, Esrc, Etgt, ef)), self.dropout, training=self.training)
+            return self.gcmid[-1](x, Esrc, Etgt, ef)
 
     def _init_stack(self, node_features, edge_features, target_features, hidden_features, num_layers, dropout):
         self.mlpin = TransitionMLP(node_features, hidden_features)

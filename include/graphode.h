@@ -690,6 +690,11 @@ int gode_gru_cell_f32_fwd(const float* x, const float* m, const float* w_ih, con
 int gode_gru_cell_f32_bwd(const float* x, const float* m, const float* w_ih, const float* w_hh, const float* gates,
                           const float* dout, int64_t n, int64_t h, float* dx, float* dm, float* dgi, float* dgh,
                           float* part, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, void* stream);
+/* dw_ih = dw_hh = NULL above: the call stops after writing its gode_gru_wgrad_parts(n) partial rows (3h (3h + 2) floats each)
+ * to `part`; gode_gru_wreduce_f32 sums n_part such rows - e.g. those of the T applications of one cell inside a message
+ * passing loop, written back to back - into the four parameter gradients (db_* nullable) */
+int gode_gru_wreduce_f32(const float* part, int64_t n_part, int64_t h, float* dw_ih, float* dw_hh, float* db_ih,
+                         float* db_hh, void* stream);
 
 /* ---- measurement aid (bench.py): HIP-event brackets around the dominant kernels ----------
  * While a profiler is enabled (process-wide; one measuring client at a time), every gode_spmm_csr_f32 main-kernel launch

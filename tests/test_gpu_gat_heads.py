@@ -558,8 +558,8 @@ def test_one_launch_dense_half_matches_multi_launch_path(golden, heads, d, metho
             return ((a - b).abs() / (b.abs() + 1e-3)).median().item()
         assert typical(res[1][1], res[0][1]) <= 1e-2, "dx (median entry)"
         if method == "rk4":                                 # adaptive steps on those rows: accept / reject moves with rounding
-            # norm-wise bar: 0.25.  It was 0.1 while the one-launch path summed its products in sub-group order (rounds 2-3:
-            # 0.03-0.09 measured); with both of its products on the matrix instruction (round 4: gat_project_d64_kernel,
+            # norm-wise bar: 0.25.  It was 0.1 (and held) while the one-launch path summed its products in sub-group order
+            # (rounds 2-3); with both of its products on the matrix instruction (round 4: gat_project_d64_kernel,
             # gat_dense_vjp_d64_kernel - each within the same 2e-5 of float64 as the kernels they replace, test above) the
             # one-head case measures 0.18: the norm is carried by the handful of rows with rstd ~ 316, where any change of
             # summation order moves the result by this much (the median entry, asserted above, agrees to 1e-2)

@@ -382,6 +382,49 @@ def test_message_chain_forms_the_edge_matrix_gradient_once():
     assert (got - Ad.grad).abs().max().item() <= 2e-6 * max(1.0, Ad.grad.abs().max().item())
 
 
+def test_gru_chain_sums_the_weight_gradient_partials_once():
+    """qc_layers.GruChain: T applications of one nn.GRUCell(2h, h) in a message-passing loop (QC/mpnn.py:30).  With a chain
+    every step's backward writes its weight-gradient partials into one buffer and the first step's backward sums all partial
+    rows once (gode_gru_wreduce_f32); without it autograd adds T gradients per parameter.  Same numbers to fp32 summation
+    accuracy, and against torch's own GRUCell on the CPU in float64."""
+    from graph_odenet_amd import qc_layers as QL
+    h, n, T = 29, 333, 3
+    g = torch.Generator().manual_seed(5)
+    cell = torch.nn.GRUCell(2 * h, h)
+    x0 = torch.randn(n, h, generator=g)
+    ms = [torch.randn(n, h, generator=g) for _ in range(T)]
+    gout = torch.randn(n, h, generator=g)
+    c64 = torch.nn.GRUCell(2 * h, h).double()
+    c64.load_state_dict({k: v.double() for k, v in cell.state_dict().items()})
+    xr = x0.double().requires_grad_(True)
+    cur = xr
+    for t in range(T):
+        cur = c64(torch.cat([cur, ms[t].double()], 1), cur)
+    cur.backward(gout.double())
+    want = [xr.grad] + [p.grad for p in c64.parameters()]
+    D = dev()
+    cell = cell.to(D)
+    res = {}
+    for use_chain in (False, True):
+        for p in cell.parameters():
+            p.grad = None
+        xd = x0.to(D).requires_grad_(True)
+        chain = QL.GruChain() if use_chain else None
+        cur = xd
+        for t in range(T):
+            cur = QL.gru_update(cell, cur, ms[t].to(D), chain)
+        cur.backward(gout.to(D))
+        res[use_chain] = [xd.grad.cpu().double()] + [p.grad.cpu().double() for p in cell.parameters()]
+        if use_chain:
+            assert chain.flushed and chain.written == T
+    for got in res.values():
+        for a, b in zip(got, want):
+            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    assert torch.equal(res[True][0], res[False][0])                # dx does not go through the chain
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+
+
 def test_qc_colliding_indices_and_weighted_incidence():
     """Q5 of SURVEY.md: the reference's batches do not offset node ids, so many edges collide on the
     first nodes; Etgt is a dense float matrix whose values are used as weights."""
