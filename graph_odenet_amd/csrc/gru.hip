@@ -21,7 +21,8 @@ constexpr int WCHUNK = 64;       // rows per weight-gradient partial
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// a[rr] += sum_j dg[rr][j] W[j][col], j < h3 (dg in LDS, row stride h3; W row-major with leading dimension ldw): 32 weight
+static_assert(RB == 8, "gru_sweep reads the eight rows of a gate column as two float4");
+// a[rr] += sum_j dg[j][rr] W[j][col], j < h3 (dg in LDS as [3h][RB]; W row-major with leading dimension ldw): 32 weight
 // rows per trip, every load unconditional (clamped row index; a surplus row multiplies a zero).  16 rows per trip made the
 // loop 28 dependent L2 round trips - 42 us per backward launch at N = 380 (87 us before any were overlapped).
 __device__ __forceinline__ void gru_sweep(const float* __restrict__ W, int ldw, const float* __restrict__ dg, int col, int h3,
@@ -34,13 +35,16 @@ __device__ __forceinline__ void gru_sweep(const float* __restrict__ W, int ldw, 
         for (int u = 0; u < 32; ++u) {
             const int j = j0 + u, jc = j < h3 ? j : h3 - 1;
             const float wv = j < h3 ? w[u] : 0.f;
-#pragma unroll
-            for (int rr = 0; rr < RB; ++rr) a[rr] = fmaf(dg[rr * h3 + jc], wv, a[rr]);
+            // dg is [j][RB] in LDS: the eight rows' values of gate column j are two 16-byte reads (row-major [RB][3h] took
+            // eight 4-byte reads per j: 3 500 LDS instructions per thread, which - not the weight loads - bounded the kernel)
+            const float4 d0 = *reinterpret_cast<const float4*>(dg + jc * RB), d1 = *reinterpret_cast<const float4*>(dg + jc * RB + 4);
+            a[0] = fmaf(d0.x, wv, a[0]); a[1] = fmaf(d0.y, wv, a[1]); a[2] = fmaf(d0.z, wv, a[2]); a[3] = fmaf(d0.w, wv, a[3]);
+            a[4] = fmaf(d1.x, wv, a[4]); a[5] = fmaf(d1.y, wv, a[5]); a[6] = fmaf(d1.z, wv, a[6]); a[7] = fmaf(d1.w, wv, a[7]);
         }
     }
 }
 
-// forward: block = RB rows.  LDS: xm[RB][2h] | gi[RB][3h] | gh[RB][3h]
+// forward: block = RB rows.  LDS: xm[2h][RB] | gi[RB][3h] | gh[RB][3h]
 __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ x, const float* __restrict__ m,
                                                       const float* __restrict__ w_ih, const float* __restrict__ w_hh,
                                                       const float* __restrict__ b_ih, const float* __restrict__ b_hh,
@@ -56,9 +60,14 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
         const int rr = idx / h2, k = idx % h2, row = row0 + rr;
         float v = 0.f;
         if (row < n) v = k < h ? x[(int64_t)row * h + k] : m[(int64_t)row * h + (k - h)];
-        xm[idx] = v;
+        xm[k * RB + rr] = v;                            // [input column][row]: the eight rows of a column are two 16-byte reads
     }
     __syncthreads();
+    auto fma8 = [](float (&acc)[RB], float w, const float* __restrict__ col) {
+        const float4 d0 = *reinterpret_cast<const float4*>(col), d1 = *reinterpret_cast<const float4*>(col + 4);
+        acc[0] = fmaf(w, d0.x, acc[0]); acc[1] = fmaf(w, d0.y, acc[1]); acc[2] = fmaf(w, d0.z, acc[2]); acc[3] = fmaf(w, d0.w, acc[3]);
+        acc[4] = fmaf(w, d1.x, acc[4]); acc[5] = fmaf(w, d1.y, acc[5]); acc[6] = fmaf(w, d1.z, acc[6]); acc[7] = fmaf(w, d1.w, acc[7]);
+    };
     for (int j = threadIdx.x; j < h3; j += 256) {       // gate column j of every row of the block: weights read once
         float ai[RB], ah[RB];
         const float bi = b_ih ? b_ih[j] : 0.f, bh = b_hh ? b_hh[j] : 0.f;
@@ -72,14 +81,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 8; ++u) w8[u] = wi[k + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int rr = 0; rr < RB; ++rr) ai[rr] = fmaf(w8[u], xm[rr * h2 + k + u], ai[rr]);
+            for (int u = 0; u < 8; ++u) fma8(ai, w8[u], xm + (k + u) * RB);
         }
         for (; k < h2; ++k) {
-            const float w = wi[k];
-#pragma unroll
-            for (int rr = 0; rr < RB; ++rr) ai[rr] = fmaf(w, xm[rr * h2 + k], ai[rr]);
+            fma8(ai, wi[k], xm + k * RB);
         }
         k = 0;
         for (; k + 8 <= h; k += 8) {
@@ -87,14 +92,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 8; ++u) w8[u] = wh[k + u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int rr = 0; rr < RB; ++rr) ah[rr] = fmaf(w8[u], xm[rr * h2 + k + u], ah[rr]);
+            for (int u = 0; u < 8; ++u) fma8(ah, w8[u], xm + (k + u) * RB);
         }
         for (; k < h; ++k) {
-            const float w = wh[k];
-#pragma unroll
-            for (int rr = 0; rr < RB; ++rr) ah[rr] = fmaf(w, xm[rr * h2 + k], ah[rr]);
+            fma8(ah, wh[k], xm + k * RB);
         }
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) { gi[rr * h3 + j] = ai[rr]; gh[rr * h3 + j] = ah[rr]; }
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
         const float z = sigmoidf_(gi[rr * h3 + h + c] + gh[rr * h3 + h + c]);
         const float hn = gh[rr * h3 + 2 * h + c];
         const float nn = tanhf(gi[rr * h3 + 2 * h + c] + r * hn);
-        const float xv = xm[rr * h2 + c];
+        const float xv = xm[c * RB + rr];
         out[(int64_t)row * h + c] = (1.0f - z) * nn + z * xv;
         if (gates) {
             float* g = gates + (int64_t)row * 4 * h;
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
             oi[c] = gr; oi[h + c] = gz; oi[2 * h + c] = gn;
             oh[c] = gr; oh[h + c] = gz; oh[2 * h + c] = ghn;
         }
-        dgi[rr * h3 + c] = gr; dgi[rr * h3 + h + c] = gz; dgi[rr * h3 + 2 * h + c] = gn;
-        dgh[rr * h3 + c] = gr; dgh[rr * h3 + h + c] = gz; dgh[rr * h3 + 2 * h + c] = ghn;
+        dgi[c * RB + rr] = gr; dgi[(h + c) * RB + rr] = gz; dgi[(2 * h + c) * RB + rr] = gn;         // [gate column][row]
+        dgh[c * RB + rr] = gr; dgh[(h + c) * RB + rr] = gz; dgh[(2 * h + c) * RB + rr] = ghn;
         dxd[rr * h + c] = d0;
     }
     __syncthreads();

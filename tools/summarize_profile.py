@@ -27,10 +27,14 @@ def short(name):
 
 # 1) kernel stats
 lines = []
-for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+for f in sorted(glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)):
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py   (round %s)" % tag)
+    # bench.py runs tools/config_bench.py (the other BASELINE configurations) as a child process first: the profiler writes one
+    # table per process - the one with the SpMM on top is the benchmark itself
+    is_main = any("spmm_vec4_kernel" in r["Name"] for r in rows[:3])
+    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py   (round %s; %s)"
+                 % (tag, "the benchmark process: C5" if is_main else "its child process tools/config_bench.py: configurations C1-C4"))
     lines.append("# %-46s %7s %12s %12s %7s" % ("kernel", "calls", "avg_us", "total_ms", "pct"))
     for r in rows[:25]:
         lines.append("%-48s %7s %12.1f %12.2f %6.1f%%" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
