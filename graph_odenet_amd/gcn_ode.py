@@ -46,7 +46,9 @@ class _Shared:
         self._ky = self._ka = self._kt = None
         self._parts = None
         # rows of the per-block column sums the forward-recompute SpMM of an adjoint stage can leave (0: not on this shape)
-        self.y2_rows = _lib.load().gode_spmm_y2_colsum_rows(graph.n_items if graph.items is not None else n, graph.n_long, d)
+        self.y2_rows = 0                       # (a row-partitioned graph runs the per-stage Python path: no per-block sums)
+        if not getattr(graph, "is_partitioned", False) and hasattr(graph, "n_items"):
+            self.y2_rows = _lib.load().gode_spmm_y2_colsum_rows(graph.n_items if graph.items is not None else n, graph.n_long, d)
         self._y2_colsum = None
 
     def bwd(self):
