@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def _time_steps(fn, warm=3, n=10):
+def _time_steps(fn, warm=5, n=20):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -96,13 +96,14 @@ def c1_cora(dev, cpu=True):
     sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     ms, (nf, nb) = _time_steps(_trainer(m, lambda: m(x, adj), idx, y))
     res = {"workload": "Cora 2708 nodes, ODEGCN3 hidden 16, rk4 64 f-evals", "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
+    yield dict(res)              # GPU part done (all_configs times every configuration on the GPU before any CPU leg)
     if cpu:
         from oracle import models_ref as M
         p = M.leaves(sd0)
         xc, ac, yc, ic = x.cpu(), adj.cpu(), y.cpu(), idx.cpu()
         t = _cpu_full_step(lambda: F.nll_loss(M.odegcn3(p, xc, ac, 0.5, True, "rk4", 1 / 16)[0][ic], yc[ic]), p, 0.01, 5e-4)
         res.update(_cpu_fields(t, "whole training steps of the oracle's ODEGCN3 (rk4, 64 + 64 evaluations, Adam): 1 warm-up, median of 3"))
-    return res
+    yield res
 
 
 def c2_pubmed(dev, cpu=True):
@@ -121,6 +122,7 @@ def c2_pubmed(dev, cpu=True):
     ms, (nf, nb) = _time_steps(_trainer(m, lambda: m(x, adj), tr, y))
     res = {"workload": "Pubmed 19717 nodes (real topology, synthetic features), GCN-dense-paper ODEGCN3 hidden 16, dopri5 tol 1e-5",
            "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
+    yield dict(res)              # GPU part done (all_configs times every configuration on the GPU before any CPU leg)
     if cpu:
         # bounded sample: one evaluation of the oracle's ODE function (dense 19717 x 19717 adjacency, as the reference
         # holds it) and one evaluation with its VJP, scaled by the evaluation counts of the GPU step above; the two
@@ -147,7 +149,7 @@ def c2_pubmed(dev, cpu=True):
                                "oracle ODE function on the dense adjacency: f-eval %.1f ms, f-eval + VJP %.1f ms (1 warm-up, median of 3 each), "
                                "first + last layer forward and backward %.1f ms; scaled to the GPU step's %d forward and %d adjoint evaluations"
                                % (t_f, t_fb, t_l, nf, nb)))
-    return res
+    yield res
 
 
 def c3_citeseer_gat(dev, heads, nhid, cpu=True):
@@ -168,6 +170,7 @@ def c3_citeseer_gat(dev, heads, nhid, cpu=True):
     ms, (nf, nb) = _time_steps(_trainer(m, lambda: m(x, src, tgt, Mtgt), idx, y))
     res = {"workload": "Citeseer 3327 nodes / %d edges, GAT ODEGCN3 %d head(s), hidden %d, rk4 64 f-evals" % (e, heads, nhid),
            "ms_per_step": round(ms, 3), "nfe_f": nf, "nfe_b": nb}
+    yield dict(res)              # GPU part done (all_configs times every configuration on the GPU before any CPU leg)
     if cpu:
         from oracle import models_ref as M
         p = M.leaves(sd0)
@@ -177,7 +180,7 @@ def c3_citeseer_gat(dev, heads, nhid, cpu=True):
                            p, 0.01, 5e-4)
         res.update(_cpu_fields(t, "whole training steps of the oracle's GAT ODEGCN3 (%d reference layer(s) per graph layer, rk4, 64 + 64 "
                                   "evaluations, Adam): 1 warm-up, median of 3" % heads))
-    return res
+    yield res
 
 
 def c4_qc(dev, model_name, cpu=True, n_timed=100):
@@ -239,6 +242,7 @@ def c4_qc(dev, model_name, cpu=True, n_timed=100):
             res.update(extra)
         except Exception as e:
             res["ms_per_step" if mode == "auto" else "ms_per_step_" + mode] = "error: %s: %s" % (type(e).__name__, e)
+    yield dict(res)              # GPU part done (all_configs times every configuration on the GPU before any CPU leg)
     if cpu and net is not None:
         from oracle import models_ref as M
         p = M.leaves(net.state_dict())
@@ -248,24 +252,36 @@ def c4_qc(dev, model_name, cpu=True, n_timed=100):
         t = _cpu_full_step(lambda: F.mse_loss(fn(p, x, ef, Esrc, Etgt, batch, 20, **kw), tgt), p, 1e-3, 0.0)
         res.update(_cpu_fields(t, "whole training steps of the oracle's %s on ONE batch of 20 molecules (dense Etgt, bmm messages, "
                                   "torch Adam): 1 warm-up, median of 3" % model_name))
-    return res
+    yield res
 
 
 def all_configs(dev, cpu=True, only=None):
-    out = {}
-    for key, fn in (("C1_cora_gcn_ode_rk4", lambda: c1_cora(dev, cpu)),
-                    ("C2_pubmed_dense_paper_ode_dopri5", lambda: c2_pubmed(dev, cpu)),
-                    ("C3_citeseer_gat_8head_ode_rk4", lambda: c3_citeseer_gat(dev, 8, 64, cpu)),
-                    ("C3_citeseer_gat_1head_ode_rk4", lambda: c3_citeseer_gat(dev, 1, 16, cpu)),
-                    ("C4_qc_edge_gcn_sum", lambda: c4_qc(dev, "EdgeGCN_K_Sum", cpu)),
-                    ("C4_qc_mpnn_enn_set2set", lambda: c4_qc(dev, "MPNN_ENN_K_Set2Set", cpu))):
+    """Every configuration's GPU timing FIRST, then the CPU legs: a CPU leg is tens of seconds of 128-thread work, and the
+    launch-bound configurations timed right after one came out 15-45 % slow (host clocks / thread pool still busy:
+    EdgeGCN 1.72 ms against 1.17 ms in a process without CPU legs)."""
+    out, gens = {}, {}
+    table = (("C1_cora_gcn_ode_rk4", lambda: c1_cora(dev, cpu)),
+             ("C2_pubmed_dense_paper_ode_dopri5", lambda: c2_pubmed(dev, cpu)),
+             ("C3_citeseer_gat_8head_ode_rk4", lambda: c3_citeseer_gat(dev, 8, 64, cpu)),
+             ("C3_citeseer_gat_1head_ode_rk4", lambda: c3_citeseer_gat(dev, 1, 16, cpu)),
+             ("C4_qc_edge_gcn_sum", lambda: c4_qc(dev, "EdgeGCN_K_Sum", cpu)),
+             ("C4_qc_mpnn_enn_set2set", lambda: c4_qc(dev, "MPNN_ENN_K_Set2Set", cpu)))
+    for key, fn in table:
         if only and not any(key.startswith(o) for o in only):
             continue
         try:
-            out[key] = fn()
-        except Exception as e:                     # a secondary number must never take the contract line down
+            gens[key] = fn()
+            out[key] = next(gens[key])                 # the GPU part
+        except Exception as e:                         # a secondary number must never take the contract line down
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            gens.pop(key, None)
         torch.cuda.empty_cache()
+    for key, g in gens.items():                        # the CPU legs (a generator without one simply ends)
+        try:
+            for res in g:
+                out[key] = res
+        except Exception as e:
+            out[key]["cpu_error"] = "%s: %s" % (type(e).__name__, e)
     return out
 
 

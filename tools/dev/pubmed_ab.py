@@ -10,6 +10,6 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 for fused in (1, 0, 1, 0):
     lib.gode_set_option(b"small_fused", fused)
-    r = cb.c2_pubmed(dev)
+    r = next(cb.c2_pubmed(dev, cpu=False))
     print("small_fused", fused, r["ms_per_step"], r["nfe_f"], r["nfe_b"], flush=True)
 lib.gode_set_option(b"small_fused", 1)
