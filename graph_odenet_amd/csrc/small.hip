@@ -466,10 +466,7 @@ int small_cg(int64_t d, int32_t groups) {
 
 // four rows per wave from 8 192 rows on (see gcn_feval_small_kernel)
 bool rows4(int64_t n) { return n >= 8192; }
-// EIGHT rows per wave in the evaluation kernel from 16 384 rows on: with four, Pubmed's 19 717 rows are 1 233 blocks - more
-// than the chip holds at once (~4.5 blocks per CU at 97 registers), i.e. two rounds of the kernel's ~8 us latency chain
-bool rows8(int64_t n) { return n >= 16384; }
-int64_t feval_blocks(int64_t n) { const int64_t per = rows8(n) ? 32 : (rows4(n) ? 16 : 4); int64_t b = (n + per - 1) / per; if (b < 1) b = 1; if (b > 2048) b = 2048; return b; }
+int64_t feval_blocks(int64_t n) { const int64_t per = rows4(n) ? 16 : 4; int64_t b = (n + per - 1) / per; if (b < 1) b = 1; if (b > 2048) b = 2048; return b; }
 
 }  // namespace
 
@@ -524,8 +521,8 @@ extern "C" int gode_gcn_feval_small_next_f32(const gode_gcn_odefunc_t* f, const 
     const int64_t d = f->d;
     const int cg = small_cg(d, f->groups);
     const dim3 grid((unsigned)feval_blocks(f->n));
-    const bool r4 = rows4(f->n), r8 = rows8(f->n);
-#define GODE_FEV(DV, CGV) if (r8) GODE_FEV_(DV, CGV, 8) else if (r4) GODE_FEV_(DV, CGV, 16) else GODE_FEV_(DV, CGV, 64)
+    const bool r4 = rows4(f->n);
+#define GODE_FEV(DV, CGV) if (r4) GODE_FEV_(DV, CGV, 16) else GODE_FEV_(DV, CGV, 64)
 #define GODE_FEV_(DV, CGV, GWV) hipLaunchKernelGGL((gcn_feval_small_kernel<DV, CGV, GWV>), grid, dim3(256), 0, (hipStream_t)stream,         \
                                              f->A.rowptr, f->A.col, f->A.val, lx, (int)f->n, f->eps, f->gamma, f->beta, f->W,    \
                                              f->b, t, alpha, lp, lcot, Y2, out, lnext, x_next);
