@@ -204,6 +204,7 @@ SIGNATURES = {
     "gode_segment_attention_f32_fwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_segment_attention_f32_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_assign_csr_supported": (c_i, [c_i64, c_i64]),
+    "gode_dense_first_nonzero_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "gode_assign_csr_i32": (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "gode_set2set_supported": (c_i, [c_i64]),
     "gode_set2set_f32_fwd": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),

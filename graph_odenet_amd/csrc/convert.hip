@@ -73,7 +73,50 @@ __global__ __launch_bounds__(NT) void assign_csr_kernel(const int64_t* __restric
     }
 }
 
+// index[c] = first row r with M[r][c] != 0 (0 for an all-zero column): the reference collate's dense N x E target matrix
+// (QC/datasets/utils.py:194-214, one entry per edge column) back to the per-edge target vector, on the device and without
+// a validity check.  What `(M != 0).to(uint8).argmax(0)` computes in three library launches, 50-80 us for a 380 x 760 batch
+// (the arg-max reduction walks the columns with a handful of threads).  A block owns 32 columns x 8 row slices: coalesced
+// 128-byte row segments, eight rows per trip in flight, the slices' first hits combined through LDS.
+__global__ __launch_bounds__(256) void dense_first_nonzero_kernel(const float* __restrict__ M, int64_t ld, int n_rows, int n_cols,
+                                                                 int64_t* __restrict__ index)
+{
+    __shared__ int first[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const int per = (n_rows + 7) / 8, r0 = sl * per, r1 = min(n_rows, r0 + per);
+    const int cc = c < n_cols ? c : n_cols - 1;
+    int f = INT32_MAX;
+    for (int r = r0; r < r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = M[(int64_t)(r + u < r1 ? r + u : r1 - 1) * ld + cc];        // unconditional, clamped
+#pragma unroll
+        for (int u = 7; u >= 0; --u) if (r + u < r1 && v[u] != 0.f) f = min(f, r + u);
+    }
+    first[sl][cl] = f;
+    __syncthreads();
+    if (sl == 0 && c < n_cols) {
+        int m = first[0][cl];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) m = min(m, first[q][cl]);
+        index[c] = m == INT32_MAX ? 0 : m;
+    }
+}
+
 }  // namespace
+
+extern "C" int gode_dense_first_nonzero_f32(const float* M, int64_t ld, int64_t n_rows, int64_t n_cols, int64_t* index, void* stream)
+{
+    if (n_rows < 0 || n_cols < 0 || ld < n_cols) return GODE_E_SHAPE;
+    if (n_cols == 0) return 0;
+    if (!index || (n_rows > 0 && !M)) return GODE_E_NULLPTR;
+    if (n_rows > INT32_MAX - 16 || n_cols > INT32_MAX - 64) return GODE_E_RANGE;
+    if (n_rows == 0) return GODE_E_SHAPE;                          // (torch raises on an arg-max over an empty dimension as well)
+    hipLaunchKernelGGL(dense_first_nonzero_kernel, dim3((unsigned)((n_cols + 31) / 32)), dim3(256), 0, (hipStream_t)stream, M, ld,
+                       (int)n_rows, (int)n_cols, index);
+    GODE_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int gode_assign_csr_supported(int64_t n_entries, int64_t n_rows) {
     return n_entries >= 0 && n_entries <= kMaxEntries && n_rows > 0 && n_rows <= kMaxRows;

@@ -849,6 +849,18 @@ def edge_matvec_bwd(edge_row, edge_val, src, A, X, dM, want_dA=True, want_dx=Tru
     return dA, dxe
 
 
+def dense_first_nonzero(M):
+    """index[c] = first row with M[r, c] != 0 (0 for an all-zero column) of a dense 2-D fp32 matrix: what
+    `(M != 0).to(torch.uint8).argmax(0)` returns, in one launch (csrc/convert.hip)."""
+    lib = _lib.load()
+    ld = _need_rows(M, "M")
+    n, e = M.shape
+    out = torch.empty(e, dtype=torch.int64, device=M.device)
+    if e:
+        check(lib.gode_dense_first_nonzero_f32(ptr(M), ld, n, e, ptr(out), stream_ptr()), "gode_dense_first_nonzero_f32")
+    return out
+
+
 EDGE_OUTER_MAX_TERMS = 8        # GODE_MAX_TERMS: message steps whose edge-matrix gradient one launch sums
 
 

@@ -39,6 +39,15 @@ from .qc_batch import pad_batch, prepare
 from .qc_step import CapturedQCStep
 
 
+def _target_index(Etgt):
+    """The per-edge target vector off the collate's dense N x E matrix: (Etgt != 0).to(uint8).argmax(0), in one launch
+    where the matrix is a 2-D fp32 GPU tensor with unit column stride (csrc/convert.hip)."""
+    if Etgt.is_cuda and Etgt.dtype == torch.float32 and Etgt.dim() == 2 and Etgt.stride(1) == 1 and Etgt.shape[0] > 0:
+        from . import ops
+        return ops.dense_first_nonzero(Etgt)
+    return (Etgt != 0).to(torch.uint8).argmax(0)
+
+
 class TrainStep:
     def __init__(self, model, optimizer, criterion, mode="auto", exchange=None):
         if mode not in ("auto", "eager", "prepared", "captured"):
@@ -65,14 +74,14 @@ class TrainStep:
         n_graphs = target.shape[0]
         if self.mode == "captured":
             if not by_index:
-                Etgt = (Etgt != 0).to(torch.uint8).argmax(0)         # one entry per edge column (the collate's layout)
+                Etgt = _target_index(Etgt)                           # one entry per edge column (the collate's layout)
             x, edge_feat, Esrc, Etgt, batch, _ = pad_batch(x, edge_feat, Esrc, Etgt, batch, n_graphs=n_graphs)
             if self._captured is None:
                 self._captured = CapturedQCStep(self.model, self.opt, self.criterion, exchange=self.exchange)
             return self._captured(x, edge_feat, Esrc, Etgt, batch, target, n_graphs=n_graphs + 1)
         if self.mode == "prepared":
             if not by_index:
-                Etgt = (Etgt != 0).to(torch.uint8).argmax(0)         # one entry per edge column (the collate's layout)
+                Etgt = _target_index(Etgt)                           # one entry per edge column (the collate's layout)
             Etgt, batch = prepare(Esrc, Etgt, batch, x.shape[0], n_graphs)
         # Without an exchange the gradients are DROPPED, not zeroed: autograd then hands every parameter its gradient
         # tensor as it is (no fill launch before the step, no `grad += new` launch after it - ~2 x 25 launches of a

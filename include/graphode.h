@@ -447,6 +447,10 @@ int gode_segment_attention_f32_bwd(const int32_t* segptr, const int32_t* perm, c
  * vals_out not: ones).  Entries with an index outside [0, n_rows) are dropped (rowptr[n_rows] counts what is left).
  * One workgroup; n_entries <= 2048, n_rows <= 4096 (gode_assign_csr_supported), else GODE_E_UNSUPPORTED. */
 int gode_assign_csr_supported(int64_t n_entries, int64_t n_rows);
+/* index[c] = first row r with M[r][c] != 0 (0 for an all-zero column), M row-major n_rows x n_cols fp32 with leading dimension
+ * ld: the reference collate's dense N x E target matrix (QC/datasets/utils.py:194-214) back to the per-edge target vector -
+ * `(M != 0).to(uint8).argmax(0)` in one launch (round 4) */
+int gode_dense_first_nonzero_f32(const float* M, int64_t ld, int64_t n_rows, int64_t n_cols, int64_t* index, void* stream);
 int gode_assign_csr_i32(const int64_t* index, int64_t n_entries, int64_t n_rows, int32_t* rowptr, int32_t* order,
                         const float* vals, float* vals_out, void* stream);
 

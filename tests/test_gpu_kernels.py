@@ -941,6 +941,28 @@ def test_piece_gemm_large_magnitude_spread():
     assert bool(((got - ref).abs() <= 1e-6 * bound).all())
 
 
+def test_dense_first_nonzero_equals_the_argmax_expression():
+    """gode_dense_first_nonzero_f32 (the collate's dense N x E target matrix back to the per-edge target vector, in one
+    launch) against `(M != 0).to(uint8).argmax(0)`: several entries per column (the first one counts), all-zero columns
+    (index 0), negative and tiny values, one row, a column block of a wider matrix."""
+    from graph_odenet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for n, e in ((380, 760), (1, 5), (9, 1), (1000, 3000), (37, 33)):
+        M = torch.zeros(n, e)
+        rows = torch.randint(0, n, (e,), generator=g)
+        M[rows, torch.arange(e)] = torch.randn(e, generator=g).sign() * (torch.rand(e, generator=g) * 1e-20 + 1e-30)
+        extra = torch.randint(0, n, (e // 3,), generator=g)
+        M[extra, torch.randint(0, e, (e // 3,), generator=g)] = 2.0          # second entries in some columns
+        M[:, ::7] = 0.0                                                      # all-zero columns
+        want = (M != 0).to(torch.uint8).argmax(0)
+        got = ops.dense_first_nonzero(M.to(dev())).cpu()
+        assert got.dtype == torch.int64 and torch.equal(got, want), (n, e)
+        wide = torch.full((n, e + 5), 3.0)
+        wide[:, :e] = M
+        got2 = ops.dense_first_nonzero(wide.to(dev())[:, :e]).cpu()          # leading dimension e + 5
+        assert torch.equal(got2, want)
+
+
 def test_one_launch_assignment_csr_matches_the_sort_based_path():
     """csrc/convert.hip gode_assign_csr_i32 (a QC mini-batch's edge -> atom and atom -> graph vectors as CSR in one launch)
     against graph.csr_from_assignment's sort-based path: row pointers, the STABLE order inside every row, gathered values;
