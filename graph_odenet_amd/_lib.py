@@ -131,9 +131,10 @@ SIGNATURES = {
     "gode_rect_gemm_nt_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "gode_rect_wgrad_parts": (c_i64, [c_i64]),
     "gode_rect_wgrad_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p]),
+    "gode_rect_wgrad_sum_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "gode_gemm_f32": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i, c_p, c_i64, c_p]),
     "gode_gemm_splitk_parts": (c_i64, [c_i64, c_i64, c_i64]),
-    "gode_gemm_splitk_f32": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p]),
+    "gode_gemm_splitk_f32": (c_i, [c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p]),
     "gode_cut_pad": (c_i64, [c_i64]),
     "gode_cut_bf16x3_f32": (c_i, [c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "gode_pgemm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),

@@ -247,7 +247,7 @@ extern "C" int64_t gode_gemm_splitk_parts(int64_t M, int64_t N, int64_t K) {
     return ch > 0 ? (K + ch - 1) / ch : 1;
 }
 extern "C" int gode_gemm_splitk_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                                    const float* B, int64_t ldb, float* part, void* stream)
+                                    const float* B, int64_t ldb, float* part, float* C, void* stream)
 {
     if (M <= 0 || N <= 0 || K <= 0) return GODE_E_SHAPE;
     if (!A || !B || !part) return GODE_E_NULLPTR;
@@ -266,7 +266,9 @@ extern "C" int gode_gemm_splitk_f32(int trans_a, int trans_b, int64_t M, int64_t
     else GODE_GEMMK(false, true);
 #undef GODE_GEMMK
     GODE_LAUNCH_CHECK();
-    return 0;
+    // C (nullable, M x N contiguous): the sum of the parts, by the library's fixed-order reduction - one call from the host
+    // instead of two (the QC step is bound by the host's launch rate on a slow host)
+    return C ? gode_reduce_parts_f32(C, part, parts, M * N, 1.f, 0, stream) : 0;
 }
 
 extern "C" int64_t gode_adam_chunk(void) { return kAdamChunk; }

@@ -287,3 +287,14 @@ extern "C" int gode_rect_wgrad_f32(const float* X, int64_t ldx, int64_t n_rows, 
     GODE_LAUNCH_CHECK();
     return 0;
 }
+
+// the same followed by the fixed-order sum of the partials into dW (K x M, contiguous): one call from the host instead of two
+extern "C" int gode_rect_wgrad_sum_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, const float* dS, int64_t ldds,
+                                       int64_t M, float* part, float* dW, void* stream)
+{
+    if (!dW) return GODE_E_NULLPTR;
+    const int rc = gode_rect_wgrad_f32(X, ldx, n_rows, K, dS, ldds, M, part, stream);
+    if (rc) return rc;
+    if (n_rows == 0) return gode_zero_f32(dW, K * M, stream);
+    return gode_reduce_parts_f32(dW, part, gode_rect_wgrad_parts(n_rows), K * M, 1.f, 0, stream);
+}

@@ -467,6 +467,10 @@ def rect_wgrad(x, dS):
     for m0 in range(0, M, 128):                       # the kernel takes up to 128 output columns per call
         mw = min(128, M - m0)
         part = torch.empty(n_part, K * mw, dtype=torch.float32, device=x.device)
+        if mw == M:                                   # one column block: partials and their sum in ONE call
+            check(lib.gode_rect_wgrad_sum_f32(ptr(x), ldx, n, K, ptr(dS), ldds, mw, ptr(part), ptr(out), stream_ptr()),
+                  "gode_rect_wgrad_sum_f32")
+            return out
         check(lib.gode_rect_wgrad_f32(ptr(x), ldx, n, K, dS.data_ptr() + 4 * m0, ldds, mw, ptr(part), stream_ptr()),
               "gode_rect_wgrad_f32")
         if mw == M:
@@ -510,8 +514,7 @@ def gemm(A, B, trans_a=False, trans_b=False, bias=None, relu=False, mask=None, o
         if parts > 1:                                  # tall contraction, few output tiles (weight gradients of small layers)
             part = torch.empty(parts, M * N, dtype=torch.float32, device=A.device)
             check(lib.gode_gemm_splitk_f32(1 if trans_a else 0, 1 if trans_b else 0, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(part),
-                                           stream_ptr()), "gode_gemm_splitk_f32")
-            reduce_parts_(out.view(-1), part)
+                                           ptr(out), stream_ptr()), "gode_gemm_splitk_f32")
             return out
     check(lib.gode_gemm_f32(1 if trans_a else 0, 1 if trans_b else 0, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(out), ldc,
                             ptr(bias), 1 if relu else 0, ptr(mask), ldm, stream_ptr()), "gode_gemm_f32")

@@ -37,12 +37,22 @@ class Adam(torch.optim.Optimizer):
         """Launch plan of one group for the parameters that have a gradient: argument blocks of <= 64 tensors with their
         chunk lists.  Rebuilt when the set of tensors or one of their addresses changes (host-side bookkeeping only)."""
         lib = _lib.load()
-        # the argument blocks bake in the addresses of all four arrays of a tensor: all four are part of the key
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel(), self.state[p]["exp_avg"].data_ptr(),
-                     self.state[p]["exp_avg_sq"].data_ptr()) for p in active)
+        # the argument blocks bake in the addresses of all four arrays of a tensor: all four are part of the key.  The
+        # gradients are keyed apart: a loop that DROPS its gradients between steps (zero_grad(set_to_none=True),
+        # qc_train.TrainStep) brings new gradient tensors every step, and then only their addresses are patched into the
+        # blocks - rebuilding the plan (a 1 750-entry work list for the 14.3 M parameters of the QC models) every step cost
+        # more host time than the launches the dropped gradients saved
+        key = tuple((p.data_ptr(), p.numel(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
+                    for p in active)
+        gkey = tuple(p.grad.data_ptr() for p in active)
         hit = self._plans.get(gi)
         dev = active[0].device
         if hit is not None and hit[0] == key:
+            if hit[3] != gkey:
+                for idx, gp in enumerate(gkey):
+                    hit[1][idx // _lib.GODE_ADAM_MAX_TENSORS][0].grad[idx % _lib.GODE_ADAM_MAX_TENSORS] = gp
+                hit = (key, hit[1], hit[2], gkey)
+                self._plans[gi] = hit
             return hit
         state_t = hit[2] if hit is not None else None
         if state_t is None:
@@ -73,7 +83,7 @@ class Adam(torch.optim.Optimizer):
                 ck = torch.tensor(rows, dtype=torch.int64).reshape(-1, 2).to(dev)
                 self.__dict__.setdefault("_chunk_cache", {})[tuple(p.numel() for p in part)] = ck
             blocks.append((args, len(part), ck, len(rows)))
-        plan = (key, blocks, state_t)
+        plan = (key, blocks, state_t, gkey)
         self._plans[gi] = plan
         return plan
 
@@ -110,7 +120,7 @@ class Adam(torch.optim.Optimizer):
                 if "exp_avg" not in st:
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            _, blocks, state_t = self._plan(gi, group, active)
+            _, blocks, state_t, _ = self._plan(gi, group, active)
             b1, b2 = group["betas"]
             check(lib.gode_adam_tick_f32(ctypes.c_void_p(state_t.data_ptr()), float(b1), float(b2), stream_ptr()),
                   "gode_adam_tick_f32")

@@ -244,6 +244,9 @@ int gode_rect_gemm_nt_f32(const float* dS, int64_t ldds, int64_t n_rows, int64_t
 int64_t gode_rect_wgrad_parts(int64_t n_rows);
 int gode_rect_wgrad_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, const float* dS, int64_t ldds,
                         int64_t M, float* part, void* stream);
+/* gode_rect_wgrad_f32 followed by the sum of its partials into dW (K x M, contiguous): one call */
+int gode_rect_wgrad_sum_f32(const float* X, int64_t ldx, int64_t n_rows, int64_t K, const float* dS, int64_t ldds, int64_t M,
+                            float* part, float* dW, void* stream);
 
 /* C[M x N] = op(A) op(B) (+ bias[col]) (relu) (* [mask[row][col] > 0]) on the exact fp32 matrix instruction: the dense
  * products of the QC edge encoder (QC/layers.py:46-86: relu(e W1 + b1) W2 + b2 on the edge rows of a batch, and their
@@ -254,11 +257,12 @@ int gode_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, con
                   const float* mask, int64_t ldmask, void* stream);
 /* The same product for a TALL contraction with few output tiles (gode_gemm_splitk_parts(M, N, K) > 1: at most 64 tiles of
  * 64 x 64 and K >= 192 - the weight gradients x^T dy of small layers): the contraction is cut into that many parts,
- * part[z][M][N] (caller-owned, parts * M * N floats) receives the raw product of part z, and the caller adds them
- * (gode_reduce_parts_f32).  No epilogue.  GODE_E_UNSUPPORTED when gode_gemm_splitk_parts is 1. */
+ * part[z][M][N] (caller-owned, parts * M * N floats) receives the raw product of part z; the parts are added into C by
+ * the same call, or by the caller (gode_reduce_parts_f32) when C is NULL.  No epilogue.  GODE_E_UNSUPPORTED when gode_gemm_splitk_parts is 1. */
 int64_t gode_gemm_splitk_parts(int64_t M, int64_t N, int64_t K);
 int gode_gemm_splitk_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                         const float* B, int64_t ldb, float* part, void* stream);
+                         const float* B, int64_t ldb, float* part, float* C /* nullable: M x N contiguous, receives the sum of
+                         the parts (second launch of the same call) */, void* stream);
 
 /* The same products for LARGE shapes on the bf16 matrix cores, from exact three-way cuts of the fp32 operands
  * (csrc/pgemm.hip; replaces the three 21.6 GFLOP products of the edge encoder, QC/layers.py:46-86 and autograd:
