@@ -18,11 +18,12 @@ Modes:
   "captured"  the batch is padded to its shape bucket (qc_batch.pad_batch: multiples of 64 atoms / 128 edges, one dummy
               graph) and the whole step - conversion, forward, loss, backward, Adam - is ONE HIP-graph replay per
               bucket (qc_step.CapturedQCStep); needs hipgraph.memset_nodes_ok();
-  "auto"      = "prepared".  Measured on never-repeating batches of 20 molecules (tools/config_bench.py, round 4):
-              EdgeGCN_K_Sum eager 2.6 ms / prepared 1.9 ms / captured 2.8 ms per step, MPNN_ENN_K_Set2Set 3.9-4.7 / 3.2 /
-              3.7 ms.  The captured step loses on this platform: replayed memset nodes are only reliable with the HIP
-              runtime's graph fast path OFF (hipgraph.py), and on that path a replay issues its ~300 kernel nodes one by
-              one from the host - no cheaper than the eager launches it replaces - while the padding adds work.
+  "auto"      = "prepared".  Measured on never-repeating batches of 20 molecules (tools/config_bench.py, end of round 4):
+              EdgeGCN_K_Sum eager 1.6-1.8 ms / prepared 1.12 ms / captured 1.23 ms per step, MPNN_ENN_K_Set2Set 1.5-1.8 / 1.29 /
+              1.41 ms.  The captured step still loses on this platform: replayed memset nodes are only reliable with the HIP
+              runtime's graph fast path OFF (hipgraph.py), on that path a replay issues its kernel nodes one by one from the
+              host - its time is the step's kernel time, without the overlap of the eager launches - and the padding adds
+              work.  (On a host too slow to issue ~120 launches per millisecond the captured step is the steadier one.)
 The number of graphs of a batch is taken from `target.shape[0]` (one row per graph, as the reference's collate emits),
 never read back from the device.
 
