@@ -67,14 +67,19 @@ __device__ __forceinline__ float4 lc_load4_self(const LinComb& lc, int64_t idx, 
 // whole wave) or 16 (FOUR rows per wave: from 8 192 rows on the launch is bound by rows in flight - 97 registers allow
 // four waves per SIMD, 4 096 waves on the chip, each a ~4.5 us chain of dependent latencies - Pubmed's 19 717 rows took
 // 26.7 us per launch with a wave per row).
-template <int D, int CG, int GW>
+// (the next-stage arguments travel only with the launches that use them: an rk4 evaluation on Cora is ~8 us of launch-bound
+// work, and 112 more bytes of kernel arguments in each of its 128 launches per step showed in the step time)
+template <bool NEXT> struct NextArgs { LinComb nxt; float* x_next; };
+template <> struct NextArgs<false> {};
+
+template <int D, int CG, int GW, bool NEXT>
 __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                              const float* __restrict__ val, LinComb xin, int n_rows,
                                                              float eps, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ W,
                                                              const float* __restrict__ bias, float t, float alpha,
                                                              LinComb pre, LinComb cot, float* __restrict__ Y2,
-                                                             float* __restrict__ out, LinComb nxt, float* __restrict__ x_next)
+                                                             float* __restrict__ out, NextArgs<NEXT> nx)
 {
     constexpr int LPR = D / 4, SG = GW / LPR, RPW = 64 / GW, PU = 4;   // lanes per row, sub-groups per row, rows per wave, gathers in flight per lane
     __shared__ __attribute__((aligned(16))) float Ws[(D + 1) * D];
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void gcn_feval_small_kernel(const int* __restr
             // the NEXT stage's combined input, row by row (a term that names `out` takes this row's value from the
             // register): the next evaluation then gathers ONE array per neighbour instead of one per term of its stage
             // input - 4.3 terms on average over the six stages of a dopri5 step, and the gather is what this kernel waits for
-            if (x_next) *reinterpret_cast<float4*>(x_next + o) = lc_load4_self(nxt, o, out, y);
+            if constexpr (NEXT) *reinterpret_cast<float4*>(nx.x_next + o) = lc_load4_self(nx.nxt, o, out, y);
         }
         __builtin_amdgcn_wave_barrier();                         // the next row's mrow stores follow these reads
     }
@@ -522,13 +527,17 @@ extern "C" int gode_gcn_feval_small_next_f32(const gode_gcn_odefunc_t* f, const 
     const int cg = small_cg(d, f->groups);
     const dim3 grid((unsigned)feval_blocks(f->n));
     const bool r4 = rows4(f->n);
+    NextArgs<true> nxa; nxa.nxt = lnext; nxa.x_next = x_next;
+    const NextArgs<false> nx0;
 #define GODE_FEV(DV, CGV) if (r4) GODE_FEV_(DV, CGV, 16) else GODE_FEV_(DV, CGV, 64)
-#define GODE_FEV_(DV, CGV, GWV) hipLaunchKernelGGL((gcn_feval_small_kernel<DV, CGV, GWV>), grid, dim3(256), 0, (hipStream_t)stream,         \
+#define GODE_FEV_(DV, CGV, GWV) if (x_next) GODE_FEV__(DV, CGV, GWV, true, nxa) else GODE_FEV__(DV, CGV, GWV, false, nx0)
+#define GODE_FEV__(DV, CGV, GWV, NXV, NXA) hipLaunchKernelGGL((gcn_feval_small_kernel<DV, CGV, GWV, NXV>), grid, dim3(256), 0, (hipStream_t)stream, \
                                              f->A.rowptr, f->A.col, f->A.val, lx, (int)f->n, f->eps, f->gamma, f->beta, f->W,    \
-                                             f->b, t, alpha, lp, lcot, Y2, out, lnext, x_next);
+                                             f->b, t, alpha, lp, lcot, Y2, out, NXA);
     GODE_SMALL_DISPATCH(GODE_FEV)
 #undef GODE_FEV
 #undef GODE_FEV_
+#undef GODE_FEV__
     GODE_LAUNCH_CHECK();
     return 0;
 }
